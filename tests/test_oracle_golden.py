@@ -1,0 +1,69 @@
+"""The oracle (CPU restatement) against the golden vectors recorded from the reference's own
+model files (tools/golden/make_golden.py).  fp32, so the bar is tight: 1e-5 abs / 1e-5 rel."""
+import torch
+
+from oracle import wan_dit as W
+from oracle.schedulers import FlowMatchEulerOracle
+from oracle.wan_pipeline import wan_denoise_loop
+
+TOL = dict(atol=2e-5, rtol=2e-5)
+
+
+def test_wan_rope_tables(golden):
+    _, _, a = golden("wan_rope")
+    f, h, w, d = a["shape"].tolist()
+    cos, sin = W.wan_rope(d, 1024, f, h, w)
+    rows = a["rows"].long()
+    assert torch.equal(cos[0, 0, rows], a["cos"])
+    assert torch.equal(sin[0, 0, rows], a["sin"])
+
+
+def test_wan_attention_self_and_cross(golden):
+    cfg, sd, a = golden("wan_block_tiny")
+    rot = (a["rot_cos"], a["rot_sin"])
+    o = W.wan_attention(sd, "blocks.0.attn1", cfg["num_attention_heads"], cfg["eps"], a["h"], None, rot)
+    torch.testing.assert_close(o, a["a_self"], **TOL)
+    o = W.wan_attention(sd, "blocks.0.attn2", cfg["num_attention_heads"], cfg["eps"], a["h"], a["ctx"], None)
+    torch.testing.assert_close(o, a["a_cross"], **TOL)
+
+
+def test_wan_block_both_temb_ranks(golden):
+    cfg, sd, a = golden("wan_block_tiny")
+    rot = (a["rot_cos"], a["rot_sin"])
+    torch.testing.assert_close(W.wan_block(sd, "blocks.0", cfg, a["h"], a["ctx"], a["temb4"], rot), a["b4"], **TOL)
+    torch.testing.assert_close(W.wan_block(sd, "blocks.0", cfg, a["h"], a["ctx"], a["temb3"], rot), a["b3"], **TOL)
+
+
+def test_wan_forward_scalar_and_per_token_timestep(golden):
+    cfg, sd, a = golden("wan_dit_tiny")
+    for ts, y in (("ts_scalar", "y_scalar"), ("ts_tok", "y_tok"), ("ts_many", "y_many")):
+        out = W.wan_forward(sd, cfg, a["x"], a[ts], a["txt"])
+        torch.testing.assert_close(out, a[y], **TOL)
+
+
+def test_wan_forward_bf16_tolerance(golden):
+    """bf16 reference vs fp32 reference on the same tiny model fixes the stated tolerance for a
+    bf16 forward: rel-RMS <= 2e-2 (random weights with std 0.2 are far harsher than a trained net)."""
+    cfg, sd, a = golden("wan_dit_tiny")
+    _, _, b = golden("wan_dit_tiny_bf16")
+    ref = a["y_tok"]
+    rel = ((b["y_tok_bf16"] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel < 2e-2, rel
+    # the oracle run in bf16 (fp32 islands kept) lands in the same band
+    sdb = {k: (v if any(s in k for s in W.FP32_KEEP) else v.bfloat16()) for k, v in sd.items()}
+    out = W.wan_forward(sdb, cfg, a["x"].bfloat16(), a["ts_tok"], a["txt"].bfloat16()).float()
+    rel2 = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel2 < 2e-2, rel2
+
+
+def test_wan_denoise_loop_matches_reference_pipeline(golden):
+    cfg, sd, a = golden("wan_pipe_tiny")
+    dit_sd = {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}
+    sched = FlowMatchEulerOracle(shift=5.0)
+    steps = int(a["steps"])
+    sched.set_timesteps(steps)
+    torch.testing.assert_close(sched.timesteps, a["timesteps"], atol=1e-4, rtol=1e-6)
+    torch.testing.assert_close(sched.sigmas, a["sigmas"], atol=1e-7, rtol=1e-6)
+    out = wan_denoise_loop(dit_sd, cfg, sched, a["latents0"], a["condition"], a["traj_latents"], a["id_latent"],
+                           a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), steps)
+    torch.testing.assert_close(out, a["out_latents"], atol=1e-4, rtol=1e-4)

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own model files on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference is imported
+unmodified, through the builder-written `diffusers` stand-in in ./diffusers_stub (diffusers
+is not installable offline).  Every fixture stores: the config, the seeded random weights
+(`sd/<reference parameter name>`), the inputs and the reference's outputs.
+
+    python tools/golden/make_golden.py [--only wan_dit,wan_pipe,...]
+
+Fixtures are data only (inputs + expected outputs); no reference source text is stored.
+"""
+import argparse
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(HERE, "diffusers_stub"))
+sys.path.insert(0, "/root/reference")
+os.chdir("/root/reference")  # the reference does sys.path.append(os.path.abspath('.'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def to_np(t):
+    if isinstance(t, torch.Tensor):
+        if t.dtype == torch.bfloat16:
+            return t.float().numpy()
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, cfg=None, sd=None, **arrays):
+    d = {}
+    if cfg is not None:
+        for k, v in cfg.items():
+            d["cfg/" + k] = np.asarray(v if v is not None else -1)
+    if sd is not None:
+        for k, v in sd.items():
+            d["sd/" + k] = to_np(v)
+    for k, v in arrays.items():
+        d[k] = to_np(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def randomize_(module, seed, std=0.2):
+    """Re-initialise every parameter with seeded noise (default inits leave e.g. norm gains at 1 and
+    would hide missing-multiply bugs)."""
+    g = torch.Generator().manual_seed(seed)
+    for n, p in module.named_parameters():
+        if n.endswith("norm_q.weight") or n.endswith("norm_k.weight") or ("norm" in n and n.endswith("weight")) \
+                or n.endswith("gamma"):
+            p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+        elif "scale_shift_table" in n:
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+        else:
+            p.copy_(std * torch.randn(p.shape, generator=g))
+
+
+# ----------------------------------------------------------------------------------- Wan DiT
+WAN_TINY = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=24, in_channels=8, out_channels=4,
+                text_dim=16, freq_dim=32, ffn_dim=64, num_layers=2, cross_attn_norm=True, eps=1e-6,
+                rope_max_seq_len=64)
+
+
+def gen_wan_dit():
+    from architecture.transformer_wan import (WanAttnProcessor2_0, WanRotaryPosEmbed, WanTransformer3DModel,
+                                              WanTransformerBlock)
+
+    # G3: rope tables at the real 704x1280 / 14-frame geometry, sampled rows
+    rope = WanRotaryPosEmbed(128, (1, 2, 2), 1024)
+    cos, sin = rope(torch.zeros(1, 1, 14, 44, 80))
+    rows = torch.tensor([0, 1, 39, 40, 879, 880, 881, 5000, 12319])
+    save("wan_rope", rows=rows, cos=cos[0, 0, rows], sin=sin[0, 0, rows], shape=np.array([14, 22, 40, 128]))
+
+    # G4: tiny full model, scalar / per-token timestep
+    torch.manual_seed(0)
+    m = WanTransformer3DModel(**{k: v for k, v in WAN_TINY.items()}).eval()
+    randomize_(m, 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 8, 3, 8, 12, generator=g)
+    txt = torch.randn(1, 20, 16, generator=g)
+    L = 3 * 4 * 6
+    ts_scalar = torch.tensor([437.0])
+    ts_tok = torch.full((1, L), 437.0)
+    ts_tok[0, : 4 * 6] = 0.0                      # first-frame tokens see t=0 (pipeline :832-843)
+    ts_many = torch.rand(1, L, generator=g) * 1000  # general per-token values
+    y_scalar = m(x, ts_scalar, txt, return_dict=False)[0]
+    y_tok = m(x, ts_tok, txt, return_dict=False)[0]
+    y_many = m(x, ts_many, txt, return_dict=False)[0]
+    save("wan_dit_tiny", cfg=WAN_TINY, sd=m.state_dict(), x=x, txt=txt, ts_scalar=ts_scalar, ts_tok=ts_tok,
+         ts_many=ts_many, y_scalar=y_scalar, y_tok=y_tok, y_many=y_many)
+
+    # G1/G2: one block + its two attention calls in isolation
+    blk = m.blocks[0]
+    h = torch.randn(1, L, 48, generator=g)
+    ctx = torch.randn(1, 20, 48, generator=g)
+    rot = m.rope(x)
+    temb4 = torch.randn(1, L, 6, 48, generator=g) * 0.3
+    temb3 = torch.randn(1, 6, 48, generator=g) * 0.3
+    a_self = blk.attn1(hidden_states=h, rotary_emb=rot)
+    a_cross = blk.attn2(hidden_states=h, encoder_hidden_states=ctx)
+    b4 = blk(h, ctx, temb4, rot)
+    b3 = blk(h, ctx, temb3, rot)
+    sd_blk = {"blocks.0." + k: v for k, v in blk.state_dict().items()}
+    save("wan_block_tiny", cfg=WAN_TINY, sd=sd_blk, h=h, ctx=ctx, rot_cos=rot[0], rot_sin=rot[1], temb4=temb4,
+         temb3=temb3, a_self=a_self, a_cross=a_cross, b4=b4, b3=b3)
+
+    # bf16 variant of G4 (fixes the stated tolerance).  fp32 islands per _keep_in_fp32_modules (:393)
+    mb = WanTransformer3DModel(**{k: v for k, v in WAN_TINY.items()}).eval()
+    mb.load_state_dict(m.state_dict())
+    keep = WanTransformer3DModel._keep_in_fp32_modules
+    for n, p in mb.named_parameters():
+        if not any(k in n for k in keep):
+            p.data = p.data.to(torch.bfloat16)
+    yb = mb(x.bfloat16(), ts_tok, txt.bfloat16(), return_dict=False)[0]
+    save("wan_dit_tiny_bf16", y_tok_bf16=yb)
+
+
+# ----------------------------------------------------------------------------------- Wan pipeline
+def gen_wan_pipe():
+    import PIL.Image
+    from diffusers.schedulers import FlowMatchEulerDiscreteScheduler
+    from architecture.autoencoder_kl_wan import AutoencoderKLWan
+    from architecture.transformer_wan import WanTransformer3DModel
+    from pipelines.pipeline_wan_i2v_motion_FrameINO import WanImageToVideoPipeline
+
+    zdim = 4
+    vae_cfg = dict(base_dim=8, decoder_base_dim=8, z_dim=zdim, dim_mult=[1, 2, 4, 4], num_res_blocks=1,
+                   attn_scales=[], temperal_downsample=[False, True, True], dropout=0.0,
+                   latents_mean=[0.1, -0.2, 0.3, 0.05], latents_std=[1.1, 0.9, 1.3, 0.7], is_residual=True,
+                   in_channels=12, out_channels=12, patch_size=2, scale_factor_temporal=4, scale_factor_spatial=16)
+    torch.manual_seed(0)
+    vae = AutoencoderKLWan(**vae_cfg).eval()
+    randomize_(vae, 11, std=0.15)
+    dit_cfg = dict(WAN_TINY, in_channels=2 * zdim, out_channels=zdim)
+    dit = WanTransformer3DModel(**dit_cfg).eval()
+    randomize_(dit, 12)
+    sched = FlowMatchEulerDiscreteScheduler(shift=5.0)
+    pipe = WanImageToVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, scheduler=sched, transformer=dit,
+                                   expand_timesteps=True)
+
+    H, W, F = 64, 96, 9                      # latent 4x6, 3 latent frames (+1 ID)
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8).numpy()
+    traj = torch.rand(F, 3, H, W, generator=g) * 2 - 1
+    idt = torch.rand(1, 3, 1, H, W, generator=g) * 2 - 1
+    pe = torch.randn(1, 12, 16, generator=g)
+    ne = torch.randn(1, 12, 16, generator=g)
+    lat0 = torch.randn(1, zdim, 3, H // 16, W // 16, generator=g)
+
+    rec = {}
+    orig = pipe.prepare_latents
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        rec["latents"], rec["condition"], rec["traj_latents"], rec["ID_latent"], rec["mask"] = out
+        return out
+
+    pipe.prepare_latents = spy
+    steps = 4
+    out_lat = pipe(image=PIL.Image.fromarray(img), prompt_embeds=pe, negative_prompt_embeds=ne, traj_tensor=traj,
+                   ID_tensor=idt, height=H, width=W, num_frames=F, num_inference_steps=steps, guidance_scale=5.0,
+                   latents=lat0.clone(), output_type="latent").frames
+    out_np = pipe(image=PIL.Image.fromarray(img), prompt_embeds=pe, negative_prompt_embeds=ne, traj_tensor=traj,
+                  ID_tensor=idt, height=H, width=W, num_frames=F, num_inference_steps=steps, guidance_scale=5.0,
+                  latents=lat0.clone(), output_type="np").frames
+    sched.set_timesteps(steps)
+    sd = {"dit." + k: v for k, v in dit.state_dict().items()}
+    sd.update({"vae." + k: v for k, v in vae.state_dict().items()})
+    cfg = dict(dit_cfg)
+    cfg.update({"vae_" + k: v for k, v in vae_cfg.items()})
+    save("wan_pipe_tiny", cfg=cfg, sd=sd, image=img, traj=traj, id_tensor=idt, prompt_embeds=pe, negative_embeds=ne,
+         latents0=lat0, condition=rec["condition"], traj_latents=rec["traj_latents"], id_latent=rec["ID_latent"],
+         mask=rec["mask"], timesteps=sched.timesteps, sigmas=sched.sigmas, out_latents=out_lat, out_video=out_np,
+         steps=np.array(steps), guidance=np.array(5.0))
+
+
+GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for k, fn in GENS.items():
+        if not a.only or k in a.only.split(","):
+            fn()
