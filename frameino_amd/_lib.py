@@ -1,0 +1,71 @@
+"""ctypes binding of libframeino_hip.so (C ABI declared in include/frameino_hip.h).
+
+The product path has no fallback: if the shared library is absent this module raises, and every
+wrapper raises RuntimeError(fino_last_error()) on a non-zero return code."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libframeino_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "frameino_hip.h")
+
+c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "fino_version": [],
+    "fino_last_error": [],
+    "fino_adaln_modulate": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_void_p,
+                            c_float, c_int, c_void_p],
+    "fino_layernorm": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_void_p, c_void_p, c_float, c_int, c_void_p],
+    "fino_gated_residual": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64,
+                            c_void_p, c_int, c_void_p],
+    "fino_rmsnorm_rope": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int,
+                          c_void_p],
+    "fino_headnorm_rope": [c_void_p, c_int, c_i64, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p, c_float,
+                           c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "fino_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 12 + [c_float, c_int, c_void_p],
+    "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
+    "fino_skinny_linear": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
+    "fino_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
+    "fino_unpatchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
+    "fino_wan_model_input": [c_void_p] * 5 + [c_int] * 6 + [c_void_p],
+    "fino_cfg_euler_step": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_int, c_int, c_void_p],
+}
+_RESTYPES = {"fino_last_error": ctypes.c_char_p}
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Every function the public header declares (used by the CPU test that checks the .so exports them)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fino_[a-z0-9_]+)\s*\(", text)))
+
+
+def load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"frameino_amd: HIP library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C frameino_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().fino_last_error().decode()}")

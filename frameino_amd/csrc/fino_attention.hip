@@ -1,0 +1,297 @@
+// Non-causal flash attention forward for the DiT (3D spatio-temporal self-attention, text cross-attention).
+// Replaces F.scaled_dot_product_attention at architecture/transformer_wan.py:108 and
+// architecture/attention_processor.py:2863/:2934 of the reference.
+//
+// CDNA4 design (8-wave structure of the gfx950 playbook, written for this path):
+//   * workgroup = 8 waves = 256 query rows of one (batch, head); each wave owns 32 query rows.
+//   * S^T = K.Q^T ("swapped" product, v_mfma_f32_32x32x16): the query index sits on the lane, so the online
+//     softmax is lane-local (row max/sum = 32 registers + one permlane32_swap with the partner half-wave).
+//   * O^T = V^T.P^T: the S^T accumulator registers, packed to bf16, ARE the B operand of the second product
+//     (k-order permuted: element j of half h is key 16s + 8(j>>2) + 4h + (j&3)); V^T comes from LDS through
+//     ds_read_b64_tr_b16 in the same permuted order -- no cross-lane movement of P, no LDS round trip for P.
+//   * K/V tiles of 64 keys are register-staged (global_load_dwordx4 issued before the tile's math, ds_write_b128
+//     after it) into a double-buffered, XOR-swizzled LDS image that is conflict-free for both the row reads (K)
+//     and the transposed reads (V); one barrier per tile.
+//   * q/k/v are read in place from the fused-QKV GEMM output ([L, 3*H*Dh], strides passed in), o is written
+//     token-major [L, H*Dh]: no transposes anywhere.
+//   * blockIdx -> (head, q-block) is XCD-aware: all q-blocks of a head share blockIdx%8, i.e. one XCD's L2 holds
+//     that head's K/V while its 32 CUs sweep it.
+#include "fino_common.h"
+
+namespace {
+
+struct AttnParams {
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* v;
+    uint16_t* o;
+    int batch, heads;
+    int lq, lk;
+    int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
+    float scale_log2;
+    int nqb;  // q blocks per head
+};
+
+constexpr int kQRowsPerWave = 32;
+constexpr int kWaves = 8;
+constexpr int kQBlock = kQRowsPerWave * kWaves;  // 256
+constexpr int kKV = 64;
+
+// Byte offset of 16-byte chunk `ch` of row `row` inside a [kKV][D] tile.
+//  D=128 (256-B rows): ch ^ (((row&3)<<2) | ((row>>2)&3))
+//  D=64  (128-B rows): ch ^ (((row&3)<<1) | ((row>>2)&1))       (8 chunks per row)
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int ch) {
+    if constexpr (D == 128) {
+        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    } else {
+        return row * 128 + ((ch ^ (((row & 3) << 1) | ((row >> 2) & 1))) << 4);
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kTileBytes = kKV * D * 2;
+    constexpr int kChunksPerRow = D / 8;
+    constexpr int kLoadsPerThread = (kKV * kChunksPerRow) / (kWaves * 64);  // 2 (D=128) or 1 (D=64)
+    constexpr int kKS = D / 16;                                             // k-steps of QK^T
+    constexpr int kDT = D / 32;                                             // d-tiles of O^T
+    typedef typename T::vec8 vec8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- XCD-aware block -> (head-batch, q-block) ----
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int hb = xcd + 8 * (slot / p.nqb);
+    const int qb = slot % p.nqb;
+    if (hb >= p.batch * p.heads) return;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
+    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+    vec8 qf[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        qf[ks] = __builtin_bit_cast(vec8, u);
+    }
+
+    // ---- staging roles ----
+    int st_row[kLoadsPerThread], st_ch[kLoadsPerThread];
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        const int cid = tid + i * (kWaves * 64);
+        st_row[i] = cid / kChunksPerRow;
+        st_ch[i] = cid % kChunksPerRow;
+    }
+    // NOTE: plain macros over named arrays (lambdas capturing the staging arrays sent them to scratch).
+    u32x4_t kreg[kLoadsPerThread], vreg[kLoadsPerThread];
+    int st_off[kLoadsPerThread];
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) st_off[i] = lds_off<D>(st_row[i], st_ch[i]);
+#define STAGE_LOAD(T_)                                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
+        int row_ = (T_) * kKV + st_row[i_];                                                           \
+        row_ = row_ < p.lk ? row_ : p.lk - 1;                                                         \
+        kreg[i_] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)row_ * p.k_rs + st_ch[i_] * 8);      \
+        vreg[i_] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)row_ * p.v_rs + st_ch[i_] * 8);      \
+    }
+#define STAGE_WRITE(BUF_)                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
+        *reinterpret_cast<u32x4_t*>(smem + (BUF_) * kTileBytes + st_off[i_]) = kreg[i_];                \
+        *reinterpret_cast<u32x4_t*>(smem + (2 + (BUF_)) * kTileBytes + st_off[i_]) = vreg[i_];          \
+    }
+
+    // ---- per-lane LDS read addressing ----
+    // K row read (A operand): row = r (+32), chunk = 2*ks + h
+    // V transposed read: 16-lane group g16 = lane>>4; inside it lane 4q+p supplies row q, columns 4p..4p+3.
+    const int tq = (lane & 15) >> 2;
+    const int tp = lane & 3;
+    const int g1 = (lane >> 4) & 1;
+
+    f32x16_t o[kDT];
+#pragma unroll
+    for (int i = 0; i < kDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+
+    const int nt = (p.lk + kKV - 1) / kKV;
+    STAGE_LOAD(0)
+    STAGE_WRITE(0)
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) { STAGE_LOAD(t + 1) }
+
+        // ---------------- S^T = K . Q^T ----------------
+        const char* kb = smem + cur * kTileBytes;
+        f32x16_t s0, s1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(kb + lds_off<D>(r, 2 * ks + h));
+            const uint4 a1 = *reinterpret_cast<const uint4*>(kb + lds_off<D>(32 + r, 2 * ks + h));
+            s0 = T::mfma32(__builtin_bit_cast(vec8, a0), qf[ks], s0);
+            s1 = T::mfma32(__builtin_bit_cast(vec8, a1), qf[ks], s1);
+        }
+        // rows of the 32x32 accumulator: key = (j&3) + 8*(j>>2) + 4*h
+        if (t == nt - 1 && (p.lk & (kKV - 1))) {
+            const int kbase = t * kKV + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int key = kbase + (j & 3) + 8 * (j >> 2);
+                if (key >= p.lk) s0[j] = -INFINITY;
+                if (key + 32 >= p.lk) s1[j] = -INFINITY;
+            }
+        }
+
+        // ---------------- online softmax (query on the lane) ----------------
+        float mx = s0[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, s0[j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s1[j]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mx * p.scale_log2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            s0[j] = __builtin_amdgcn_exp2f(s0[j] * p.scale_log2 - m_new);
+            s1[j] = __builtin_amdgcn_exp2f(s1[j] * p.scale_log2 - m_new);
+            psum += s0[j] + s1[j];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < kDT; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+
+        // ---------------- O^T += V^T . P^T ----------------
+        const char* vb = smem + (2 + cur) * kTileBytes;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                vec8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = kt == 0 ? s0[8 * s2 + j] : s1[8 * s2 + j];
+                    pb[j] = (typename T::scalar)pv;
+                }
+                const int key0 = kt * 32 + 16 * s2 + 4 * h + tq;
+#pragma unroll
+                for (int dt = 0; dt < kDT; ++dt) {
+                    const int ch = dt * 4 + 2 * g1 + (tp >> 1);
+                    const int a_lo = lds_off<D>(key0, ch) + 8 * (tp & 1);
+                    const int a_hi = lds_off<D>(key0 + 8, ch) + 8 * (tp & 1);
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_lo));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_hi));
+                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                    const s16x8_t va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = T::mfma32(__builtin_bit_cast(vec8, va), pb, o[dt]);
+                }
+            }
+        }
+
+        if (t + 1 < nt) { STAGE_WRITE(cur ^ 1) }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: normalise, store O[q][d] ----------------
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l_run;
+    if (qrow < p.lq) {
+        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
+                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+            }
+        }
+    }
+}
+
+template <typename T, int D>
+int launch_attn(const AttnParams& p, hipStream_t st) {
+    constexpr int smem = 4 * kKV * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            fino_set_error("fino_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return FINO_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int hb = p.batch * p.heads;
+    const int groups = (hb + 7) / 8;
+    const dim3 grid((unsigned)(8 * groups * p.nqb));
+    attn_fwd_kernel<T, D><<<grid, kWaves * 64, smem, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+}  // namespace
+
+extern "C" int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                             int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
+                             int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
+                             int64_t o_rs, int64_t o_hs, float scale, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_fwd: dtype %d", dtype);
+    FINO_CHECK(q && k && v && o, FINO_ERR_ARG, "fino_attn_fwd: null pointer");
+    FINO_CHECK(batch > 0 && heads > 0 && lq >= 0 && lk > 0, FINO_ERR_ARG,
+               "fino_attn_fwd: bad shape B=%d H=%d Lq=%lld Lk=%lld", batch, heads, (long long)lq, (long long)lk);
+    FINO_CHECK(head_dim == 128 || head_dim == 64, FINO_ERR_UNSUPPORTED,
+               "fino_attn_fwd: head_dim %d not in {64,128}", head_dim);
+    FINO_CHECK(lq < (1ll << 31) - 256 && lk < (1ll << 31) - 64, FINO_ERR_ARG, "fino_attn_fwd: sequence too long");
+    FINO_CHECK(fino_aligned16(q) && fino_aligned16(k) && fino_aligned16(v) && fino_aligned16(o) && q_rs % 8 == 0 &&
+                   k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 &&
+                   v_hs % 8 == 0 && o_hs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0,
+               FINO_ERR_ARG, "fino_attn_fwd: pointers and strides must be 16-byte aligned");
+    FINO_CHECK(scale > 0.f, FINO_ERR_ARG, "fino_attn_fwd: scale must be > 0");
+    if (lq == 0) return FINO_OK;
+    AttnParams p;
+    p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o;
+    p.batch = batch; p.heads = heads; p.lq = (int)lq; p.lk = (int)lk;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs;
+    p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs; p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = o_hs;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        return head_dim == 128 ? launch_attn<BF16, 128>(p, st) : launch_attn<BF16, 64>(p, st);
+    return head_dim == 128 ? launch_attn<F16, 128>(p, st) : launch_attn<F16, 64>(p, st);
+}

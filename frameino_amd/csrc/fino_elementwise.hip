@@ -1,0 +1,573 @@
+// HBM-bound kernels of the DiT forward: LayerNorm+AdaLN modulate, gated residual, RMSNorm(all heads)+RoPE,
+// per-head LayerNorm+RoPE (CogVideoX), patchify/unpatchify gathers, sampler glue.
+//
+// Design (MI355X): one 64-lane wave owns one token row; a lane moves 16 B (8 elements) per access, the row stays in
+// registers between the statistics pass and the apply pass, so every tensor is read once and written once
+// (algorithmic bytes = 2*rows*dim*2 B per pass).  4 waves per workgroup, rows*... >> 256 workgroups.
+// Built with -ffp-contract=off: the rounding points are the reference's (mul, mul, sub -- not fma).
+#include <type_traits>
+
+#include "fino_common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxPasses = 8;  // dim <= 8 * 512 = 4096
+
+template <typename T, int NP>
+struct RowRegs {
+    float v[NP][8];
+};
+
+template <typename T, int NP>
+__device__ __forceinline__ void load_row(const uint16_t* __restrict__ p, int dim, int lane, float (&v)[NP][8]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < dim) {
+            const uint4 u = *reinterpret_cast<const uint4*>(p + c);
+            unpack8<T>(u, v[i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void ln_stats(const float (&v)[NP][8], int dim, int lane, float eps, float& mean,
+                                         float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+    mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < dim) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)dim;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MODE 0: y = LN(x)*(1+scale)+shift (table rows), MODE 1: y = LN(x)*w+b (w/b may be null)
+template <typename T, int NP, int MODE>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+    const float* __restrict__ p_shift, const float* __restrict__ p_scale, int64_t mod_stride,
+    const int32_t* __restrict__ sel, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NP][8];
+    load_row<T, NP>(x + row * ldx, dim, lane, v);
+    float mean, rstd;
+    ln_stats<NP>(v, dim, lane, eps, mean, rstd);
+    const int64_t moff = (MODE == 0 && sel) ? (int64_t)sel[row] * mod_stride : 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c >= dim) continue;
+        float o[8];
+        float a[8], b[8];
+        if (MODE == 0 || p_scale) {
+            const float4 a0 = *reinterpret_cast<const float4*>(p_scale + moff + c);
+            const float4 a1 = *reinterpret_cast<const float4*>(p_scale + moff + c + 4);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+        }
+        if (MODE == 0 || p_shift) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p_shift + moff + c);
+            const float4 b1 = *reinterpret_cast<const float4*>(p_shift + moff + c + 4);
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = (v[i][j] - mean) * rstd;
+            if (MODE == 0) {
+                o[j] = n * (1.0f + a[j]) + b[j];
+            } else {
+                float t = n;
+                if (p_scale) t = t * a[j];
+                if (p_shift) t = t + b[j];
+                o[j] = t;
+            }
+        }
+        *reinterpret_cast<uint4*>(y + row * ldy + c) = pack8<T>(o);
+    }
+}
+
+// out = T(float(x) + float(y)*gate) or T(x + y)
+template <typename T>
+__global__ __launch_bounds__(256) void gated_residual_kernel(const uint16_t* __restrict__ x,
+                                                             const uint16_t* __restrict__ y,
+                                                             uint16_t* __restrict__ out, int64_t rows, int dim,
+                                                             int64_t ldx, int64_t ldy, int64_t ldo,
+                                                             const float* __restrict__ gate, int64_t mod_stride,
+                                                             const int32_t* __restrict__ sel) {
+    const int chunks = dim >> 3;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / chunks;
+        const int c = (int)(i - row * chunks) * 8;
+        float a[8], b[8], o[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(x + row * ldx + c), a);
+        unpack8<T>(*reinterpret_cast<const uint4*>(y + row * ldy + c), b);
+        if (gate) {
+            const float* g = gate + (sel ? (int64_t)sel[row] * mod_stride : 0) + c;
+            const float4 g0 = *reinterpret_cast<const float4*>(g);
+            const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = a[j] + b[j] * gg[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = a[j] + b[j];
+        }
+        *reinterpret_cast<uint4*>(out + row * ldo + c) = pack8<T>(o);
+    }
+}
+
+// RMSNorm over the full row + weight (T) + RoPE, in place.  grid.y selects nothing; one wave per row.
+template <typename T, int NP>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint16_t* __restrict__ x, int64_t rows,
+                                                                           int dim, int64_t ldx,
+                                                                           const uint16_t* __restrict__ w, float eps,
+                                                                           const float* __restrict__ cos_t,
+                                                                           const float* __restrict__ sin_t,
+                                                                           int head_dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NP][8];
+    load_row<T, NP>(x + row * ldx, dim, lane, v);
+    float rs = 1.f;
+    if (w) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += v[i][j] * v[i][j];
+        const float var = wave_sum(q) / (float)dim;
+        rs = 1.0f / sqrtf(var + eps);
+    }
+    const int half = head_dim >> 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c >= dim) continue;
+        float o[8];
+        if (w) {
+            float ww[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(w + c), ww);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = round_to<T>(round_to<T>(v[i][j] * rs) * ww[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[i][j];
+        }
+        if (cos_t) {
+            const int pidx = (c % head_dim) >> 1;  // first of 4 pairs
+            const float4 cs = *reinterpret_cast<const float4*>(cos_t + row * half + pidx);
+            const float4 sn = *reinterpret_cast<const float4*>(sin_t + row * half + pidx);
+            const float cc[4] = {cs.x, cs.y, cs.z, cs.w};
+            const float ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x1 = o[2 * j], x2 = o[2 * j + 1];
+                o[2 * j] = x1 * cc[j] - x2 * ss[j];
+                o[2 * j + 1] = x1 * ss[j] + x2 * cc[j];
+            }
+        }
+        *reinterpret_cast<uint4*>(x + row * ldx + c) = pack8<T>(o);
+    }
+}
+
+// CogVideoX: per-head LayerNorm(head_dim) (affine, T params; statistics fp32, output rounded to T) then RoPE
+// out = T(float(x)*cos + float(rot(x))*sin) on rows >= rope_row0.  One lane owns 8 channels; a head spans
+// head_dim/8 consecutive lanes (8 for 64, 16 for 128) -> xor-shuffle reduction inside the group.
+template <typename T>
+__global__ __launch_bounds__(256) void headnorm_rope_kernel(uint16_t* __restrict__ x, int batch, int64_t rows,
+                                                            int heads, int head_dim, int64_t ldx,
+                                                            int64_t batch_stride, const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ b, float eps,
+                                                            const float* __restrict__ cos_t,
+                                                            const float* __restrict__ sin_t, int64_t rope_row0) {
+    const int lanes_per_head = head_dim >> 3;
+    const int64_t chunks_per_row = (int64_t)heads * lanes_per_head;
+    const int64_t total = (int64_t)batch * rows * chunks_per_row;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < total;
+    const int64_t ii = active ? i : total - 1;
+    const int64_t br = ii / chunks_per_row;
+    const int cw = (int)(ii - br * chunks_per_row);
+    const int64_t bi = br / rows;
+    const int64_t row = br - bi * rows;
+    const int cin = (cw % lanes_per_head) * 8;  // channel inside the head
+    uint16_t* p = x + bi * batch_stride + row * ldx + (int64_t)cw * 8;
+    float v[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(p), v);
+    if (w) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+        for (int off = lanes_per_head >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)head_dim;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[j] - mean;
+            q += d * d;
+        }
+        for (int off = lanes_per_head >> 1; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)head_dim + eps);
+        float ww[8], bb[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(w + cin), ww);
+        unpack8<T>(*reinterpret_cast<const uint4*>(b + cin), bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = round_to<T>((v[j] - mean) * rstd * ww[j] + bb[j]);
+    }
+    if (cos_t && row >= rope_row0) {
+        const float* cp = cos_t + (row - rope_row0) * head_dim + cin;
+        const float* sp = sin_t + (row - rope_row0) * head_dim + cin;
+        float cc[8], ss[8];
+        *reinterpret_cast<float4*>(cc) = *reinterpret_cast<const float4*>(cp);
+        *reinterpret_cast<float4*>(cc + 4) = *reinterpret_cast<const float4*>(cp + 4);
+        *reinterpret_cast<float4*>(ss) = *reinterpret_cast<const float4*>(sp);
+        *reinterpret_cast<float4*>(ss + 4) = *reinterpret_cast<const float4*>(sp + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xr = v[2 * j], xi = v[2 * j + 1];
+            o[2 * j] = xr * cc[2 * j] + (-xi) * ss[2 * j];
+            o[2 * j + 1] = xi * cc[2 * j + 1] + xr * ss[2 * j + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = o[j];
+    }
+    if (active) *reinterpret_cast<uint4*>(p) = pack8<T>(v);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// patchify: a[token][((c*pt+dt)*ph+dh)*pw+dw] = x[c][f*pt+dt][i*ph+dh][j*pw+dw]; thread = one (token, c, dt, dh)
+// run of pw elements.  Tokens vary fastest across threads so the global reads walk W contiguously.
+__global__ __launch_bounds__(256) void patchify_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ a,
+                                                       int C, int F, int H, int W, int pt, int ph, int pw,
+                                                       int64_t lda) {
+    const int ppf = F / pt, pph = H / ph, ppw = W / pw;
+    const int64_t L = (int64_t)ppf * pph * ppw;
+    const int64_t runs = (int64_t)C * pt * ph;
+    const int64_t total = L * runs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tok = i % L;
+        const int64_t run = i / L;  // (c*pt+dt)*ph+dh
+        const int dh = (int)(run % ph);
+        const int dt = (int)((run / ph) % pt);
+        const int c = (int)(run / ((int64_t)ph * pt));
+        const int j = (int)(tok % ppw);
+        const int ii = (int)((tok / ppw) % pph);
+        const int f = (int)(tok / ((int64_t)ppw * pph));
+        const uint16_t* src = x + (((int64_t)c * F + (f * pt + dt)) * H + (ii * ph + dh)) * W + (int64_t)j * pw;
+        uint16_t* dst = a + tok * lda + run * pw;
+        for (int d = 0; d < pw; ++d) dst[d] = src[d];
+    }
+}
+
+// unpatchify: out[c][f*pt+dt][i*ph+dh][j*pw+dw] = y[token][((dt*ph+dh)*pw+dw)*Cout + c]
+__global__ __launch_bounds__(256) void unpatchify_kernel(const uint16_t* __restrict__ y, uint16_t* __restrict__ out,
+                                                         int Cout, int F, int H, int W, int pt, int ph, int pw,
+                                                         int64_t ldy) {
+    const int pph = H / ph, ppw = W / pw;
+    const int64_t total = (int64_t)Cout * F * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int f = (int)((i / ((int64_t)W * H)) % F);
+        const int c = (int)(i / ((int64_t)W * H * F));
+        const int64_t tok = ((int64_t)(f / pt) * pph + h / ph) * ppw + w / pw;
+        const int col = (((f % pt) * ph + (h % ph)) * pw + (w % pw)) * Cout + c;
+        out[i] = y[tok * ldy + col];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void wan_model_input_kernel(const float* __restrict__ lat,
+                                                              const float* __restrict__ cond,
+                                                              const float* __restrict__ idl,
+                                                              const float* __restrict__ traj,
+                                                              uint16_t* __restrict__ out, int C, int Fg, int Fid,
+                                                              int HW) {
+    const int Ft = Fg + Fid;
+    const int64_t total = (int64_t)2 * C * Ft * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % HW);
+        const int f = (int)((i / HW) % Ft);
+        const int c = (int)(i / ((int64_t)HW * Ft));
+        float v;
+        if (c < C) {
+            if (f < Fg) {
+                // (1-m)*cond + m*lat with m in {0,1}: evaluates exactly like the reference's fp32 blend
+                const float m = f == 0 ? 0.f : 1.f;
+                v = (1.f - m) * cond[(int64_t)c * HW + s] + m * lat[((int64_t)c * Fg + f) * HW + s];
+            } else {
+                v = idl[((int64_t)c * Fid + (f - Fg)) * HW + s];
+            }
+        } else {
+            v = traj[((int64_t)(c - C) * Ft + f) * HW + s];
+        }
+        out[i] = T::from_f32(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restrict__ pc,
+                                                        const uint16_t* __restrict__ pu, float* __restrict__ lat,
+                                                        int C, int Fg, int Ft, int HW, float g,
+                                                        const float* __restrict__ dt_dev, int round_out) {
+    const float dt = *dt_dev;
+    const int64_t total = (int64_t)C * Fg * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % HW);
+        const int f = (int)((i / HW) % Fg);
+        const int c = (int)(i / ((int64_t)HW * Fg));
+        const int64_t pi = ((int64_t)c * Ft + f) * HW + s;
+        float n = T::to_f32(pc[pi]);
+        if (pu) {
+            const float u = T::to_f32(pu[pi]);
+            n = round_to<T>(u + round_to<T>(g * round_to<T>(n - u)));
+        }
+        float v = lat[i] + dt * n;
+        if (round_out) v = round_to<T>(v);
+        lat[i] = v;
+    }
+}
+
+template <int NPmax, typename F>
+inline bool dispatch_np(int dim, F&& f) {
+    const int np = (dim + 511) / 512;
+    switch (np) {
+        case 1: f(std::integral_constant<int, 1>{}); return true;
+        case 2: f(std::integral_constant<int, 2>{}); return true;
+        case 3: f(std::integral_constant<int, 3>{}); return true;
+        case 4: f(std::integral_constant<int, 4>{}); return true;
+        case 5: f(std::integral_constant<int, 5>{}); return true;
+        case 6: f(std::integral_constant<int, 6>{}); return true;
+        case 7: f(std::integral_constant<int, 7>{}); return true;
+        case 8: f(std::integral_constant<int, 8>{}); return true;
+        default: return false;
+    }
+}
+
+inline int grid_1d(int64_t total, int block = 256) {
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = 256 * 8;  // ~8 blocks per CU, grid-stride the rest
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <int MODE>
+int launch_ln(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy, const float* shift,
+              const float* scale, int64_t mod_stride, const int32_t* sel, float eps, int dtype, hipStream_t st) {
+    const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+    const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
+        constexpr int NP = decltype(np)::value;
+        if (dtype == FINO_BF16)
+            ln_modulate_kernel<BF16, NP, MODE><<<grid, block, 0, st>>>((const uint16_t*)x, (uint16_t*)y, rows, dim,
+                                                                     ldx, ldy, shift, scale, mod_stride, sel, eps);
+        else
+            ln_modulate_kernel<F16, NP, MODE><<<grid, block, 0, st>>>((const uint16_t*)x, (uint16_t*)y, rows, dim,
+                                                                    ldx, ldy, shift, scale, mod_stride, sel, eps);
+    });
+    FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "layernorm: dim %d > %d unsupported", dim, kMaxPasses * 512);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+}  // namespace
+
+#define CHECK_ROWS_DIM(fn)                                                                                    \
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, fn ": dtype %d", dtype);                \
+    FINO_CHECK(rows >= 0 && dim > 0 && dim % 8 == 0, FINO_ERR_ARG, fn ": rows=%lld dim=%d (dim %% 8 != 0)",   \
+               (long long)rows, dim);                                                                         \
+    if (rows == 0) return FINO_OK;
+
+extern "C" int fino_adaln_modulate(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                                   const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel,
+                                   float eps, int dtype, void* stream) {
+    CHECK_ROWS_DIM("fino_adaln_modulate");
+    FINO_CHECK(x && y && shift && scale, FINO_ERR_ARG, "fino_adaln_modulate: null pointer");
+    FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && mod_stride % 4 == 0 && fino_aligned16(x) && fino_aligned16(y) &&
+                   fino_aligned16(shift) && fino_aligned16(scale),
+               FINO_ERR_ARG, "fino_adaln_modulate: 16-byte alignment required");
+    return launch_ln<0>(x, y, rows, dim, ldx, ldy, shift, scale, mod_stride, sel, eps, dtype, (hipStream_t)stream);
+}
+
+extern "C" int fino_layernorm(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                              const float* w, const float* b, float eps, int dtype, void* stream) {
+    CHECK_ROWS_DIM("fino_layernorm");
+    FINO_CHECK(x && y, FINO_ERR_ARG, "fino_layernorm: null pointer");
+    FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && fino_aligned16(x) && fino_aligned16(y) && fino_aligned16(w) &&
+                   fino_aligned16(b),
+               FINO_ERR_ARG, "fino_layernorm: 16-byte alignment required");
+    return launch_ln<1>(x, y, rows, dim, ldx, ldy, b, w, 0, nullptr, eps, dtype, (hipStream_t)stream);
+}
+
+extern "C" int fino_gated_residual(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx,
+                                   int64_t ldy, int64_t ldo, const float* gate, int64_t mod_stride,
+                                   const int32_t* sel, int dtype, void* stream) {
+    CHECK_ROWS_DIM("fino_gated_residual");
+    FINO_CHECK(x && y && out, FINO_ERR_ARG, "fino_gated_residual: null pointer");
+    FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && mod_stride % 4 == 0 && fino_aligned16(x) &&
+                   fino_aligned16(y) && fino_aligned16(out) && fino_aligned16(gate),
+               FINO_ERR_ARG, "fino_gated_residual: 16-byte alignment required");
+    const int grid = grid_1d(rows * (dim / 8));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        gated_residual_kernel<BF16><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)y, (uint16_t*)out,
+                                                          rows, dim, ldx, ldy, ldo, gate, mod_stride, sel);
+    else
+        gated_residual_kernel<F16><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)y, (uint16_t*)out,
+                                                         rows, dim, ldx, ldy, ldo, gate, mod_stride, sel);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                                 const float* cos_t, const float* sin_t, int head_dim, int dtype, void* stream) {
+    CHECK_ROWS_DIM("fino_rmsnorm_rope");
+    FINO_CHECK(x, FINO_ERR_ARG, "fino_rmsnorm_rope: null pointer");
+    FINO_CHECK((cos_t == nullptr) == (sin_t == nullptr), FINO_ERR_ARG, "fino_rmsnorm_rope: cos/sin must both be set");
+    FINO_CHECK(!cos_t || (head_dim > 0 && head_dim % 8 == 0 && dim % head_dim == 0), FINO_ERR_ARG,
+               "fino_rmsnorm_rope: head_dim=%d must divide dim=%d and be a multiple of 8", head_dim, dim);
+    FINO_CHECK(ldx % 8 == 0 && fino_aligned16(x) && fino_aligned16(weight) && fino_aligned16(cos_t) &&
+                   fino_aligned16(sin_t),
+               FINO_ERR_ARG, "fino_rmsnorm_rope: 16-byte alignment required");
+    const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
+        constexpr int NP = decltype(np)::value;
+        if (dtype == FINO_BF16)
+            rmsnorm_rope_kernel<BF16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx,
+                                                                  (const uint16_t*)weight, eps, cos_t, sin_t, head_dim);
+        else
+            rmsnorm_rope_kernel<F16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx,
+                                                                 (const uint16_t*)weight, eps, cos_t, sin_t, head_dim);
+    });
+    FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "fino_rmsnorm_rope: dim %d > %d unsupported", dim, kMaxPasses * 512);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx,
+                                  int64_t batch_stride, const void* w, const void* b, float eps, const float* cos_t,
+                                  const float* sin_t, int64_t rope_row0, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_headnorm_rope: dtype %d", dtype);
+    FINO_CHECK(x && batch >= 0 && rows >= 0 && heads > 0, FINO_ERR_ARG, "fino_headnorm_rope: bad shape");
+    FINO_CHECK(head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128, FINO_ERR_UNSUPPORTED,
+               "fino_headnorm_rope: head_dim %d not in {16,32,64,128}", head_dim);
+    FINO_CHECK((w == nullptr) == (b == nullptr) && (cos_t == nullptr) == (sin_t == nullptr), FINO_ERR_ARG,
+               "fino_headnorm_rope: w/b and cos/sin come in pairs");
+    FINO_CHECK(ldx % 8 == 0 && batch_stride % 8 == 0 && fino_aligned16(x) && fino_aligned16(w) && fino_aligned16(b) &&
+                   fino_aligned16(cos_t) && fino_aligned16(sin_t),
+               FINO_ERR_ARG, "fino_headnorm_rope: 16-byte alignment required");
+    const int64_t total = (int64_t)batch * rows * heads * (head_dim / 8);
+    if (total == 0) return FINO_OK;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        headnorm_rope_kernel<BF16><<<grid, 256, 0, st>>>((uint16_t*)x, batch, rows, heads, head_dim, ldx, batch_stride,
+                                                         (const uint16_t*)w, (const uint16_t*)b, eps, cos_t, sin_t,
+                                                         rope_row0);
+    else
+        headnorm_rope_kernel<F16><<<grid, 256, 0, st>>>((uint16_t*)x, batch, rows, heads, head_dim, ldx, batch_stride,
+                                                        (const uint16_t*)w, (const uint16_t*)b, eps, cos_t, sin_t,
+                                                        rope_row0);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_patchify(const void* x, void* a, int channels, int frames, int height, int width, int pt, int ph,
+                             int pw, int64_t lda, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_patchify: dtype %d", dtype);
+    FINO_CHECK(x && a && channels > 0 && pt > 0 && ph > 0 && pw > 0, FINO_ERR_ARG, "fino_patchify: bad arguments");
+    FINO_CHECK(frames % pt == 0 && height % ph == 0 && width % pw == 0, FINO_ERR_ARG,
+               "fino_patchify: (%d,%d,%d) not divisible by patch (%d,%d,%d)", frames, height, width, pt, ph, pw);
+    FINO_CHECK(lda >= (int64_t)channels * pt * ph * pw, FINO_ERR_ARG, "fino_patchify: lda too small");
+    const int64_t total = (int64_t)channels * frames * height * width / pw;
+    if (total == 0) return FINO_OK;
+    patchify_kernel<<<grid_1d(total), 256, 0, (hipStream_t)stream>>>((const uint16_t*)x, (uint16_t*)a, channels,
+                                                                     frames, height, width, pt, ph, pw, lda);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_unpatchify(const void* y, void* out, int cout, int frames, int height, int width, int pt, int ph,
+                               int pw, int64_t ldy, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_unpatchify: dtype %d", dtype);
+    FINO_CHECK(y && out && cout > 0 && pt > 0 && ph > 0 && pw > 0, FINO_ERR_ARG, "fino_unpatchify: bad arguments");
+    FINO_CHECK(frames % pt == 0 && height % ph == 0 && width % pw == 0, FINO_ERR_ARG,
+               "fino_unpatchify: (%d,%d,%d) not divisible by patch (%d,%d,%d)", frames, height, width, pt, ph, pw);
+    FINO_CHECK(ldy >= (int64_t)cout * pt * ph * pw, FINO_ERR_ARG, "fino_unpatchify: ldy too small");
+    const int64_t total = (int64_t)cout * frames * height * width;
+    if (total == 0) return FINO_OK;
+    unpatchify_kernel<<<grid_1d(total), 256, 0, (hipStream_t)stream>>>((const uint16_t*)y, (uint16_t*)out, cout,
+                                                                       frames, height, width, pt, ph, pw, ldy);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_wan_model_input(const float* lat, const float* cond, const float* id_lat, const float* traj,
+                                    void* out, int channels, int gen_frames, int id_frames, int height, int width,
+                                    int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_wan_model_input: dtype %d", dtype);
+    FINO_CHECK(lat && cond && traj && out && (id_frames == 0 || id_lat), FINO_ERR_ARG,
+               "fino_wan_model_input: null pointer");
+    FINO_CHECK(channels > 0 && gen_frames > 0 && id_frames >= 0 && height > 0 && width > 0, FINO_ERR_ARG,
+               "fino_wan_model_input: bad shape");
+    const int64_t total = (int64_t)2 * channels * (gen_frames + id_frames) * height * width;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        wan_model_input_kernel<BF16><<<grid_1d(total), 256, 0, st>>>(lat, cond, id_lat, traj, (uint16_t*)out, channels,
+                                                                     gen_frames, id_frames, height * width);
+    else
+        wan_model_input_kernel<F16><<<grid_1d(total), 256, 0, st>>>(lat, cond, id_lat, traj, (uint16_t*)out, channels,
+                                                                    gen_frames, id_frames, height * width);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_cfg_euler_step(const void* cond_pred, const void* uncond_pred, float* lat, int channels,
+                                   int gen_frames, int total_frames, int height, int width, float guidance,
+                                   const float* dt_dev, int round_out, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_cfg_euler_step: dtype %d", dtype);
+    FINO_CHECK(cond_pred && lat && dt_dev, FINO_ERR_ARG, "fino_cfg_euler_step: null pointer");
+    FINO_CHECK(channels > 0 && gen_frames > 0 && total_frames >= gen_frames && height > 0 && width > 0, FINO_ERR_ARG,
+               "fino_cfg_euler_step: bad shape");
+    const int64_t total = (int64_t)channels * gen_frames * height * width;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        cfg_euler_kernel<BF16><<<grid_1d(total), 256, 0, st>>>((const uint16_t*)cond_pred,
+                                                               (const uint16_t*)uncond_pred, lat, channels, gen_frames,
+                                                               total_frames, height * width, guidance, dt_dev,
+                                                               round_out);
+    else
+        cfg_euler_kernel<F16><<<grid_1d(total), 256, 0, st>>>((const uint16_t*)cond_pred, (const uint16_t*)uncond_pred,
+                                                              lat, channels, gen_frames, total_frames, height * width,
+                                                              guidance, dt_dev, round_out);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}

@@ -1,0 +1,332 @@
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias): the nn.Linear call sites of the DiT (QKV / out / FFN / patch-embed /
+// proj_out), bf16|fp16 operands, fp32 accumulate, fused bias + GELU-tanh + (gated) residual epilogues.
+//
+// CDNA4 design: 256x256 output tile per 8-wave workgroup (2(M) x 4(N) waves, 128x64 per wave), BK = 64,
+// v_mfma_f32_16x16x32 in the swapped orientation D = W_frag . A_frag^T so that every lane ends up with 4
+// consecutive output columns of one row (8-byte packed values).  Operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip) into a double-buffered LDS image whose 16-byte chunks are
+// XOR-swizzled on the SOURCE address (LDS-DMA writes are lane-linear) and on the ds_read_b128 address, which makes
+// the fragment reads bank-conflict free.  The next K-tile's DMA is issued before the current tile's MFMAs.
+// The epilogue stages the bf16 tile through LDS so that global stores (and the fused residual reads) are whole
+// 512-byte rows.  Workgroup ids are remapped per XCD (8 L2s) in 4-tile-high groups for operand reuse in L2.
+// A generic variant (register-staged, predicated, zero-filled) covers ragged K and is used for tiny shapes.
+#include <type_traits>
+
+#include "fino_common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kThreads = 512;
+constexpr int kTileBytes = BM * BK * 2;        // 32 KiB per operand tile
+constexpr int kStageBytes = 2 * kTileBytes;    // A + W
+constexpr int kCsStride = BN * 2 + 16;         // padded epilogue row (bytes)
+constexpr int kSmemBytes = (2 * kStageBytes > BM * kCsStride) ? 2 * kStageBytes : BM * kCsStride;
+
+struct GemmParams {
+    const uint16_t* a;
+    const uint16_t* w;
+    const uint16_t* bias;
+    uint16_t* c;
+    const uint16_t* r;
+    const float* gate;
+    const int32_t* sel;
+    int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+    // 0.5*x*(1+tanh(u)) == x*sigmoid(2u),  u = sqrt(2/pi)*(x + 0.044715 x^3)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+// swizzle of the 16-byte chunk index inside a 128-byte tile row
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <typename T, int EPI, bool GENERIC>
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename T::vec8 vec8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2;  // 0..1
+    const int wn = wave & 3;   // 0..3
+
+    // ---- XCD-aware tile id: contiguous id range per XCD, 4-high groups inside ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    }
+    constexpr int GROUP_M = 4;
+    const int group = id / (GROUP_M * p.tiles_n);
+    const int first_m = group * GROUP_M;
+    const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
+    const int in_group = id - group * GROUP_M * p.tiles_n;
+    const int tm = first_m + in_group % gsz;
+    const int tn = in_group / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    // ---- staging: 4 rounds per operand; wave-instruction = 8 rows x 128 B ----
+    // thread -> (row_in_round = wave*8 + lane>>3, phys chunk = lane&7); LDS byte = round*8192 + tid*16
+    const int srow = wave * 8 + (lane >> 3);
+    const int sch = lane & 7;
+    const uint16_t* a_src[4];
+    const uint16_t* w_src[4];
+    bool a_ok[4], w_ok[4];
+    int sk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = j * 64 + srow;
+        const int lch = sch ^ swz(row);  // logical k-chunk held at this physical slot
+        sk[j] = lch * 8;
+        int64_t gm = m0 + row, gn = n0 + row;
+        a_ok[j] = gm < p.m;
+        w_ok[j] = gn < p.n;
+        if (gm >= p.m) gm = p.m - 1;
+        if (gn >= p.n) gn = p.n - 1;
+        a_src[j] = p.a + gm * p.lda + sk[j];
+        w_src[j] = p.w + gn * p.ldw + sk[j];
+    }
+    auto stage = [&](int buf, int kt) {
+        char* ab = smem + buf * kStageBytes;
+        char* wb = ab + kTileBytes;
+        const int64_t k0 = (int64_t)kt * BK;
+        if constexpr (!GENERIC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_global_load_lds((const FINO_GLB void*)(a_src[j] + k0),
+                                                 (FINO_LDS void*)(ab + j * 8192 + wave * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const FINO_GLB void*)(w_src[j] + k0),
+                                                 (FINO_LDS void*)(wb + j * 8192 + wave * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool kin = k0 + sk[j] < p.k;
+                uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
+                if (kin && a_ok[j]) va = *reinterpret_cast<const uint4*>(a_src[j] + k0);
+                if (kin && w_ok[j]) vw = *reinterpret_cast<const uint4*>(w_src[j] + k0);
+                *reinterpret_cast<uint4*>(ab + j * 8192 + tid * 16) = va;
+                *reinterpret_cast<uint4*>(wb + j * 8192 + tid * 16) = vw;
+            }
+        }
+    };
+
+    // ---- fragment read addressing: row = base + 16*tile + (lane&15), chunk = (4*kk + (lane>>4)) ^ swz(row) ----
+    const int frow = lane & 15;
+    const int pch0 = (lane >> 4) ^ (frow >> 1);  // physical chunk for kk = 0; kk = 1 flips bit 2
+    const int a_base = (wm * 128 + frow) * 128;
+    const int w_base = kTileBytes + (wn * 64 + frow) * 128;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((p.k + BK - 1) / BK);
+    stage(0, 0);
+    __syncthreads();  // (drains the LDS-DMA: vmcnt(0) + barrier)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sb = smem + cur * kStageBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int pch = (pch0 ^ (kk << 2)) << 4;
+            vec8 wf[4], af[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4*>(sb + w_base + j * 2048 + pch));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                af[i] = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4*>(sb + a_base + i * 2048 + pch));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(wf[j], af[i], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
+    // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*128 + i*16 + (lane&15)
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int64_t gn = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + e;
+            if (gn >= p.n) gn = p.n - 1;
+            bv[j][e] = p.bias ? T::to_f32(p.bias[gn]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = acc[i][j][e] + bv[j][e];
+                if (EPI == FINO_EPI_GELU_TANH) y[e] = gelu_tanh_f32(round_to<T>(y[e]));
+            }
+            const uint32_t w0 = (uint32_t)T::from_f32(y[0]) | ((uint32_t)T::from_f32(y[1]) << 16);
+            const uint32_t w1 = (uint32_t)T::from_f32(y[2]) | ((uint32_t)T::from_f32(y[3]) << 16);
+            const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<uint2*>(smem + row * kCsStride + col * 2) = make_uint2(w0, w1);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < (BM * BN / 8) / kThreads; ++it) {
+        const int idx = it * kThreads + tid;
+        const int row = idx >> 5;
+        const int ch = idx & 31;
+        const int64_t gm = m0 + row, gn = n0 + ch * 8;
+        if (gm >= p.m || gn >= p.n) continue;
+        uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
+        if (EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL) {
+            float y[8], rv[8], o[8];
+            unpack8<T>(yv, y);
+            unpack8<T>(*reinterpret_cast<const uint4*>(p.r + gm * p.ldr + gn), rv);
+            if (EPI == FINO_EPI_GATED_RESIDUAL) {
+                const float* g = p.gate + (p.sel ? (int64_t)p.sel[gm] * p.mod_stride : 0) + gn;
+                const float4 g0 = *reinterpret_cast<const float4*>(g);
+                const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e] * gg[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
+            }
+            yv = pack8<T>(o);
+        }
+        *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
+    }
+}
+
+template <typename T, int EPI, bool GENERIC>
+int launch_gemm_t(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, GENERIC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        if (e != hipSuccess) {
+            fino_set_error("fino_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return FINO_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    gemm_kernel<T, EPI, GENERIC><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+template <typename T, bool GENERIC>
+int launch_gemm_e(const GemmParams& p, int epi, hipStream_t st) {
+    switch (epi) {
+        case FINO_EPI_NONE: return launch_gemm_t<T, FINO_EPI_NONE, GENERIC>(p, st);
+        case FINO_EPI_GELU_TANH: return launch_gemm_t<T, FINO_EPI_GELU_TANH, GENERIC>(p, st);
+        case FINO_EPI_RESIDUAL: return launch_gemm_t<T, FINO_EPI_RESIDUAL, GENERIC>(p, st);
+        default: return launch_gemm_t<T, FINO_EPI_GATED_RESIDUAL, GENERIC>(p, st);
+    }
+}
+
+// ---- skinny fp32 linear: one wave per output column, M <= 16 rows kept in registers ---------------------------
+template <int WT>  // -1 fp32, FINO_BF16, FINO_F16
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ x, const void* __restrict__ w,
+                                                            const void* __restrict__ b, float* __restrict__ y, int m,
+                                                            int64_t n, int64_t k, int silu_input) {
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= n) return;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int64_t kk = lane; kk < k; kk += 64) {
+        float wv;
+        if (WT == -1) wv = ((const float*)w)[col * k + kk];
+        else if (WT == FINO_BF16) wv = BF16::to_f32(((const uint16_t*)w)[col * k + kk]);
+        else wv = F16::to_f32(((const uint16_t*)w)[col * k + kk]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < m) {
+                float xv = x[(int64_t)i * k + kk];
+                if (silu_input) xv = xv / (1.0f + __expf(-xv));
+                acc[i] += xv * wv;
+            }
+        }
+    }
+    float bias = 0.f;
+    if (b) {
+        if (WT == -1) bias = ((const float*)b)[col];
+        else if (WT == FINO_BF16) bias = BF16::to_f32(((const uint16_t*)b)[col]);
+        else bias = F16::to_f32(((const uint16_t*)b)[col]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < m) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0) y[(int64_t)i * n + col] = s + bias;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
+                         int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
+                         const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm: dtype %d", dtype);
+    FINO_CHECK(a && w && c, FINO_ERR_ARG, "fino_gemm: null pointer");
+    FINO_CHECK(m >= 0 && n > 0 && k > 0, FINO_ERR_ARG, "fino_gemm: bad shape M=%lld N=%lld K=%lld", (long long)m,
+               (long long)n, (long long)k);
+    FINO_CHECK(n % 8 == 0 && k % 8 == 0, FINO_ERR_ARG, "fino_gemm: N=%lld and K=%lld must be multiples of 8",
+               (long long)n, (long long)k);
+    FINO_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= k && ldw >= k && ldc >= n, FINO_ERR_ARG,
+               "fino_gemm: leading dimensions must be multiples of 8 and cover the row");
+    FINO_CHECK(fino_aligned16(a) && fino_aligned16(w) && fino_aligned16(c), FINO_ERR_ARG,
+               "fino_gemm: A/W/C must be 16-byte aligned");
+    FINO_CHECK(epilogue >= FINO_EPI_NONE && epilogue <= FINO_EPI_GATED_RESIDUAL, FINO_ERR_ARG,
+               "fino_gemm: epilogue %d", epilogue);
+    if (epilogue == FINO_EPI_RESIDUAL || epilogue == FINO_EPI_GATED_RESIDUAL)
+        FINO_CHECK(r && ldr % 8 == 0 && ldr >= n && fino_aligned16(r), FINO_ERR_ARG, "fino_gemm: residual operand");
+    if (epilogue == FINO_EPI_GATED_RESIDUAL)
+        FINO_CHECK(gate && fino_aligned16(gate) && mod_stride % 4 == 0, FINO_ERR_ARG, "fino_gemm: gate operand");
+    if (m == 0) return FINO_OK;
+    GemmParams p;
+    p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.c = (uint16_t*)c;
+    p.r = (const uint16_t*)r; p.gate = gate; p.sel = sel;
+    p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
+    p.tiles_m = (int)((m + BM - 1) / BM);
+    p.tiles_n = (int)((n + BN - 1) / BN);
+    hipStream_t st = (hipStream_t)stream;
+    const bool generic = (k % BK) != 0;
+    if (dtype == FINO_BF16)
+        return generic ? launch_gemm_e<BF16, true>(p, epilogue, st) : launch_gemm_e<BF16, false>(p, epilogue, st);
+    return generic ? launch_gemm_e<F16, true>(p, epilogue, st) : launch_gemm_e<F16, false>(p, epilogue, st);
+}
+
+extern "C" int fino_skinny_linear(const float* x, const void* w, const void* b, float* y, int m, int64_t n,
+                                  int64_t k, int w_dtype, int silu_input, void* stream) {
+    FINO_CHECK(x && w && y, FINO_ERR_ARG, "fino_skinny_linear: null pointer");
+    FINO_CHECK(m >= 1 && m <= 16 && n > 0 && k > 0, FINO_ERR_ARG, "fino_skinny_linear: need 1 <= M <= 16 (M=%d)", m);
+    FINO_CHECK(w_dtype == -1 || w_dtype == FINO_BF16 || w_dtype == FINO_F16, FINO_ERR_ARG,
+               "fino_skinny_linear: w_dtype %d", w_dtype);
+    const dim3 grid((unsigned)((n + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (w_dtype == -1) skinny_linear_kernel<-1><<<grid, 256, 0, st>>>(x, w, b, y, m, n, k, silu_input);
+    else if (w_dtype == FINO_BF16) skinny_linear_kernel<FINO_BF16><<<grid, 256, 0, st>>>(x, w, b, y, m, n, k, silu_input);
+    else skinny_linear_kernel<FINO_F16><<<grid, 256, 0, st>>>(x, w, b, y, m, n, k, silu_input);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}

@@ -1,0 +1,201 @@
+"""Torch-tensor front end of the C ABI (include/frameino_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every op below forwards raw
+pointers + strides to libframeino_hip.so on torch's *current* stream (so the calls are capturable in a
+torch.cuda.CUDAGraph == hipGraph).  No op has a torch/CPU fallback.
+"""
+import torch
+
+from . import _lib
+
+BF16, F16 = 0, 1
+EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_GATED_RESIDUAL = 0, 1, 2, 3
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError(f"frameino_amd: activations must be bf16 or fp16, got {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _rows2d(t):
+    """View [..., D] with contiguous last dim and uniform row stride as (rows, D, ld)."""
+    if not t.is_cuda:
+        raise RuntimeError("frameino_amd ops need CUDA(HIP) tensors; there is no CPU path")
+    if t.stride(-1) != 1:
+        raise ValueError("last dimension must be contiguous")
+    t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1]) if t.is_contiguous() else None
+    if t2 is None:
+        if t.dim() == 3 and t.shape[0] == 1:
+            t2 = t[0]
+        else:
+            raise ValueError("need a 2-D row-strided view")
+    return t2, t2.shape[0], t2.shape[1], t2.stride(0)
+
+
+def adaln_modulate(x, shift, scale, sel=None, eps=1e-6, out=None):
+    """y = T(LN(x)*(1+scale[sel])+shift[sel]).  shift/scale: fp32 [R, D] views of one table (same row stride)."""
+    x2, rows, dim, ldx = _rows2d(x)
+    out = torch.empty_like(x2) if out is None else out
+    o2, _, _, ldy = _rows2d(out)
+    assert shift.dtype == torch.float32 and scale.dtype == torch.float32
+    ms = shift.stride(0) if shift.dim() == 2 else 0
+    if scale.dim() == 2:
+        assert scale.stride(0) == ms
+    _lib.check(_lib.lib().fino_adaln_modulate(_p(x2), _p(o2), rows, dim, ldx, ldy, _p(shift), _p(scale), ms, _p(sel),
+                                             eps, _dt(x), _stream()), "fino_adaln_modulate")
+    return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
+
+
+def layernorm(x, weight=None, bias=None, eps=1e-5, out=None):
+    x2, rows, dim, ldx = _rows2d(x)
+    out = torch.empty_like(x2) if out is None else out
+    o2, _, _, ldy = _rows2d(out)
+    for t in (weight, bias):
+        assert t is None or t.dtype == torch.float32
+    _lib.check(_lib.lib().fino_layernorm(_p(x2), _p(o2), rows, dim, ldx, ldy, _p(weight), _p(bias), eps, _dt(x),
+                                        _stream()), "fino_layernorm")
+    return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
+
+
+def gated_residual(x, y, gate=None, sel=None, out=None):
+    """out = T(float(x) + float(y)*gate[sel]) (gate None => T(x+y))."""
+    x2, rows, dim, ldx = _rows2d(x)
+    y2, _, _, ldy = _rows2d(y)
+    out = torch.empty_like(x2) if out is None else out
+    o2, _, _, ldo = _rows2d(out)
+    ms = gate.stride(0) if (gate is not None and gate.dim() == 2) else 0
+    _lib.check(_lib.lib().fino_gated_residual(_p(x2), _p(y2), _p(o2), rows, dim, ldx, ldy, ldo, _p(gate), ms, _p(sel),
+                                             _dt(x), _stream()), "fino_gated_residual")
+    return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
+
+
+def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0):
+    """In place on the row-strided view x [rows, D] (e.g. the q or k column block of a fused QKV buffer)."""
+    x2, rows, dim, ldx = _rows2d(x)
+    if cos is not None:
+        assert cos.dtype == torch.float32 and cos.is_contiguous() and cos.shape == (rows, head_dim // 2)
+        assert sin.dtype == torch.float32 and sin.is_contiguous() and sin.shape == cos.shape
+    _lib.check(_lib.lib().fino_rmsnorm_rope(_p(x2), rows, dim, ldx, _p(weight), eps, _p(cos), _p(sin), head_dim,
+                                           _dt(x), _stream()), "fino_rmsnorm_rope")
+    return x
+
+
+def headnorm_rope_(x, heads, head_dim, weight, bias, eps, cos=None, sin=None, rope_row0=0):
+    """In place on x [B, rows, heads*head_dim] (row-strided): per-head LayerNorm + RoPE on rows >= rope_row0."""
+    assert x.dim() == 3 and x.stride(2) == 1
+    b, rows, _ = x.shape
+    _lib.check(_lib.lib().fino_headnorm_rope(_p(x), b, rows, heads, head_dim, x.stride(1), x.stride(0), _p(weight),
+                                            _p(bias), eps, _p(cos), _p(sin), rope_row0, _dt(x), _stream()),
+               "fino_headnorm_rope")
+    return x
+
+
+def attention(q, k, v, heads, out=None, scale=None):
+    """q [B, Lq, H*Dh] (row-strided view), k/v [B, Lk, H*Dh] -> o [B, Lq, H*Dh].  Non-causal SDPA."""
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
+    b, lq, hd = q.shape
+    lk = k.shape[1]
+    dh = hd // heads
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.is_cuda
+    if out is None:
+        out = torch.empty((b, lq, hd), dtype=q.dtype, device=q.device)
+    scale = dh ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().fino_attn_fwd(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh,
+                                       q.stride(0), q.stride(1), dh, k.stride(0), k.stride(1), dh,
+                                       v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), dh,
+                                       float(scale), _dt(q), _stream()), "fino_attn_fwd")
+    return out
+
+
+def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None):
+    """C = epilogue(A.W^T + bias).  a [M, K] row-strided, w [N, K] (nn.Linear weight)."""
+    a2, m, k, lda = _rows2d(a)
+    assert w.dim() == 2 and w.stride(1) == 1 and w.shape[1] == k and w.dtype == a.dtype
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    o2, _, _, ldc = _rows2d(out)
+    r2, ldr = (None, 0)
+    if residual is not None:
+        r2, _, _, ldr = _rows2d(residual)
+    ms = gate.stride(0) if (gate is not None and gate.dim() == 2) else 0
+    if bias is not None:
+        assert bias.dtype == a.dtype and bias.is_contiguous()
+    _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
+                                   ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
+    return out
+
+
+def skinny_linear(x, w, b=None, silu_input=False):
+    """fp32 y = W.(silu?)(x) + b for M <= 16 rows; w fp32 or bf16/fp16."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and w.is_contiguous()
+    m, k = x.shape
+    n = w.shape[0]
+    wd = -1 if w.dtype == torch.float32 else _dt(w)
+    if b is not None:
+        assert b.dtype == w.dtype
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().fino_skinny_linear(_p(x), _p(w), _p(b), _p(y), m, n, k, wd, int(silu_input), _stream()),
+               "fino_skinny_linear")
+    return y
+
+
+def patchify(x, patch, out=None):
+    """x [C, F, H, W] -> a [L, C*pt*ph*pw]"""
+    assert x.dim() == 4 and x.is_contiguous()
+    c, f, h, w = x.shape
+    pt, ph, pw = patch
+    L = (f // pt) * (h // ph) * (w // pw)
+    if out is None:
+        out = torch.empty((L, c * pt * ph * pw), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().fino_patchify(_p(x), _p(out), c, f, h, w, pt, ph, pw, out.stride(0), _dt(x), _stream()),
+               "fino_patchify")
+    return out
+
+
+def unpatchify(y, cout, frames, height, width, patch, out=None):
+    """y [L, pt*ph*pw*cout] -> [cout, F, H, W]"""
+    pt, ph, pw = patch
+    if out is None:
+        out = torch.empty((cout, frames, height, width), dtype=y.dtype, device=y.device)
+    _lib.check(_lib.lib().fino_unpatchify(_p(y), _p(out), cout, frames, height, width, pt, ph, pw, y.stride(0), _dt(y),
+                                         _stream()), "fino_unpatchify")
+    return out
+
+
+def wan_model_input(lat, cond, id_lat, traj, dtype, out=None):
+    """lat [C,Fg,H,W], cond [C,1,H,W], id_lat [C,n_id,H,W]|None, traj [C,Fg+n_id,H,W] (fp32) -> [2C,Fg+n_id,H,W]."""
+    c, fg, h, w = lat.shape
+    nid = 0 if id_lat is None else id_lat.shape[1]
+    for t in (lat, cond, id_lat, traj):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    assert traj.shape == (c, fg + nid, h, w) and cond.shape == (c, 1, h, w)
+    if out is None:
+        out = torch.empty((2 * c, fg + nid, h, w), dtype=dtype, device=lat.device)
+    _lib.check(_lib.lib().fino_wan_model_input(_p(lat), _p(cond), _p(id_lat), _p(traj), _p(out), c, fg, nid, h, w,
+                                              _dt(out), _stream()), "fino_wan_model_input")
+    return out
+
+
+def cfg_euler_step_(lat, cond_pred, uncond_pred, guidance, dt_dev, round_out=True):
+    """In place on lat [C,Fg,H,W] fp32; preds [C,Ft,H,W] of the model dtype; dt_dev: 1-element fp32 device tensor."""
+    c, fg, h, w = lat.shape
+    ft = cond_pred.shape[1]
+    assert lat.dtype == torch.float32 and lat.is_contiguous() and cond_pred.is_contiguous()
+    assert dt_dev.dtype == torch.float32 and dt_dev.is_cuda
+    _lib.check(_lib.lib().fino_cfg_euler_step(_p(cond_pred), _p(uncond_pred), _p(lat), c, fg, ft, h, w, float(guidance),
+                                             _p(dt_dev), int(round_out), _dt(cond_pred), _stream()),
+               "fino_cfg_euler_step")
+    return lat

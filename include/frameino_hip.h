@@ -1,0 +1,131 @@
+/* frameino_hip.h -- C ABI of libframeino_hip.so: the MI355X (gfx950) kernels behind FrameINO's
+ * denoising hot path (Wan2.2 / CogVideoX DiT forward, sampler glue, Wan VAE decode).
+ *
+ * Contract:
+ *  - plain pointers + sizes, no tensor objects; the CALLER owns every buffer (inputs, outputs, workspace);
+ *  - every call only validates arguments on the host and enqueues kernels on `stream` (a hipStream_t passed
+ *    as void*): no allocation, no host sync, no host read of device memory => hipGraph-capturable;
+ *  - return 0 on success, <0 on error; fino_last_error() gives the thread-local message;
+ *  - `dtype` selects the storage/MFMA-operand type of activations and weights (FINO_BF16 / FINO_F16);
+ *    accumulation and the "fp32 islands" of the reference are fp32 inside the kernels.
+ *
+ * Each entry point cites the reference call site(s) it replaces (paths under /root/reference).
+ * The reference itself has no native interface for this path (pure PyTorch), so these are the operator
+ * boundaries of its attention-processor / block code.
+ */
+#ifndef FRAMEINO_HIP_H
+#define FRAMEINO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FINO_VERSION 100
+
+enum { FINO_BF16 = 0, FINO_F16 = 1 };
+enum {
+    FINO_OK = 0,
+    FINO_ERR_ARG = -1,     /* bad shape / alignment / dtype */
+    FINO_ERR_LAUNCH = -2,  /* HIP launch error */
+    FINO_ERR_UNSUPPORTED = -3
+};
+
+int fino_version(void);
+const char* fino_last_error(void);
+
+/* ---- normalisation + modulation (HBM-bound, one wave per token row) ------------------------------------
+ * y = T( LN_fp32(x) * (1 + scale[r]) + shift[r] ),  LN without affine, statistics in fp32.
+ * scale/shift are fp32 rows of a small modulation table: element (row, c) is  p[sel ? sel[row]*mod_stride : 0][c].
+ * Replaces architecture/transformer_wan.py:334, :344-346, :536 (FP32LayerNorm + AdaLN-zero modulate); the
+ * table has ONE row per distinct timestep instead of the reference's [1,L,6,D] fp32 tensor. */
+int fino_adaln_modulate(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                        const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel,
+                        float eps, int dtype, void* stream);
+
+/* y = T( LN_fp32(x) * w + b ), w/b fp32 (may be NULL => no affine).  transformer_wan.py:339 (norm2),
+ * also nn.LayerNorm call sites of CogVideoX (cogvideox_transformer_3d.py:531-538). */
+int fino_layernorm(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy, const float* w,
+                   const float* b, float eps, int dtype, void* stream);
+
+/* out = T( float(x) + float(y) * gate[r] )  (gate fp32 table row as above; gate==NULL => out = T(x + y)).
+ * transformer_wan.py:336, :341, :348. out may alias x. */
+int fino_gated_residual(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                        int64_t ldo, const float* gate, int64_t mod_stride, const int32_t* sel, int dtype,
+                        void* stream);
+
+/* In-place q/k preparation: RMSNorm over the whole row (all heads), weight multiply in T, then RoPE on adjacent
+ * channel pairs with per-token tables cos/sin [rows, head_dim/2] fp32 (NULL => no RoPE).
+ * transformer_wan.py:64-67 (norm_q / norm_k, "rms_norm_across_heads") and :73-90 (apply_rotary_emb).
+ * weight == NULL skips the norm (RoPE only). */
+int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                      const float* cos_t, const float* sin_t, int head_dim, int dtype, void* stream);
+
+/* Per-head LayerNorm(head_dim, affine) + RoPE on rows >= rope_row0 of every batch element (CogVideoX):
+ * architecture/attention_processor.py:2851-2860.  x is [batch, rows, heads*head_dim] with row stride ldx.
+ * w/b are T vectors of head_dim (NULL => skip LN). cos/sin are [rows - rope_row0, head_dim] fp32 (full width,
+ * as the Cog pipeline builds them), NULL => no RoPE. */
+int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx, int64_t batch_stride,
+                       const void* w, const void* b, float eps, const float* cos_t, const float* sin_t,
+                       int64_t rope_row0, int dtype, void* stream);
+
+/* ---- attention (MFMA-bound) -----------------------------------------------------------------------------
+ * o[b, i, h, :] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] ) v[b,j,h,:]   non-causal, no mask, no dropout.
+ * Element (b, row, h, d) of X lives at X + b*x_bs + row*x_rs + h*x_hs + d  (strides in ELEMENTS; d contiguous),
+ * so q/k/v can be column slices of one fused-QKV GEMM output and o is written token-major [L, H*Dh].
+ * head_dim in {64, 128}.  Replaces F.scaled_dot_product_attention at transformer_wan.py:108,
+ * attention_processor.py:2863, :2934. */
+int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                  int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs,
+                  int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs,
+                  int64_t o_hs, float scale, int dtype, void* stream);
+
+/* ---- GEMM with fused epilogue (MFMA-bound) --------------------------------------------------------------
+ * C[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] ),  A/W/C/R of `dtype`, bias of `dtype` (NULL => 0), fp32 accumulate.
+ * W is the nn.Linear weight as stored ([out, in], K contiguous).  lda/ldw/ldc/ldr in elements, multiples of 8.
+ * The value y = T(acc + bias) is rounded to T first (the reference materialises the Linear output), then:
+ *   FINO_EPI_NONE            C = y
+ *   FINO_EPI_GELU_TANH       C = T(gelu_tanh(y))                       (FeedForward "gelu-approximate")
+ *   FINO_EPI_RESIDUAL        C = T(R + y)                              (transformer_wan.py:341)
+ *   FINO_EPI_GATED_RESIDUAL  C = T(float(R) + float(y) * gate[r][n])   (transformer_wan.py:336, :348)
+ * gate rows as in fino_adaln_modulate. C may alias R.  Replaces nn.Linear at transformer_wan.py:60-62, :117,
+ * diffusers FeedForward (:347), patch_embedding (:486) and proj_out (:537) after patchify. */
+enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EPI_GATED_RESIDUAL = 3 };
+int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
+              int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
+              int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
+
+/* Skinny fp32-accurate linear for the conditioning MLPs (M <= 16 rows):
+ * y[m,n] = act( sum_k x[m,k] w[n,k] + b[n] ), x/y fp32, w/b fp32 (w_dtype=-1) or T; act: 0 none, 1 SiLU on the INPUT
+ * (y = W.silu(x) + b).  transformer_wan.py:175-183 (time_embedder kept fp32 by :393, time_proj). */
+int fino_skinny_linear(const float* x, const void* w, const void* b, float* y, int m, int64_t n, int64_t k,
+                       int w_dtype, int silu_input, void* stream);
+
+/* ---- patchify / unpatchify (HBM-bound gathers) ------------------------------------------------------------
+ * patchify: x [C, F, H, W] (one batch element) -> a [L, C*pt*ph*pw], L = (F/pt)(H/ph)(W/pw), column =
+ * ((c*pt+dt)*ph+dh)*pw+dw = the flattening of nn.Conv3d's weight; followed by fino_gemm it is the strided conv of
+ * transformer_wan.py:424, :486-487. */
+int fino_patchify(const void* x, void* a, int channels, int frames, int height, int width, int pt, int ph, int pw,
+                  int64_t lda, int dtype, void* stream);
+/* unpatchify: y [L, pt*ph*pw*Cout] -> out [Cout, F, H, W]   (transformer_wan.py:539-543). */
+int fino_unpatchify(const void* y, void* out, int cout, int frames, int height, int width, int pt, int ph, int pw,
+                    int64_t ldy, int dtype, void* stream);
+
+/* ---- sampler glue (pipelines/pipeline_wan_i2v_motion_FrameINO.py:829-891) -------------------------------- */
+/* model input: x[0:C] = T((1-m)*cond + m*lat) for the F_gen generated frames, then the n_id ID frames (:829,:854);
+ * x[C:2C] = T(traj) (:858).  lat/cond/id/traj fp32; lat [C,Fg,H,W]; cond [C,1,H,W]; id [C,n_id,H,W];
+ * traj [C,Fg+n_id,H,W]; m is 0 on frame 0 and 1 elsewhere (:528-532).  out [2C, Fg+n_id, H, W] of T. */
+int fino_wan_model_input(const float* lat, const float* cond, const float* id_lat, const float* traj, void* out,
+                         int channels, int gen_frames, int id_frames, int height, int width, int dtype, void* stream);
+/* CFG + flow-match Euler update on the generated frames (:882-891):
+ *   n = T(u + T(g * T(c - u)))   (the reference combines in the model dtype)   [g <= 1 or u == NULL: n = c]
+ *   lat' = lat + dt * n  in fp32, then rounded to T when round_out != 0 (diffusers Euler casts to the model dtype).
+ * cond_pred/uncond_pred are [C, Fg+n_id, H, W] of T (ID frames dropped, :886); lat fp32 [C, Fg, H, W], in place. */
+int fino_cfg_euler_step(const void* cond_pred, const void* uncond_pred, float* lat, int channels, int gen_frames,
+                        int total_frames, int height, int width, float guidance, const float* dt_dev, int round_out,
+                        int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAMEINO_HIP_H */
