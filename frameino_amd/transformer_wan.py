@@ -1,0 +1,367 @@
+"""MI355X-native WanTransformer3DModel (Wan2.2-TI2V-5B DiT as used by FrameINO).
+
+Host-side mirror of /root/reference/architecture/transformer_wan.py: same class / parameter names (HF checkpoints
+load by key), same `forward(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None,
+return_dict=True, attention_kwargs=None)` signature, same `blocks[i].attn1/attn2` + processor plugin surface,
+`cache_context(name)`, `.config`, `.dtype`.  All arithmetic runs in the HIP kernels of libframeino_hip.so.
+
+What is different by design (results identical):
+  * the per-token timestep embedding is de-duplicated: R distinct timestep values -> R rows through the time MLP
+    and an [R, layers, 6, D] fp32 modulation table + an int32 per-token selector, instead of the reference's
+    [1, L, 6, D] fp32 tensors (908 MB per block at L=12320);
+  * RoPE tables are built once per (frames, height, width) and kept compact ([L, 64] cos/sin);
+  * text K/V of the cross-attention (step-invariant) are cached per `cache_context` name;
+  * Q/K/V are one fused GEMM; norm+RoPE run in place on the fused buffer; attention reads it in place;
+    bias / GELU / gated-residual are GEMM epilogues.
+"""
+import contextlib
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import ops
+from .attention_processor import Attention, MI355WanAttnProcessor
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+class _FP32LayerNormParams(nn.Module):
+    """Parameter holder for diffusers' FP32LayerNorm (weight/bias stay fp32: reference :393)."""
+
+    def __init__(self, dim, eps, elementwise_affine):
+        super().__init__()
+        self.eps = eps
+        if elementwise_affine:
+            self.weight = nn.Parameter(torch.ones(dim))
+            self.bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+
+class _GELUProj(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out)
+
+
+class FeedForward(nn.Module):
+    """Parameter layout of diffusers FeedForward("gelu-approximate"): net.0.proj, net.2."""
+
+    def __init__(self, dim, inner_dim):
+        super().__init__()
+        self.net = nn.ModuleList([_GELUProj(dim, inner_dim), nn.Dropout(0.0), nn.Linear(inner_dim, dim)])
+
+
+class _MLP2(nn.Module):
+    def __init__(self, d_in, d_hidden, d_out=None):
+        super().__init__()
+        self.linear_1 = nn.Linear(d_in, d_hidden)
+        self.linear_2 = nn.Linear(d_hidden, d_out or d_hidden)
+
+
+class WanTimeTextImageEmbedding(nn.Module):
+    """Parameters of reference :146-166 (image_embedder absent: image_dim=None for TI2V-5B)."""
+
+    def __init__(self, dim, time_freq_dim, time_proj_dim, text_embed_dim):
+        super().__init__()
+        self.time_embedder = _MLP2(time_freq_dim, dim)
+        self.time_proj = nn.Linear(dim, time_proj_dim)
+        self.text_embedder = _MLP2(text_embed_dim, dim)
+
+
+def wan_rope_tables(head_dim, max_seq_len, ppf, pph, ppw, theta=10000.0):
+    """Compact RoPE tables [L, head_dim/2] (cos, sin) equal to WanRotaryPosEmbed (reference :192-253) sampled at
+    the slots the processor reads (:82-83).  fp64 angle tables, stored fp32, as the reference."""
+    h_dim = w_dim = 2 * (head_dim // 6)
+    t_dim = head_dim - h_dim - w_dim
+
+    def axis(dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
+        ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64), freqs)
+        return ang.cos().float(), ang.sin().float()          # [S, dim/2] (pairwise-repeated values deduplicated)
+
+    (ct, st), (ch, sh), (cw, sw) = axis(t_dim), axis(h_dim), axis(w_dim)
+
+    def build(t, h, w):
+        a = t[:ppf].view(ppf, 1, 1, -1).expand(ppf, pph, ppw, -1)
+        b = h[:pph].view(1, pph, 1, -1).expand(ppf, pph, ppw, -1)
+        c = w[:ppw].view(1, 1, ppw, -1).expand(ppf, pph, ppw, -1)
+        return torch.cat([a, b, c], dim=-1).reshape(ppf * pph * ppw, -1).contiguous()
+
+    return build(ct, ch, cw), build(st, sh, sw)
+
+
+class WanTransformerBlock(nn.Module):
+    def __init__(self, dim, ffn_dim, num_heads, qk_norm="rms_norm_across_heads", cross_attn_norm=False, eps=1e-6):
+        super().__init__()
+        self.attn1 = Attention(dim, heads=num_heads, dim_head=dim // num_heads, qk_norm=qk_norm, eps=eps, bias=True,
+                               out_bias=True, processor=MI355WanAttnProcessor())
+        self.attn2 = Attention(dim, heads=num_heads, dim_head=dim // num_heads, qk_norm=qk_norm, eps=eps, bias=True,
+                               out_bias=True, processor=MI355WanAttnProcessor())
+        self.norm2 = _FP32LayerNormParams(dim, eps, True) if cross_attn_norm else None
+        self.ffn = FeedForward(dim, ffn_dim)
+        self.scale_shift_table = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+
+
+class WanTransformer3DModel(nn.Module):
+    _keep_in_fp32_modules = ["time_embedder", "scale_shift_table", "norm1", "norm2", "norm3"]   # reference :393
+
+    def __init__(self, patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16,
+                 out_channels=16, text_dim=4096, freq_dim=256, ffn_dim=13824, num_layers=40, cross_attn_norm=True,
+                 qk_norm="rms_norm_across_heads", eps=1e-6, image_dim=None, added_kv_proj_dim=None,
+                 rope_max_seq_len=1024, pos_embed_seq_len=None):
+        super().__init__()
+        if image_dim is not None or added_kv_proj_dim is not None:
+            raise NotImplementedError("Wan2.1 image-embedding branch is outside FrameINO's TI2V-5B path")
+        self.config = _Config(patch_size=tuple(patch_size), num_attention_heads=num_attention_heads,
+                              attention_head_dim=attention_head_dim, in_channels=in_channels,
+                              out_channels=out_channels or in_channels, text_dim=text_dim, freq_dim=freq_dim,
+                              ffn_dim=ffn_dim, num_layers=num_layers, cross_attn_norm=cross_attn_norm, qk_norm=qk_norm,
+                              eps=eps, image_dim=image_dim, added_kv_proj_dim=added_kv_proj_dim,
+                              rope_max_seq_len=rope_max_seq_len, pos_embed_seq_len=pos_embed_seq_len)
+        inner = num_attention_heads * attention_head_dim
+        self.inner_dim = inner
+        self.patch_embedding = nn.Conv3d(in_channels, inner, kernel_size=patch_size, stride=patch_size)
+        self.condition_embedder = WanTimeTextImageEmbedding(inner, freq_dim, inner * 6, text_dim)
+        self.blocks = nn.ModuleList([WanTransformerBlock(inner, ffn_dim, num_attention_heads, qk_norm, cross_attn_norm,
+                                                         eps) for _ in range(num_layers)])
+        self.proj_out = nn.Linear(inner, self.config.out_channels * math.prod(patch_size))
+        self.scale_shift_table = nn.Parameter(torch.randn(1, 2, inner) / inner ** 0.5)
+        self._packed = None
+        self._rope_cache = {}
+        self._text_cache = {}
+        self._ws = {}
+        self._ctx_name = None
+
+    # ------------------------------------------------------------------ diffusers-style surface
+    @property
+    def dtype(self):
+        return self.proj_out.weight.dtype
+
+    @property
+    def device(self):
+        return self.proj_out.weight.device
+
+    @contextlib.contextmanager
+    def cache_context(self, name):
+        prev, self._ctx_name = self._ctx_name, name
+        try:
+            yield
+        finally:
+            self._ctx_name = prev
+
+    @property
+    def attn_processors(self):
+        out = {}
+        for i, blk in enumerate(self.blocks):
+            out[f"blocks.{i}.attn1.processor"] = blk.attn1.processor
+            out[f"blocks.{i}.attn2.processor"] = blk.attn2.processor
+        return out
+
+    def load_reference_state_dict(self, sd, dtype=None):
+        """Load weights keyed by the reference's parameter names; non-fp32-island tensors are cast to `dtype`."""
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        extra = [k for k in sd if k not in own]
+        if missing or extra:
+            raise KeyError(f"state-dict mismatch: missing {missing[:5]} unexpected {extra[:5]}")
+        with torch.no_grad():
+            for k, p in self.named_parameters():
+                keep32 = any(s in k for s in self._keep_in_fp32_modules)
+                t = sd[k].to(torch.float32 if keep32 else (dtype or sd[k].dtype))
+                p.data = t.to(p.device).contiguous()
+        self._packed = None
+        self._text_cache.clear()
+        return self
+
+    # ------------------------------------------------------------------ packed weights
+    def _pack(self):
+        """One-time repack for the fused kernels: fused QKV / KV weights, flat patch-embed weight, the 30 per-block
+        scale_shift_tables stacked (fp32)."""
+        d = self.inner_dim
+        pk = SimpleNamespace(layers=[])
+        for blk in self.blocks:
+            a1, a2 = blk.attn1, blk.attn2
+            e = SimpleNamespace()
+            e.wqkv = torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]).detach().contiguous()
+            e.bqkv = torch.cat([a1.to_q.bias, a1.to_k.bias, a1.to_v.bias]).detach().contiguous()
+            e.wkv2 = torch.cat([a2.to_k.weight, a2.to_v.weight]).detach().contiguous()
+            e.bkv2 = torch.cat([a2.to_k.bias, a2.to_v.bias]).detach().contiguous()
+            pk.layers.append(e)
+        pk.sst = torch.stack([b.scale_shift_table.detach().float()[0] for b in self.blocks])        # [layers, 6, D]
+        pk.w_patch = self.patch_embedding.weight.detach().reshape(d, -1).contiguous()
+        # exactly our processor (not a subclass): the fused path below IS that processor's body; anything else the
+        # user installed (set_processor) is called through the plugin protocol instead.
+        pk.default_procs = all(type(b.attn1.processor) is MI355WanAttnProcessor and
+                               type(b.attn2.processor) is MI355WanAttnProcessor for b in self.blocks)
+        self._packed = pk
+        return pk
+
+    def _workspace(self, L, dtype, device):
+        key = (L, dtype, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            d, f = self.inner_dim, self.config.ffn_dim
+            mk = lambda *s: torch.empty(*s, dtype=dtype, device=device)          # noqa: E731
+            ws = SimpleNamespace(x=mk(L, d), n=mk(L, d), qkv=mk(L, 3 * d), att=mk(L, d), q2=mk(L, d), ff=mk(L, f),
+                                 a=mk(L, self.config.in_channels * math.prod(self.config.patch_size)),
+                                 po=mk(L, self.config.out_channels * math.prod(self.config.patch_size)))
+            self._ws = {key: ws}
+        return ws
+
+    def _rope(self, ppf, pph, ppw, device):
+        key = (ppf, pph, ppw, str(device))
+        if key not in self._rope_cache:
+            cos, sin = wan_rope_tables(self.config.attention_head_dim, self.config.rope_max_seq_len, ppf, pph, ppw)
+            self._rope_cache[key] = (cos.to(device), sin.to(device))
+        return self._rope_cache[key]
+
+    # ------------------------------------------------------------------ conditioning
+    def _time_rows(self, t_rows, act_dtype):
+        """Reference :175-183 on R distinct timestep values.  Returns temb [R, D] (act dtype) and
+        timestep_proj [R, 6, D] (act dtype)."""
+        ce = self.condition_embedder
+        half = self.config.freq_dim // 2
+        expo = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t_rows.device) / half)
+        ang = t_rows.float()[:, None] * expo[None, :]
+        sinus = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)               # flip_sin_to_cos=True
+        te = ce.time_embedder
+        wd = te.linear_1.weight.dtype                     # fp32 when the reference's fp32 islands are kept (:393)
+        silu = torch.nn.functional.silu
+        outs = []
+        for i in range(0, sinus.shape[0], 16):                                    # skinny kernel: <= 16 rows/call
+            s = sinus[i:i + 16].to(wd).float().contiguous()                       # :179-181
+            h = ops.skinny_linear(s, te.linear_1.weight, te.linear_1.bias).to(wd)
+            h = silu(h).float().contiguous()
+            e = ops.skinny_linear(h, te.linear_2.weight, te.linear_2.bias).to(wd)
+            temb = e.to(act_dtype)                                                # .type_as(encoder_hidden_states) :182
+            a = silu(temb).float().contiguous()                                   # act_fn(temb) in the act dtype :183
+            tp = ops.skinny_linear(a, ce.time_proj.weight, ce.time_proj.bias).to(ce.time_proj.weight.dtype)
+            outs.append((temb, tp))
+        temb = torch.cat([o[0] for o in outs])
+        tproj = torch.cat([o[1] for o in outs]).unflatten(1, (6, -1))
+        return temb, tproj
+
+    def _text_kv(self, encoder_hidden_states, pk):
+        """text_embedder (:185) + the 30 layers' attn2 K (after norm_k) and V: step-invariant, cached per
+        cache_context name and prompt tensor identity."""
+        key = (self._ctx_name, encoder_hidden_states.data_ptr(), encoder_hidden_states._version,
+               tuple(encoder_hidden_states.shape))
+        hit = self._text_cache.get(self._ctx_name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        ce = self.condition_embedder
+        d = self.inner_dim
+        ctx = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1])
+        h = ops.gemm(ctx, ce.text_embedder.linear_1.weight, ce.text_embedder.linear_1.bias, ops.EPI_GELU_TANH)
+        txt = ops.gemm(h, ce.text_embedder.linear_2.weight, ce.text_embedder.linear_2.bias)
+        kvs = []
+        for blk, e in zip(self.blocks, pk.layers):
+            kv = ops.gemm(txt, e.wkv2, e.bkv2)                                     # [Lt, 2D]
+            ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
+            kvs.append(kv)
+        val = SimpleNamespace(txt=txt, kv=kvs)
+        self._text_cache[self._ctx_name] = (key, val)
+        return val
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None,
+                return_dict=True, attention_kwargs=None, timestep_rows=None):
+        """`timestep_rows=(values [R], selector int32 [L])` is the de-duplicated form of a per-token timestep; when a
+        2-D `timestep` is given instead it is de-duplicated here (torch.unique: host sync, eager only)."""
+        if encoder_hidden_states_image is not None:
+            raise NotImplementedError("encoder_hidden_states_image: Wan2.1 branch, outside the TI2V-5B path")
+        if attention_kwargs is not None:
+            attention_kwargs = dict(attention_kwargs)
+            attention_kwargs.pop("scale", None)                                    # LoRA scale (:463-476): no PEFT here
+        b = hidden_states.shape[0]
+        if b != 1:
+            outs = [self.forward(hidden_states[i:i + 1], timestep[i:i + 1] if timestep is not None else None,
+                                 encoder_hidden_states[i:i + 1], None, False, attention_kwargs, timestep_rows)[0]
+                    for i in range(b)]
+            out = torch.cat(outs)
+            return SimpleNamespace(sample=out) if return_dict else (out,)
+        pk = self._packed or self._pack()
+        cfg = self.config
+        _, c, nf, hh, ww = hidden_states.shape
+        pt, ph, pw = cfg.patch_size
+        ppf, pph, ppw = nf // pt, hh // ph, ww // pw
+        L = ppf * pph * ppw
+        d, heads, dh = self.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim
+        dev, dt = hidden_states.device, hidden_states.dtype
+        ws = self._workspace(L, dt, dev)
+        cos, sin = self._rope(ppf, pph, ppw, dev)
+
+        # ---- timestep rows + selector (F7) ----
+        if timestep_rows is not None:
+            t_rows, sel = timestep_rows
+        elif timestep.ndim == 2:
+            t_rows, inv = torch.unique(timestep[0], return_inverse=True)
+            sel = inv.to(torch.int32).contiguous()
+        else:
+            t_rows, sel = timestep.reshape(1), None
+        temb, tproj = self._time_rows(t_rows.to(dev), encoder_hidden_states.dtype)       # [R,D], [R,6,D]
+        # per-layer modulation tables: scale_shift_table + temb.float()  (:317-319)  -> [R, layers, 6, D] fp32
+        mod = (pk.sst[None] + tproj.float()[:, None]).contiguous()
+        head = (self.scale_shift_table.float() + temb.float()[:, None]).contiguous()     # [R, 2, D]  (:522/:527)
+
+        text = self._text_kv(encoder_hidden_states, pk)
+
+        # ---- patch embedding (:486-487): gather + GEMM ----
+        ops.patchify(hidden_states[0], cfg.patch_size, out=ws.a)
+        x = ops.gemm(ws.a, pk.w_patch, self.patch_embedding.bias, out=ws.x)
+
+        for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
+            m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
+            # 1. self-attention (:334-336)
+            ops.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=ws.n)
+            if pk.default_procs:
+                ops.gemm(ws.n, e.wqkv, e.bqkv, out=ws.qkv)
+                ops.rmsnorm_rope_(ws.qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
+                ops.rmsnorm_rope_(ws.qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                q3 = ws.qkv.view(1, L, 3 * d)
+                ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=ws.att.view(1, L, d))
+                ops.gemm(ws.att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, ops.EPI_GATED_RESIDUAL,
+                         residual=x, gate=m[:, 2], sel=sel, out=x)
+            else:
+                rot = _CompactRope((cos, sin))
+                a = blk.attn1(ws.n.view(1, L, d), rotary_emb=rot, **(attention_kwargs or {}))
+                ops.gated_residual(x, a.reshape(L, d), m[:, 2], sel, out=x)
+            # 2. cross-attention (:339-341)
+            n2 = blk.norm2
+            ops.layernorm(x, None if n2 is None else n2.weight, None if n2 is None else n2.bias, cfg.eps, out=ws.n) \
+                if n2 is not None else ws.n.copy_(x)
+            if pk.default_procs:
+                ops.gemm(ws.n, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=ws.q2)
+                ops.rmsnorm_rope_(ws.q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
+                kv = text.kv[li].view(1, -1, 2 * d)
+                ops.attention(ws.q2.view(1, L, d), kv[:, :, :d], kv[:, :, d:], heads, out=ws.att.view(1, L, d))
+                ops.gemm(ws.att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, ops.EPI_RESIDUAL, residual=x,
+                         out=x)
+            else:
+                a = blk.attn2(ws.n.view(1, L, d), encoder_hidden_states=text.txt[None], **(attention_kwargs or {}))
+                ops.gated_residual(x, a.reshape(L, d), out=x)
+            # 3. feed-forward (:344-348)
+            ops.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=ws.n)
+            ops.gemm(ws.n, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, ops.EPI_GELU_TANH, out=ws.ff)
+            ops.gemm(ws.ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, ops.EPI_GATED_RESIDUAL, residual=x,
+                     gate=m[:, 5], sel=sel, out=x)
+
+        # ---- output head (:519-543) ----
+        ops.adaln_modulate(x, head[:, 0], head[:, 1], sel, cfg.eps, out=ws.n)
+        ops.gemm(ws.n, self.proj_out.weight, self.proj_out.bias, out=ws.po)
+        out = ops.unpatchify(ws.po, cfg.out_channels, nf, hh, ww, cfg.patch_size)[None]
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+
+class _CompactRope(tuple):
+    """(cos, sin) already in the compact [L, Dh/2] layout; recognised by MI355WanAttnProcessor."""
+    compact = True

@@ -65,7 +65,7 @@ def randomize_(module, seed, std=0.2):
 
 
 # ----------------------------------------------------------------------------------- Wan DiT
-WAN_TINY = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=24, in_channels=8, out_channels=4,
+WAN_TINY = dict(patch_size=(1, 2, 2), num_attention_heads=2, attention_head_dim=128, in_channels=8, out_channels=4,
                 text_dim=16, freq_dim=32, ffn_dim=64, num_layers=2, cross_attn_norm=True, eps=1e-6,
                 rope_max_seq_len=64)
 
@@ -100,11 +100,11 @@ def gen_wan_dit():
 
     # G1/G2: one block + its two attention calls in isolation
     blk = m.blocks[0]
-    h = torch.randn(1, L, 48, generator=g)
-    ctx = torch.randn(1, 20, 48, generator=g)
+    h = torch.randn(1, L, 256, generator=g)
+    ctx = torch.randn(1, 20, 256, generator=g)
     rot = m.rope(x)
-    temb4 = torch.randn(1, L, 6, 48, generator=g) * 0.3
-    temb3 = torch.randn(1, 6, 48, generator=g) * 0.3
+    temb4 = torch.randn(1, L, 6, 256, generator=g) * 0.3
+    temb3 = torch.randn(1, 6, 256, generator=g) * 0.3
     a_self = blk.attn1(hidden_states=h, rotary_emb=rot)
     a_cross = blk.attn2(hidden_states=h, encoder_hidden_states=ctx)
     b4 = blk(h, ctx, temb4, rot)
