@@ -12,6 +12,44 @@ BF16, F16 = 0, 1
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_GATED_RESIDUAL = 0, 1, 2, 3
 
 
+class KernelTimer:
+    """HIP-event timing of named kernel launches on the stream they are launched on (used by bench.py for the
+    live `roofline.achieved` figure).  `with KernelTimer({"attn_self"}) as kt: ...; kt.summary()`."""
+
+    active = None
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in self.names}
+        self.flops = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, evs in self.events.items():
+            ms = [s.elapsed_time(e) for s, e in evs]
+            if ms:
+                out[n] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+
+def _timed(name):
+    kt = KernelTimer.active
+    if kt is None or name not in kt.names:
+        return None
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kt.events[name].append((s, e))
+    s.record()
+    return e
+
+
 def _dt(t):
     if t.dtype == torch.bfloat16:
         return BF16
@@ -112,10 +150,13 @@ def attention(q, k, v, heads, out=None, scale=None):
     if out is None:
         out = torch.empty((b, lq, hd), dtype=q.dtype, device=q.device)
     scale = dh ** -0.5 if scale is None else scale
+    ev = _timed("attn_self" if lq == lk else "attn_cross")
     _lib.check(_lib.lib().fino_attn_fwd(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh,
                                        q.stride(0), q.stride(1), dh, k.stride(0), k.stride(1), dh,
                                        v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), dh,
                                        float(scale), _dt(q), _stream()), "fino_attn_fwd")
+    if ev is not None:
+        ev.record()
     return out
 
 
@@ -133,8 +174,12 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     ms = gate.stride(0) if (gate is not None and gate.dim() == 2) else 0
     if bias is not None:
         assert bias.dtype == a.dtype and bias.is_contiguous()
+    ev = _timed("gemm")
     _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
                                    ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
+    if ev is not None:
+        ev.record()
+        KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
     return out
 
 
