@@ -36,6 +36,7 @@ constexpr int kQRowsPerWave = 32;
 constexpr int kWaves = 8;
 constexpr int kQBlock = kQRowsPerWave * kWaves;  // 256
 constexpr int kKV = 64;
+constexpr float kRescaleThr = 8.0f;  // log2 units: P <= 256 between rescales
 
 // Byte offset of 16-byte chunk `ch` of row `row` inside a [kKV][D] tile.
 //  D=128 (256-B rows): ch ^ (((row&3)<<2) | ((row>>2)&3))
@@ -49,7 +50,9 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
     }
 }
 
-template <typename T, int D>
+// VAR only names the launch site (0: long-KV self-attention, 1: short-KV text cross-attention) so that profilers
+// report the two call classes as separate kernel symbols; the code is identical.
+template <typename T, int D, int VAR>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kTileBytes = kKV * D * 2;
@@ -128,97 +131,158 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     for (int i = 0; i < kDT; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
-    float m_run = -INFINITY;
+    float m_run = -INFINITY;   // running max of scale_log2 * s (log2 domain); only moved by a rescale
     float l_run = 0.f;
+    const float c2 = p.scale_log2;
 
+    // S^T = K.Q^T for one 64-key tile held in LDS buffer `KB_` -> two 32x32 accumulators
+#define QK_TILE(KB_, S0_, S1_)                                                                              \
+    {                                                                                                       \
+        const char* kb_ = smem + (KB_) * kTileBytes;                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) { S0_[j_] = 0.f; S1_[j_] = 0.f; }                 \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < kKS; ++ks_) {                                             \
+            const uint4 a0_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(r, 2 * ks_ + h));            \
+            const uint4 a1_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(32 + r, 2 * ks_ + h));       \
+            S0_ = T::mfma32(__builtin_bit_cast(vec8, a0_), qf[ks_], S0_);                                   \
+            S1_ = T::mfma32(__builtin_bit_cast(vec8, a1_), qf[ks_], S1_);                                   \
+        }                                                                                                   \
+    }
+
+    // Software pipeline (K runs one tile ahead of V): iteration t issues S(t+1) = K(t+1).Q^T on the matrix pipe
+    // while the VALU does the softmax of S(t); then O += V(t)^T.P(t).  LDS: K[2] ring + V[2] ring; K(t+2) and
+    // V(t+1) travel global -> registers during the iteration and are written to LDS at its end; 1 barrier / tile.
     const int nt = (p.lk + kKV - 1) / kKV;
     STAGE_LOAD(0)
     STAGE_WRITE(0)
+    if (nt > 1) {
+        // K(1) only
+#pragma unroll
+        for (int i = 0; i < kLoadsPerThread; ++i) {
+            int row = kKV + st_row[i];
+            row = row < p.lk ? row : p.lk - 1;
+            kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)row * p.k_rs + st_ch[i] * 8);
+            *reinterpret_cast<u32x4_t*>(smem + 1 * kTileBytes + st_off[i]) = kreg[i];
+        }
+    }
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) { STAGE_LOAD(t + 1) }
+    f32x16_t sc0, sc1;   // S(t)
+    QK_TILE(0, sc0, sc1)
 
-        // ---------------- S^T = K . Q^T ----------------
-        const char* kb = smem + cur * kTileBytes;
-        f32x16_t s0, s1;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < kKS; ++ks) {
-            const uint4 a0 = *reinterpret_cast<const uint4*>(kb + lds_off<D>(r, 2 * ks + h));
-            const uint4 a1 = *reinterpret_cast<const uint4*>(kb + lds_off<D>(32 + r, 2 * ks + h));
-            s0 = T::mfma32(__builtin_bit_cast(vec8, a0), qf[ks], s0);
-            s1 = T::mfma32(__builtin_bit_cast(vec8, a1), qf[ks], s1);
-        }
-        // rows of the 32x32 accumulator: key = (j&3) + 8*(j>>2) + 4*h
-        if (t == nt - 1 && (p.lk & (kKV - 1))) {
-            const int kbase = t * kKV + 4 * h;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int key = kbase + (j & 3) + 8 * (j >> 2);
-                if (key >= p.lk) s0[j] = -INFINITY;
-                if (key + 32 >= p.lk) s1[j] = -INFINITY;
-            }
-        }
-
-        // ---------------- online softmax (query on the lane) ----------------
-        float mx = s0[0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, s0[j]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s1[j]);
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m_run, mx * p.scale_log2);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            s0[j] = __builtin_amdgcn_exp2f(s0[j] * p.scale_log2 - m_new);
-            s1[j] = __builtin_amdgcn_exp2f(s1[j] * p.scale_log2 - m_new);
-            psum += s0[j] + s1[j];
-        }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < kDT; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
-
-        // ---------------- O^T += V^T . P^T ----------------
-        const char* vb = smem + (2 + cur) * kTileBytes;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                vec8 pb;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = kt == 0 ? s0[8 * s2 + j] : s1[8 * s2 + j];
-                    pb[j] = (typename T::scalar)pv;
-                }
-                const int key0 = kt * 32 + 16 * s2 + 4 * h + tq;
-#pragma unroll
-                for (int dt = 0; dt < kDT; ++dt) {
-                    const int ch = dt * 4 + 2 * g1 + (tp >> 1);
-                    const int a_lo = lds_off<D>(key0, ch) + 8 * (tp & 1);
-                    const int a_hi = lds_off<D>(key0 + 8, ch) + 8 * (tp & 1);
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_lo));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_hi));
-                    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-                    const s16x8_t va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = T::mfma32(__builtin_bit_cast(vec8, va), pb, o[dt]);
-                }
-            }
-        }
-
-        if (t + 1 < nt) { STAGE_WRITE(cur ^ 1) }
-        __syncthreads();
+    // row max of a tile (query on the lane; partner half-wave holds the other 32 keys) -> MX_
+#define ROW_MAX(S0_, S1_, MX_)                                                                               \
+    {                                                                                                        \
+        float mx_ = fmaxf(fmaxf(S0_[0], S0_[1]), S0_[2]);                                                    \
+        _Pragma("unroll") for (int j = 3; j < 15; j += 2) mx_ = fmaxf(fmaxf(mx_, S0_[j]), S0_[j + 1]);       \
+        mx_ = fmaxf(fmaxf(mx_, S0_[15]), S1_[0]);                                                            \
+        _Pragma("unroll") for (int j = 1; j < 15; j += 2) mx_ = fmaxf(fmaxf(mx_, S1_[j]), S1_[j + 1]);       \
+        mx_ = fmaxf(mx_, S1_[15]);                                                                           \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false); \
+        MX_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                       \
     }
+    // deferred rescale (T13): move the running max only when it grew by more than kRescaleThr (log2 units).  O, l
+    // and m move together and only BETWEEN tiles (all of the previous tile's P.V is in O, no P of the next exists).
+    // Rows beyond lk in a ragged last tile are clamped copies of key lk-1, so the max over the padded tile is the
+    // max over the valid keys.
+#define MAYBE_RESCALE(MX_)                                                                                   \
+    {                                                                                                        \
+        const float m_cand_ = fmaxf(m_run, (MX_) * c2);                                                      \
+        if (__any((m_cand_ - m_run) > kRescaleThr)) {                                                        \
+            const float alpha_ = __builtin_amdgcn_exp2f(m_run - m_cand_);                                    \
+            m_run = m_cand_;                                                                                 \
+            l_run *= alpha_;                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < kDT; ++i)                                                  \
+                _Pragma("unroll") for (int j = 0; j < 16; ++j) o[i][j] *= alpha_;                            \
+        }                                                                                                    \
+    }
+    {
+        float mx0;
+        ROW_MAX(sc0, sc1, mx0)
+        MAYBE_RESCALE(mx0)
+    }
+
+    // One tile of the pipeline.  HAS_NEXT_: S(t+1) is issued (every tile but the last); LAST_: ragged-tail mask.
+#define TILE_BODY(HAS_NEXT_, LAST_)                                                                          \
+    {                                                                                                        \
+        const int cur = t & 1;                                                                               \
+        /* global -> registers: K(t+2), V(t+1) (clamped rows; dead data is never written to LDS) */          \
+        if (HAS_NEXT_) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i) {                                    \
+                int rk = (t + 2) * kKV + st_row[i];                                                          \
+                int rv = (t + 1) * kKV + st_row[i];                                                          \
+                rk = rk < p.lk ? rk : p.lk - 1;                                                              \
+                rv = rv < p.lk ? rv : p.lk - 1;                                                              \
+                kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)rk * p.k_rs + st_ch[i] * 8);      \
+                vreg[i] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)rv * p.v_rs + st_ch[i] * 8);      \
+            }                                                                                                \
+        }                                                                                                    \
+        /* matrix pipe: S(t+1) = K(t+1).Q^T   ||   VALU: P(t) = exp2(c.S(t) - m), row sums */                \
+        f32x16_t sn0, sn1;                                                                                   \
+        if (HAS_NEXT_) QK_TILE(cur ^ 1, sn0, sn1)                                                            \
+        float psum0 = 0.f, psum1 = 0.f;                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                     \
+            sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);                                            \
+            sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);                                            \
+        }                                                                                                    \
+        if (LAST_ && (p.lk & (kKV - 1))) { /* key = (j&3) + 8*(j>>2) + 4*h (+32) */                          \
+            const int kbase = t * kKV + 4 * h;                                                               \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                 \
+                const int key = kbase + (j & 3) + 8 * (j >> 2);                                              \
+                if (key >= p.lk) sc0[j] = 0.f;                                                               \
+                if (key + 32 >= p.lk) sc1[j] = 0.f;                                                          \
+            }                                                                                                \
+        }                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                     \
+            psum0 += sc0[j];                                                                                 \
+            psum1 += sc1[j];                                                                                 \
+        }                                                                                                    \
+        l_run += psum0 + psum1;                                                                              \
+        /* matrix pipe: O^T += V(t)^T . P(t)^T   ||   VALU: bf16 packing, row max of S(t+1) */               \
+        const char* vb = smem + (2 + cur) * kTileBytes;                                                      \
+        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                   \
+            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                               \
+                vec8 pb;                                                                                     \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                              \
+                    const float pv = kt == 0 ? sc0[8 * s2 + j] : sc1[8 * s2 + j];                            \
+                    pb[j] = (typename T::scalar)pv;                                                          \
+                }                                                                                            \
+                const int key0 = kt * 32 + 16 * s2 + 4 * h + tq;                                             \
+                _Pragma("unroll") for (int dt = 0; dt < kDT; ++dt) {                                         \
+                    const int ch = dt * 4 + 2 * g1 + (tp >> 1);                                              \
+                    const int a_lo = lds_off<D>(key0, ch) + 8 * (tp & 1);                                    \
+                    const int a_hi = lds_off<D>(key0 + 8, ch) + 8 * (tp & 1);                                \
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_lo)); \
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_hi)); \
+                    const s16x8_t va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);              \
+                    o[dt] = T::mfma32(__builtin_bit_cast(vec8, va), pb, o[dt]);                              \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+        if (HAS_NEXT_) {                                                                                     \
+            float mxn;                                                                                       \
+            ROW_MAX(sn0, sn1, mxn)                                                                           \
+            /* registers -> LDS: K(t+2) into the K slot S(t) came from, V(t+1) into the other V slot */      \
+            if (t + 2 < nt) {                                                                                \
+                _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
+                    *reinterpret_cast<u32x4_t*>(smem + cur * kTileBytes + st_off[i]) = kreg[i];              \
+            }                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                      \
+                *reinterpret_cast<u32x4_t*>(smem + (2 + (cur ^ 1)) * kTileBytes + st_off[i]) = vreg[i];      \
+            sc0 = sn0;                                                                                       \
+            sc1 = sn1;                                                                                       \
+            MAYBE_RESCALE(mxn)                                                                               \
+            __syncthreads();                                                                                 \
+        }                                                                                                    \
+    }
+
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    int t = 0;
+    for (; t < nt - 1; ++t) TILE_BODY(true, false)
+    TILE_BODY(false, true)
+#undef TILE_BODY
+#undef ROW_MAX
+#undef MAYBE_RESCALE
+#undef QK_TILE
 
     // ---------------- epilogue: normalise, store O[q][d] ----------------
     {
@@ -243,12 +307,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     }
 }
 
-template <typename T, int D>
-int launch_attn(const AttnParams& p, hipStream_t st) {
+template <typename T, int D, int VAR>
+int launch_attn_v(const AttnParams& p, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             fino_set_error("fino_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -259,9 +323,14 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
     const int hb = p.batch * p.heads;
     const int groups = (hb + 7) / 8;
     const dim3 grid((unsigned)(8 * groups * p.nqb));
-    attn_fwd_kernel<T, D><<<grid, kWaves * 64, smem, st>>>(p);
+    attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
+}
+
+template <typename T, int D>
+int launch_attn(const AttnParams& p, hipStream_t st) {
+    return p.lk > 1024 ? launch_attn_v<T, D, 0>(p, st) : launch_attn_v<T, D, 1>(p, st);
 }
 
 }  // namespace

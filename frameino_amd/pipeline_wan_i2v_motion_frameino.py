@@ -248,19 +248,25 @@ class WanImageToVideoPipeline:
     # ---- the hot loop ----
     def _step(self, st):
         """One denoise step on static buffers `st` (graph-capturable: no host sync, no allocation-dependent shapes)."""
-        tr = self.transformer
-        x = ops.wan_model_input(st.lat, st.cond, st.idl, st.traj, tr.dtype, out=st.x)[None]
+        tr, o = self.transformer, self.transformer.ops
+        x = o.wan_model_input(st.lat, st.cond, st.idl, st.traj, tr.dtype, out=st.x)[None]
         rows = (st.t_rows, st.sel)
-        with tr.cache_context("cond"):
-            pc = tr(hidden_states=x, timestep=None, encoder_hidden_states=st.pe, return_dict=False,
-                    attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0]
-        pu = None
-        if st.cfg:
-            with tr.cache_context("uncond"):
-                pu = tr(hidden_states=x, timestep=None, encoder_hidden_states=st.ne, return_dict=False,
-                        attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0]
-        ops.cfg_euler_step_(st.lat, pc[0], None if pu is None else pu[0], st.guidance, st.dt,
-                            round_out=getattr(self.scheduler, "cast_output_to_model_dtype", True))
+
+        def fwd(name, emb):
+            with tr.cache_context(name):
+                return tr(hidden_states=x, timestep=None, encoder_hidden_states=emb, return_dict=False,
+                          attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0][0]
+
+        plan = getattr(self, "parallel", None)
+        if plan is not None and plan.cfg_ways == 2 and st.cfg:
+            # CFG branches on two rank groups; one exchange of noise_pred per step (frameino_amd/parallel.py)
+            mine = fwd("cond", st.pe) if plan.cfg_idx == 0 else fwd("uncond", st.ne)
+            pc, pu = plan.exchange_cfg(mine)
+        else:
+            pc = fwd("cond", st.pe)
+            pu = fwd("uncond", st.ne) if st.cfg else None
+        o.cfg_euler_step_(st.lat, pc, pu, st.guidance, st.dt,
+                          round_out=getattr(self.scheduler, "cast_output_to_model_dtype", True))
 
     def make_state(self, latents, condition, traj_latents, id_latent, first_frame_mask, prompt_embeds,
                    negative_prompt_embeds, guidance_scale, attention_kwargs=None):

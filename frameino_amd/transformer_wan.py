@@ -137,6 +137,8 @@ class WanTransformer3DModel(nn.Module):
         self._text_cache = {}
         self._ws = {}
         self._ctx_name = None
+        self.ops = ops            # kernel front end (tests of the sharding logic inject a CPU stand-in)
+        self.parallel = None      # frameino_amd.parallel.TokenShard or None
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -236,12 +238,12 @@ class WanTransformer3DModel(nn.Module):
         outs = []
         for i in range(0, sinus.shape[0], 16):                                    # skinny kernel: <= 16 rows/call
             s = sinus[i:i + 16].to(wd).float().contiguous()                       # :179-181
-            h = ops.skinny_linear(s, te.linear_1.weight, te.linear_1.bias).to(wd)
+            h = self.ops.skinny_linear(s, te.linear_1.weight, te.linear_1.bias).to(wd)
             h = silu(h).float().contiguous()
-            e = ops.skinny_linear(h, te.linear_2.weight, te.linear_2.bias).to(wd)
+            e = self.ops.skinny_linear(h, te.linear_2.weight, te.linear_2.bias).to(wd)
             temb = e.to(act_dtype)                                                # .type_as(encoder_hidden_states) :182
             a = silu(temb).float().contiguous()                                   # act_fn(temb) in the act dtype :183
-            tp = ops.skinny_linear(a, ce.time_proj.weight, ce.time_proj.bias).to(ce.time_proj.weight.dtype)
+            tp = self.ops.skinny_linear(a, ce.time_proj.weight, ce.time_proj.bias).to(ce.time_proj.weight.dtype)
             outs.append((temb, tp))
         temb = torch.cat([o[0] for o in outs])
         tproj = torch.cat([o[1] for o in outs]).unflatten(1, (6, -1))
@@ -258,12 +260,12 @@ class WanTransformer3DModel(nn.Module):
         ce = self.condition_embedder
         d = self.inner_dim
         ctx = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1])
-        h = ops.gemm(ctx, ce.text_embedder.linear_1.weight, ce.text_embedder.linear_1.bias, ops.EPI_GELU_TANH)
-        txt = ops.gemm(h, ce.text_embedder.linear_2.weight, ce.text_embedder.linear_2.bias)
+        h = self.ops.gemm(ctx, ce.text_embedder.linear_1.weight, ce.text_embedder.linear_1.bias, self.ops.EPI_GELU_TANH)
+        txt = self.ops.gemm(h, ce.text_embedder.linear_2.weight, ce.text_embedder.linear_2.bias)
         kvs = []
         for blk, e in zip(self.blocks, pk.layers):
-            kv = ops.gemm(txt, e.wkv2, e.bkv2)                                     # [Lt, 2D]
-            ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
+            kv = self.ops.gemm(txt, e.wkv2, e.bkv2)                                     # [Lt, 2D]
+            self.ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
             kvs.append(kv)
         val = SimpleNamespace(txt=txt, kv=kvs)
         self._text_cache[self._ctx_name] = (key, val)
@@ -288,6 +290,7 @@ class WanTransformer3DModel(nn.Module):
             out = torch.cat(outs)
             return SimpleNamespace(sample=out) if return_dict else (out,)
         pk = self._packed or self._pack()
+        o = self.ops
         cfg = self.config
         _, c, nf, hh, ww = hidden_states.shape
         pt, ph, pw = cfg.patch_size
@@ -295,8 +298,16 @@ class WanTransformer3DModel(nn.Module):
         L = ppf * pph * ppw
         d, heads, dh = self.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim
         dev, dt = hidden_states.device, hidden_states.dtype
-        ws = self._workspace(L, dt, dev)
         cos, sin = self._rope(ppf, pph, ppw, dev)
+
+        # ---- token shard of this rank (frameino_amd/parallel.py); single GPU: the whole sequence ----
+        sh = self.parallel if (self.parallel is not None and self.parallel.ways > 1) else None
+        if sh is not None:
+            lo, n, lpad = sh.rows(L)              # first row, valid rows, padded shard length (equal on all ranks)
+            cos, sin = cos[lo:lo + n].contiguous(), sin[lo:lo + n].contiguous()
+        else:
+            lo, n, lpad = 0, L, L
+        ws = self._workspace(lpad, dt, dev)
 
         # ---- timestep rows + selector (F7) ----
         if timestep_rows is not None:
@@ -306,6 +317,8 @@ class WanTransformer3DModel(nn.Module):
             sel = inv.to(torch.int32).contiguous()
         else:
             t_rows, sel = timestep.reshape(1), None
+        if sel is not None and sh is not None:
+            sel = sel[lo:lo + n].contiguous()
         temb, tproj = self._time_rows(t_rows.to(dev), encoder_hidden_states.dtype)       # [R,D], [R,6,D]
         # per-layer modulation tables: scale_shift_table + temb.float()  (:317-319)  -> [R, layers, 6, D] fp32
         mod = (pk.sst[None] + tproj.float()[:, None]).contiguous()
@@ -313,50 +326,73 @@ class WanTransformer3DModel(nn.Module):
 
         text = self._text_kv(encoder_hidden_states, pk)
 
-        # ---- patch embedding (:486-487): gather + GEMM ----
-        ops.patchify(hidden_states[0], cfg.patch_size, out=ws.a)
-        x = ops.gemm(ws.a, pk.w_patch, self.patch_embedding.bias, out=ws.x)
+        # ---- patch embedding (:486-487): gather + GEMM (the gather is 9 MB; every rank builds it, keeps its rows) ----
+        a_full = o.patchify(hidden_states[0], cfg.patch_size)
+        x = o.gemm(a_full[lo:lo + n], pk.w_patch, self.patch_embedding.bias, out=ws.x[:n])
+        nrm, att, q2, ff = ws.n[:n], ws.att[:n], ws.q2[:n], ws.ff[:n]
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
             # 1. self-attention (:334-336)
-            ops.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=ws.n)
-            if pk.default_procs:
-                ops.gemm(ws.n, e.wqkv, e.bqkv, out=ws.qkv)
-                ops.rmsnorm_rope_(ws.qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
-                ops.rmsnorm_rope_(ws.qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
-                q3 = ws.qkv.view(1, L, 3 * d)
-                ops.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=ws.att.view(1, L, d))
-                ops.gemm(ws.att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, ops.EPI_GATED_RESIDUAL,
-                         residual=x, gate=m[:, 2], sel=sel, out=x)
-            else:
+            o.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=nrm)
+            if not pk.default_procs:
+                if sh is not None:
+                    raise NotImplementedError("token-sharded execution needs the built-in MI355WanAttnProcessor")
                 rot = _CompactRope((cos, sin))
-                a = blk.attn1(ws.n.view(1, L, d), rotary_emb=rot, **(attention_kwargs or {}))
-                ops.gated_residual(x, a.reshape(L, d), m[:, 2], sel, out=x)
-            # 2. cross-attention (:339-341)
-            n2 = blk.norm2
-            ops.layernorm(x, None if n2 is None else n2.weight, None if n2 is None else n2.bias, cfg.eps, out=ws.n) \
-                if n2 is not None else ws.n.copy_(x)
-            if pk.default_procs:
-                ops.gemm(ws.n, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=ws.q2)
-                ops.rmsnorm_rope_(ws.q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
-                kv = text.kv[li].view(1, -1, 2 * d)
-                ops.attention(ws.q2.view(1, L, d), kv[:, :, :d], kv[:, :, d:], heads, out=ws.att.view(1, L, d))
-                ops.gemm(ws.att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, ops.EPI_RESIDUAL, residual=x,
-                         out=x)
+                a = blk.attn1(nrm.view(1, n, d), rotary_emb=rot, **(attention_kwargs or {}))
+                o.gated_residual(x, a.reshape(n, d), m[:, 2], sel, out=x)
+            elif sh is None:
+                qkv = ws.qkv[:n]
+                o.gemm(nrm, e.wqkv, e.bqkv, out=qkv)
+                o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
+                o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                q3 = qkv.view(1, n, 3 * d)
+                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(1, n, d))
             else:
-                a = blk.attn2(ws.n.view(1, L, d), encoder_hidden_states=text.txt[None], **(attention_kwargs or {}))
-                ops.gated_residual(x, a.reshape(L, d), out=x)
+                # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
+                kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
+                o.gemm(nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n])
+                o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                kv_all, work = sh.all_gather_kv(kv_loc)
+                o.gemm(nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
+                o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
+                if work is not None:
+                    work.wait()
+                kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
+                o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
+            if pk.default_procs:
+                o.gemm(att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
+                       residual=x, gate=m[:, 2], sel=sel, out=x)
+            # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange
+            n2 = blk.norm2
+            if n2 is not None:
+                o.layernorm(x, n2.weight, n2.bias, cfg.eps, out=nrm)
+            else:
+                nrm.copy_(x)
+            if pk.default_procs:
+                o.gemm(nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=q2)
+                o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
+                kv = text.kv[li].view(1, -1, 2 * d)
+                o.attention(q2.view(1, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(1, n, d))
+                o.gemm(att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=x, out=x)
+            else:
+                a = blk.attn2(nrm.view(1, n, d), encoder_hidden_states=text.txt[None], **(attention_kwargs or {}))
+                o.gated_residual(x, a.reshape(n, d), out=x)
             # 3. feed-forward (:344-348)
-            ops.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=ws.n)
-            ops.gemm(ws.n, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, ops.EPI_GELU_TANH, out=ws.ff)
-            ops.gemm(ws.ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, ops.EPI_GATED_RESIDUAL, residual=x,
-                     gate=m[:, 5], sel=sel, out=x)
+            o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
+            o.gemm(nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
+            o.gemm(ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x, gate=m[:, 5],
+                   sel=sel, out=x)
 
         # ---- output head (:519-543) ----
-        ops.adaln_modulate(x, head[:, 0], head[:, 1], sel, cfg.eps, out=ws.n)
-        ops.gemm(ws.n, self.proj_out.weight, self.proj_out.bias, out=ws.po)
-        out = ops.unpatchify(ws.po, cfg.out_channels, nf, hh, ww, cfg.patch_size)[None]
+        o.adaln_modulate(x, head[:, 0], head[:, 1], sel, cfg.eps, out=nrm)
+        if sh is None:
+            po = o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=ws.po[:n])
+        else:
+            po_loc = sh.out_local(lpad, ws.po.shape[1], dt, dev)
+            o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=po_loc[:n])
+            po = sh.all_gather_out(po_loc)[:L]
+        out = o.unpatchify(po, cfg.out_channels, nf, hh, ww, cfg.patch_size)[None]
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
