@@ -67,3 +67,46 @@ def test_wan_denoise_loop_matches_reference_pipeline(golden):
     out = wan_denoise_loop(dit_sd, cfg, sched, a["latents0"], a["condition"], a["traj_latents"], a["id_latent"],
                            a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), steps)
     torch.testing.assert_close(out, a["out_latents"], atol=1e-4, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- Wan VAE
+def _vae_cfg(cfg):
+    out = dict(cfg)
+    for k in ("dim_mult", "temperal_downsample", "latents_mean", "latents_std"):
+        out[k] = list(out[k])
+    out["is_residual"] = bool(out["is_residual"])
+    return out
+
+
+def test_wan_vae_whole_sequence_equals_reference_chunked_streaming(golden):
+    """The oracle runs every layer once over the whole sequence; the reference streams chunks through feat_cache."""
+    from oracle import wan_vae as V
+    cfg, sd, a = golden("wan_vae_tiny")
+    cfg = _vae_cfg(cfg)
+    for nf in (1, 5, 9):
+        out = V.wan_vae_encode(sd, cfg, a[f"enc_in_{nf}"])
+        torch.testing.assert_close(out, a[f"enc_out_{nf}"], atol=1e-4, rtol=1e-4)
+    for nl in (1, 2, 3):
+        out = V.wan_vae_decode(sd, cfg, a[f"dec_in_{nl}"])
+        assert out.shape == a[f"dec_out_{nl}"].shape == (1, 3, 1 + 4 * (nl - 1), 32, 48)
+        torch.testing.assert_close(out, a[f"dec_out_{nl}"], atol=1e-4, rtol=1e-4)
+
+
+def test_wan_vae_in_reference_pipeline_run(golden):
+    """Conditions and decoded video of the recorded reference pipeline run (prepare_latents :400-553, decode :916-927)."""
+    from oracle import wan_vae as V
+    cfg, sd, a = golden("wan_pipe_tiny")
+    vcfg = _vae_cfg({k[4:]: v for k, v in cfg.items() if k.startswith("vae_")})
+    vsd = {k[4:]: v for k, v in sd.items() if k.startswith("vae.")}
+    z = vcfg["z_dim"]
+    mean = torch.tensor(vcfg["latents_mean"]).view(1, z, 1, 1, 1)
+    inv_std = 1.0 / torch.tensor(vcfg["latents_std"]).view(1, z, 1, 1, 1)
+    traj = a["traj"].unsqueeze(0).permute(0, 2, 1, 3, 4)
+    tl = (V.wan_vae_encode(vsd, vcfg, traj)[:, :z] - mean) * inv_std
+    torch.testing.assert_close(tl, a["traj_latents"][:, :, :tl.shape[2]], atol=1e-4, rtol=1e-4)
+    idl = (V.wan_vae_encode(vsd, vcfg, a["id_tensor"])[:, :z] - mean) * inv_std
+    torch.testing.assert_close(idl, a["id_latent"], atol=1e-4, rtol=1e-4)
+    video = V.wan_vae_decode(vsd, vcfg, a["out_latents"] / inv_std + mean)
+    ref = a["out_video"]                                   # [1, F, H, W, 3] in [0, 1]
+    got = (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
+    torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)

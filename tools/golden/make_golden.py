@@ -183,7 +183,34 @@ def gen_wan_pipe():
          steps=np.array(steps), guidance=np.array(5.0))
 
 
-GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe}
+# ----------------------------------------------------------------------------------- Wan VAE
+VAE_TINY = dict(base_dim=8, decoder_base_dim=16, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                temperal_downsample=[False, True, True], dropout=0.0, latents_mean=[0.1, -0.2, 0.3, 0.05],
+                latents_std=[1.1, 0.9, 1.3, 0.7], is_residual=True, in_channels=12, out_channels=12, patch_size=2,
+                scale_factor_temporal=4, scale_factor_spatial=16)
+
+
+def gen_wan_vae():
+    """G6: the reference's chunked (feat_cache streaming) encode / decode on a tiny Wan2.2-style residual VAE."""
+    from architecture.autoencoder_kl_wan import AutoencoderKLWan
+    torch.manual_seed(0)
+    vae = AutoencoderKLWan(**VAE_TINY).eval()
+    randomize_(vae, 21, std=0.12)
+    g = torch.Generator().manual_seed(22)
+    arrays = {}
+    for nf in (1, 5, 9):
+        x = torch.rand(1, 3, nf, 32, 48, generator=g) * 2 - 1
+        arrays[f"enc_in_{nf}"] = x
+        arrays[f"enc_out_{nf}"] = vae.encode(x).latent_dist.parameters       # moments [1, 2z, T', 2, 3]
+    for nl in (1, 2, 3):
+        z = torch.randn(1, 4, nl, 2, 3, generator=g)
+        arrays[f"dec_in_{nl}"] = z
+        arrays[f"dec_out_{nl}"] = vae.decode(z, return_dict=False)[0]
+    save("wan_vae_tiny", cfg={k: v for k, v in VAE_TINY.items() if k not in ("attn_scales",)}, sd=vae.state_dict(),
+         **arrays)
+
+
+GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
