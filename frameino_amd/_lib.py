@@ -32,6 +32,13 @@ SIGNATURES = {
     "fino_unpatchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
     "fino_wan_model_input": [c_void_p] * 5 + [c_int] * 6 + [c_void_p],
     "fino_cfg_euler_step": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_int, c_int, c_void_p],
+    "fino_conv3d": [c_void_p] * 4 + [c_int] * 19 + [c_void_p, c_void_p, c_int, c_void_p],
+    "fino_rmsnorm_silu_cl": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "fino_softmax_rows": [c_void_p, c_i64, c_int, c_i64, c_float, c_int, c_void_p],
+    "fino_dup_up3d_add": [c_void_p] * 3 + [c_int] * 10 + [c_void_p],
+    "fino_avg_down3d_add": [c_void_p] * 3 + [c_int] * 10 + [c_void_p],
+    "fino_vae_unpatchify_clamp": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "fino_vae_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
 }
 _RESTYPES = {"fino_last_error": ctypes.c_char_p}
 

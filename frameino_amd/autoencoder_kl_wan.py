@@ -1,0 +1,370 @@
+"""MI355X-native Wan 3D causal VAE (Wan2.2 residual variant) -- mirror of
+/root/reference/architecture/autoencoder_kl_wan.py::AutoencoderKLWan for the calls the FrameINO pipeline makes:
+`vae.encode(x).latent_dist.mode()/sample()`, `vae.decode(z, return_dict=False)[0]`, `vae.config.*`, `vae.dtype`.
+
+MI355X design:
+  * whole-sequence execution: the reference streams the time axis in chunks through 34 (decoder) / 26 (encoder)
+    `feat_cache` slots because a 24-80 GB GPU cannot hold the activations; every temporal conv is causal, so chunking
+    is only a schedule.  With 288 GB of HBM each layer runs ONCE over all frames (rules in oracle/wan_vae.py, checked
+    against the reference's streaming run): M = T.H.W output positions per conv launch, no cache bookkeeping.
+  * channels-last activations [T, H, W, Cpad] (Cpad = multiple of 64): every conv -- 3x3x3 causal, (3,1,1) time
+    convs, the 3x3 Conv2d of WanResample with its nearest-exact 2x upsample folded into the gather, 1x1x1 shortcuts --
+    is an implicit GEMM on the MFMA GEMM kernel (fino_conv3d), the residual add is its epilogue.
+  * RMS-norm+SiLU, DupUp3D/AvgDown3D shortcuts, patchify/unpatchify+clamp are fused HBM-bound kernels.
+Weights are stored under the reference's parameter names (`load_reference_state_dict`), packed once for the kernels.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+
+
+def cpad(c):
+    return (c + 63) // 64 * 64
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+class DiagonalGaussianDistribution:
+    """diffusers' posterior object for the two calls the pipelines make (mode / sample)."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None):
+        gdev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype)
+        return self.mean + self.std * noise.to(self.mean.device)
+
+
+def wan_vae_param_shapes(cfg):
+    """Parameter names and shapes of the reference module tree (is_residual=True)."""
+    mult = list(cfg["dim_mult"])
+    enc = [cfg["base_dim"] * u for u in [1] + mult]
+    dec = [cfg["decoder_base_dim"] * u for u in [mult[-1]] + mult[::-1]]
+    z, nres = cfg["z_dim"], cfg["num_res_blocks"]
+    tdown = list(cfg["temperal_downsample"])
+    tup = tdown[::-1]
+    s = {}
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"] = (co, ci) + tuple(k)
+        s[name + ".bias"] = (co,)
+
+    def res(name, ci, co):
+        s[name + ".norm1.gamma"] = (ci, 1, 1, 1)
+        conv(name + ".conv1", co, ci, (3, 3, 3))
+        s[name + ".norm2.gamma"] = (co, 1, 1, 1)
+        conv(name + ".conv2", co, co, (3, 3, 3))
+        if ci != co:
+            conv(name + ".conv_shortcut", co, ci, (1, 1, 1))
+
+    def mid(name, c):
+        res(name + ".resnets.0", c, c)
+        s[name + ".attentions.0.norm.gamma"] = (c, 1, 1)
+        conv(name + ".attentions.0.to_qkv", 3 * c, c, (1, 1))
+        conv(name + ".attentions.0.proj", c, c, (1, 1))
+        res(name + ".resnets.1", c, c)
+
+    conv("encoder.conv_in", enc[0], cfg["in_channels"], (3, 3, 3))
+    nb = len(mult)
+    for i in range(nb):
+        p = f"encoder.down_blocks.{i}"
+        ci = enc[i]
+        for r in range(nres):
+            res(f"{p}.resnets.{r}", ci, enc[i + 1])
+            ci = enc[i + 1]
+        if i != nb - 1:
+            conv(f"{p}.downsampler.resample.1", enc[i + 1], enc[i + 1], (3, 3))
+            if tdown[i]:
+                conv(f"{p}.downsampler.time_conv", enc[i + 1], enc[i + 1], (3, 1, 1))
+    mid("encoder.mid_block", enc[-1])
+    s["encoder.norm_out.gamma"] = (enc[-1], 1, 1, 1)
+    conv("encoder.conv_out", 2 * z, enc[-1], (3, 3, 3))
+    conv("quant_conv", 2 * z, 2 * z, (1, 1, 1))
+    conv("post_quant_conv", z, z, (1, 1, 1))
+    conv("decoder.conv_in", dec[0], z, (3, 3, 3))
+    mid("decoder.mid_block", dec[0])
+    for i in range(nb):
+        p = f"decoder.up_blocks.{i}"
+        ci = dec[i]
+        for r in range(nres + 1):
+            res(f"{p}.resnets.{r}", ci, dec[i + 1])
+            ci = dec[i + 1]
+        if i != nb - 1:
+            conv(f"{p}.upsampler.resample.1", dec[i + 1], dec[i + 1], (3, 3))
+            if tup[i]:
+                conv(f"{p}.upsampler.time_conv", 2 * dec[i + 1], dec[i + 1], (3, 1, 1))
+    s["decoder.norm_out.gamma"] = (dec[-1], 1, 1, 1)
+    conv("decoder.conv_out", cfg["out_channels"], dec[-1], (3, 3, 3))
+    return s
+
+
+class AutoencoderKLWan:
+    def __init__(self, base_dim=96, decoder_base_dim=None, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
+                 attn_scales=(), temperal_downsample=(False, True, True), dropout=0.0, latents_mean=None,
+                 latents_std=None, is_residual=False, in_channels=3, out_channels=3, patch_size=None,
+                 scale_factor_temporal=4, scale_factor_spatial=8):
+        if not is_residual:
+            raise NotImplementedError("FrameINO's Wan path uses the Wan2.2 residual VAE (is_residual=True)")
+        self.config = _Config(base_dim=base_dim, decoder_base_dim=decoder_base_dim or base_dim, z_dim=z_dim,
+                              dim_mult=list(dim_mult), num_res_blocks=num_res_blocks, attn_scales=list(attn_scales),
+                              temperal_downsample=list(temperal_downsample), dropout=dropout,
+                              latents_mean=list(latents_mean or [0.0] * z_dim),
+                              latents_std=list(latents_std or [1.0] * z_dim), is_residual=is_residual,
+                              in_channels=in_channels, out_channels=out_channels, patch_size=patch_size,
+                              scale_factor_temporal=scale_factor_temporal, scale_factor_spatial=scale_factor_spatial)
+        self._sd = None
+        self._pk = None
+        self._dtype = torch.bfloat16
+        self._device = torch.device("cpu")
+        self.use_slicing = self.use_tiling = False
+
+    # ---- module-like surface ----
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        if dtype is not None:
+            self._dtype = dtype
+        if device is not None:
+            self._device = torch.device(device)
+        if self._sd is not None:
+            self._sd = {k: v.to(self._device) for k, v in self._sd.items()}
+            self._pk = None
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def load_reference_state_dict(self, sd, dtype=torch.bfloat16):
+        shapes = wan_vae_param_shapes(self.config)
+        missing = [k for k in shapes if k not in sd]
+        if missing:
+            raise KeyError(f"VAE state-dict is missing {missing[:5]}")
+        for k, shp in shapes.items():
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: expected {shp}, got {tuple(sd[k].shape)}")
+        self._sd = {k: sd[k].detach().to(self._device).float() for k in shapes}
+        self._dtype = dtype
+        self._pk = None
+        return self
+
+    def random_init_(self, seed=0, std=0.03, device=None, dtype=torch.bfloat16):
+        """Seeded random weights of the right shapes (no checkpoints offline)."""
+        if device is not None:
+            self._device = torch.device(device)
+        g = torch.Generator(device=self._device).manual_seed(seed)
+        sd = {}
+        for k, shp in wan_vae_param_shapes(self.config).items():
+            if k.endswith("gamma"):
+                sd[k] = 1.0 + 0.05 * torch.randn(shp, generator=g, device=self._device)
+            elif k.endswith("bias"):
+                sd[k] = 0.01 * torch.randn(shp, generator=g, device=self._device)
+            else:
+                fan = math.prod(shp[1:])
+                sd[k] = torch.randn(shp, generator=g, device=self._device) * (1.0 / math.sqrt(fan))
+        self._sd, self._dtype, self._pk = sd, dtype, None
+        return self
+
+    # ---- packing ----
+    def _pack(self):
+        sd, dt = self._sd, self._dtype
+        pk = {}
+
+        def pack_conv(name, halves=1):
+            w = sd[name + ".weight"]
+            b = sd[name + ".bias"]
+            if w.dim() == 4:
+                w = w.unsqueeze(2)                           # Conv2d -> kt = 1
+            co, ci, kt, kh, kw = w.shape
+            cip = cpad(ci)
+            coh = co // halves
+            cop = cpad(coh)
+            w2 = torch.zeros(halves * cop, kt * kh * kw, cip, device=w.device, dtype=torch.float32)
+            b2 = torch.zeros(halves * cop, device=w.device, dtype=torch.float32)
+            wt = w.permute(0, 2, 3, 4, 1).reshape(co, kt * kh * kw, ci)      # [co, tap, ci], tap = (dt*kh+dh)*kw+dw
+            for s in range(halves):
+                w2[s * cop:s * cop + coh, :, :ci] = wt[s * coh:(s + 1) * coh]
+                b2[s * cop:s * cop + coh] = b[s * coh:(s + 1) * coh]
+            pk[name] = SimpleNamespace(w=w2.reshape(halves * cop, -1).to(dt).contiguous(), b=b2.to(dt), k=(kt, kh, kw),
+                                       ci=ci, co=coh, cip=cip, cop=cop)
+
+        def pack_gamma(name):
+            g = sd[name].reshape(-1)
+            out = torch.zeros(cpad(g.numel()), device=g.device, dtype=torch.float32)
+            out[:g.numel()] = g
+            pk[name] = SimpleNamespace(g=out, c=g.numel())
+
+        for k in sd:
+            if k.endswith(".weight"):
+                n = k[:-7]
+                if n.endswith("upsampler.time_conv"):
+                    pack_conv(n, halves=2)
+                elif n.endswith("to_qkv"):
+                    pack_conv(n, halves=3)
+                else:
+                    pack_conv(n)
+            elif k.endswith("gamma"):
+                pack_gamma(k)
+        self._pk = pk
+        return pk
+
+    # ---- layer helpers (all on channels-last [T, H, W, Cpad]) ----
+    def _conv(self, x, name, pad, stride=(1, 1, 1), up=False, residual=None, out_thw=None):
+        e = self._pk[name]
+        return ops.conv3d_cl(x, e.w, e.b, e.k, stride, pad, out_thw, up, residual)
+
+    def _causal3(self, x, name, residual=None):
+        e = self._pk[name]
+        kt, kh, kw = e.k
+        return self._conv(x, name, (kt - 1, kh // 2, kw // 2), residual=residual)
+
+    def _norm(self, x, name, silu=True):
+        e = self._pk[name]
+        return ops.rmsnorm_silu_cl(x, e.g, e.c, silu)
+
+    def _res(self, x, p):
+        h = self._causal3(x, p + ".conv_shortcut") if (p + ".conv_shortcut") in self._pk else x
+        y = self._causal3(self._norm(x, p + ".norm1.gamma"), p + ".conv1")
+        return self._causal3(self._norm(y, p + ".norm2.gamma"), p + ".conv2", residual=h)
+
+    def _attn(self, x, p):
+        """WanAttentionBlock (:402-427): one head of dim C over the h.w tokens of each frame."""
+        t, h, w, cp = x.shape
+        e = self._pk[p + ".to_qkv"]
+        c, hw = e.co, h * w
+        hwp = (hw + 7) // 8 * 8
+        n = self._norm(x, p + ".norm.gamma", silu=False).view(t, hw, cp)
+        wq, wk, wv = e.w[:cp], e.w[cp:2 * cp], e.w[2 * cp:]
+        bq, bk, bv = e.b[:cp], e.b[cp:2 * cp], e.b[2 * cp:]
+        out = torch.empty_like(n)
+        scale = c ** -0.5
+        pr = self._pk[p + ".proj"]
+        for f in range(t):
+            nf = n[f]
+            if hwp != hw:                                     # tiny test shapes only: pad tokens to a multiple of 8
+                nf = torch.zeros(hwp, cp, dtype=x.dtype, device=x.device)
+                nf[:hw] = n[f]
+            q = ops.gemm(nf[:hw], wq, bq)
+            k = ops.gemm(nf, wk, bk)
+            if hwp != hw:
+                k[hw:] = 0
+            vt = ops.gemm(wv, nf)                             # V^T [Cpad, hwp] (bias added after P.V: rows of P sum to 1)
+            s = ops.gemm(q, k)                                # [hw, hwp]
+            ops.softmax_rows_(s, hw, scale)
+            if hwp != hw:
+                s[:, hw:] = 0
+            o = ops.gemm(s, vt, bv)
+            ops.gemm(o, pr.w, pr.b, ops.EPI_RESIDUAL, residual=x.view(t, hw, cp)[f], out=out[f])
+        return out.view(t, h, w, cp)
+
+    def _mid(self, x, p):
+        x = self._res(x, p + ".resnets.0")
+        x = self._attn(x, p + ".attentions.0")
+        return self._res(x, p + ".resnets.1")
+
+    # ---- decode (reference :1198-1227, whole-sequence) ----
+    @torch.no_grad()
+    def decode(self, z, return_dict=True):
+        if z.shape[0] != 1:
+            outs = [self.decode(z[i:i + 1], return_dict=False)[0] for i in range(z.shape[0])]
+            out = torch.cat(outs)
+            return (out,) if not return_dict else SimpleNamespace(sample=out)
+        pk = self._pk or self._pack()
+        cfg, dt = self.config, self._dtype
+        mult = cfg.dim_mult
+        dec = [cfg.decoder_base_dim * u for u in [mult[-1]] + mult[::-1]]
+        tup = cfg.temperal_downsample[::-1]
+        zc = cfg.z_dim
+        _, _, t, h, w = z.shape
+        x = torch.zeros(t, h, w, cpad(zc), dtype=dt, device=z.device)
+        x[..., :zc] = z[0].permute(1, 2, 3, 0).to(dt)
+        x = self._causal3(x, "post_quant_conv")
+        x = self._causal3(x, "decoder.conv_in")
+        x = self._mid(x, "decoder.mid_block")
+        nb = len(mult)
+        for i in range(nb):
+            p = f"decoder.up_blocks.{i}"
+            up_flag = i != nb - 1
+            temporal = bool(tup[i]) if up_flag else False
+            x_copy = x
+            for r in range(cfg.num_res_blocks + 1):
+                x = self._res(x, f"{p}.resnets.{r}")
+            if up_flag:
+                if temporal and x.shape[0] > 1:
+                    e = pk[p + ".upsampler.time_conv"]
+                    tt, hh, ww, cp = x.shape
+                    y = self._causal3(x[1:].contiguous(), p + ".upsampler.time_conv")     # [T-1, H, W, 2*Cpad]
+                    xn = torch.empty(1 + 2 * (tt - 1), hh, ww, cp, dtype=dt, device=x.device)
+                    xn[0] = x[0]
+                    xn[1:].view(tt - 1, 2, hh, ww, cp).copy_(y.view(tt - 1, hh, ww, 2, e.cop).permute(0, 3, 1, 2, 4))
+                    x = xn
+                x = self._conv(x, p + ".upsampler.resample.1", (0, 1, 1), up=True)
+                x = ops.dup_up3d_add(x, x_copy, dec[i], dec[i + 1], 2 if temporal else 1, 2)
+        x = self._norm(x, "decoder.norm_out.gamma")
+        x = self._causal3(x, "decoder.conv_out")
+        out = ops.vae_unpatchify_clamp(x, cfg.out_channels // (cfg.patch_size or 1) ** 2, cfg.patch_size or 1)[None]
+        return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+    # ---- encode (reference :1145-1169, whole-sequence) ----
+    @torch.no_grad()
+    def _encode(self, x):
+        pk = self._pk or self._pack()
+        cfg, dt = self.config, self._dtype
+        mult = cfg.dim_mult
+        enc = [cfg.base_dim * u for u in [1] + mult]
+        tdown = cfg.temperal_downsample
+        ps = cfg.patch_size or 1
+        x = ops.vae_patchify(x[0].float().contiguous(), cpad(cfg.in_channels), ps, dt)
+        x = self._causal3(x, "encoder.conv_in")
+        nb = len(mult)
+        for i in range(nb):
+            p = f"encoder.down_blocks.{i}"
+            down_flag = i != nb - 1
+            temporal = bool(tdown[i]) if down_flag else False
+            x_copy = x
+            for r in range(cfg.num_res_blocks):
+                x = self._res(x, f"{p}.resnets.{r}")
+            if down_flag:
+                tt, hh, ww, _ = x.shape
+                # ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2): taps past the bottom/right edge read zeros
+                x = self._conv(x, p + ".downsampler.resample.1", (0, 0, 0), stride=(1, 2, 2),
+                               out_thw=(tt, hh // 2, ww // 2))
+                if temporal and x.shape[0] > 1:
+                    tt = x.shape[0]
+                    zc = self._conv(x, p + ".downsampler.time_conv", (0, 0, 0), stride=(2, 1, 1),
+                                    out_thw=((tt - 1) // 2, x.shape[1], x.shape[2]))
+                    x = torch.cat([x[:1], zc], dim=0)
+            x = ops.avg_down3d_add(x, x_copy, enc[i], enc[i + 1], 2 if temporal else 1, 2 if down_flag else 1)
+        x = self._mid(x, "encoder.mid_block")
+        x = self._norm(x, "encoder.norm_out.gamma")
+        x = self._causal3(x, "encoder.conv_out")
+        x = self._causal3(x, "quant_conv")
+        z2 = 2 * cfg.z_dim
+        return x[..., :z2].permute(3, 0, 1, 2).float()[None].contiguous()             # [1, 2z, T', h, w]
+
+    def encode(self, x, return_dict=True):
+        moments = torch.cat([self._encode(x[i:i + 1]) for i in range(x.shape[0])])
+        post = DiagonalGaussianDistribution(moments)
+        return (post,) if not return_dict else SimpleNamespace(latent_dist=post)

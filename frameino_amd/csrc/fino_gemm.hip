@@ -33,6 +33,11 @@ struct GemmParams {
     const int32_t* sel;
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
+    // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
+    // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
+    int to, ho, wo, ti, hi, wi;      // output / input extents
+    int kt, kh, kw, st, sh, sw, pt, ph, pw, up, cin_chunks;
+    const uint16_t* zero_page;       // >= 128 B of zeros: source of out-of-range taps (LDS-DMA cannot zero-fill)
 };
 
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
@@ -44,7 +49,7 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
 // swizzle of the 16-byte chunk index inside a 128-byte tile row
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <typename T, int EPI, bool GENERIC>
+template <typename T, int EPI, bool GENERIC, bool CONV>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::vec8 vec8;
@@ -92,11 +97,46 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
         a_src[j] = p.a + gm * p.lda + sk[j];
         w_src[j] = p.w + gn * p.ldw + sk[j];
     }
+    // CONV: output position of each staged row
+    int pos_t[4], pos_h[4], pos_w[4];
+    if constexpr (CONV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t gm = m0 + j * 64 + srow;
+            if (gm >= p.m) gm = p.m - 1;
+            const int hw = p.ho * p.wo;
+            pos_t[j] = (int)(gm / hw);
+            const int rem = (int)(gm - (int64_t)pos_t[j] * hw);
+            pos_h[j] = rem / p.wo;
+            pos_w[j] = rem - pos_h[j] * p.wo;
+        }
+    }
     auto stage = [&](int buf, int kt) {
         char* ab = smem + buf * kStageBytes;
         char* wb = ab + kTileBytes;
         const int64_t k0 = (int64_t)kt * BK;
-        if constexpr (!GENERIC) {
+        if constexpr (CONV) {
+            const int tap = kt / p.cin_chunks;
+            const int c0 = (kt - tap * p.cin_chunks) * BK;
+            const int dw = tap % p.kw;
+            const int dh = (tap / p.kw) % p.kh;
+            const int dt = tap / (p.kw * p.kh);
+            const int hlim = p.up ? 2 * p.hi : p.hi, wlim = p.up ? 2 * p.wi : p.wi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ti = pos_t[j] * p.st + dt - p.pt;
+                int hi = pos_h[j] * p.sh + dh - p.ph;
+                int wi = pos_w[j] * p.sw + dw - p.pw;
+                const bool ok = a_ok[j] && ti >= 0 && ti < p.ti && hi >= 0 && hi < hlim && wi >= 0 && wi < wlim;
+                if (p.up) { hi >>= 1; wi >>= 1; }
+                const uint16_t* src = ok ? p.a + (((int64_t)ti * p.hi + hi) * p.wi + wi) * p.lda + c0 + sk[j]
+                                         : p.zero_page + sk[j];
+                __builtin_amdgcn_global_load_lds((const FINO_GLB void*)src,
+                                                 (FINO_LDS void*)(ab + j * 8192 + wave * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const FINO_GLB void*)(w_src[j] + k0),
+                                                 (FINO_LDS void*)(wb + j * 8192 + wave * 1024), 16, 0, 0);
+            }
+        } else if constexpr (!GENERIC) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 __builtin_amdgcn_global_load_lds((const FINO_GLB void*)(a_src[j] + k0),
@@ -214,11 +254,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <typename T, int EPI, bool GENERIC>
+template <typename T, int EPI, bool GENERIC, bool CONV = false>
 int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, GENERIC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, GENERIC, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         if (e != hipSuccess) {
             fino_set_error("fino_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -226,7 +266,7 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    gemm_kernel<T, EPI, GENERIC><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    gemm_kernel<T, EPI, GENERIC, CONV><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -303,7 +343,7 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
     if (epilogue == FINO_EPI_GATED_RESIDUAL)
         FINO_CHECK(gate && fino_aligned16(gate) && mod_stride % 4 == 0, FINO_ERR_ARG, "fino_gemm: gate operand");
     if (m == 0) return FINO_OK;
-    GemmParams p;
+    GemmParams p = {};
     p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.c = (uint16_t*)c;
     p.r = (const uint16_t*)r; p.gate = gate; p.sel = sel;
     p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
@@ -314,6 +354,40 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
     if (dtype == FINO_BF16)
         return generic ? launch_gemm_e<BF16, true>(p, epilogue, st) : launch_gemm_e<BF16, false>(p, epilogue, st);
     return generic ? launch_gemm_e<F16, true>(p, epilogue, st) : launch_gemm_e<F16, false>(p, epilogue, st);
+}
+
+extern "C" int fino_conv3d(const void* x, const void* w, const void* bias, void* y, int t_in, int h_in, int w_in,
+                           int c_in_pad, int t_out, int h_out, int w_out, int c_out_pad, int kt, int kh, int kw, int st,
+                           int sh, int sw, int pt, int ph, int pw, int upsample2x, int epilogue, const void* r,
+                           const void* zero_page, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_conv3d: dtype %d", dtype);
+    FINO_CHECK(x && w && y && zero_page, FINO_ERR_ARG, "fino_conv3d: null pointer");
+    FINO_CHECK(c_in_pad > 0 && c_in_pad % BK == 0, FINO_ERR_ARG,
+               "fino_conv3d: c_in_pad=%d must be a multiple of %d (pad channels with zeros)", c_in_pad, BK);
+    FINO_CHECK(c_out_pad > 0 && c_out_pad % 8 == 0, FINO_ERR_ARG, "fino_conv3d: c_out_pad=%d %% 8 != 0", c_out_pad);
+    FINO_CHECK(t_in > 0 && h_in > 0 && w_in > 0 && t_out > 0 && h_out > 0 && w_out > 0 && kt > 0 && kh > 0 && kw > 0 &&
+                   st > 0 && sh > 0 && sw > 0 && pt >= 0 && ph >= 0 && pw >= 0,
+               FINO_ERR_ARG, "fino_conv3d: bad geometry");
+    FINO_CHECK(epilogue == FINO_EPI_NONE || (epilogue == FINO_EPI_RESIDUAL && r), FINO_ERR_ARG,
+               "fino_conv3d: epilogue %d (NONE or RESIDUAL with r)", epilogue);
+    FINO_CHECK(fino_aligned16(x) && fino_aligned16(w) && fino_aligned16(y) && fino_aligned16(r) &&
+                   fino_aligned16(zero_page),
+               FINO_ERR_ARG, "fino_conv3d: 16-byte alignment required");
+    GemmParams p = {};
+    p.a = (const uint16_t*)x; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.c = (uint16_t*)y;
+    p.r = (const uint16_t*)r; p.gate = nullptr; p.sel = nullptr;
+    p.m = (int64_t)t_out * h_out * w_out; p.n = c_out_pad; p.k = (int64_t)kt * kh * kw * c_in_pad;
+    p.lda = c_in_pad; p.ldw = p.k; p.ldc = c_out_pad; p.ldr = c_out_pad; p.mod_stride = 0;
+    p.tiles_m = (int)((p.m + BM - 1) / BM); p.tiles_n = (int)((p.n + BN - 1) / BN);
+    p.to = t_out; p.ho = h_out; p.wo = w_out; p.ti = t_in; p.hi = h_in; p.wi = w_in;
+    p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.sh = sh; p.sw = sw; p.pt = pt; p.ph = ph; p.pw = pw;
+    p.up = upsample2x; p.cin_chunks = c_in_pad / BK; p.zero_page = (const uint16_t*)zero_page;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        return epilogue == FINO_EPI_NONE ? launch_gemm_t<BF16, FINO_EPI_NONE, false, true>(p, s)
+                                         : launch_gemm_t<BF16, FINO_EPI_RESIDUAL, false, true>(p, s);
+    return epilogue == FINO_EPI_NONE ? launch_gemm_t<F16, FINO_EPI_NONE, false, true>(p, s)
+                                     : launch_gemm_t<F16, FINO_EPI_RESIDUAL, false, true>(p, s);
 }
 
 extern "C" int fino_skinny_linear(const float* x, const void* w, const void* b, float* y, int m, int64_t n,

@@ -244,3 +244,92 @@ def cfg_euler_step_(lat, cond_pred, uncond_pred, guidance, dt_dev, round_out=Tru
                                              _p(dt_dev), int(round_out), _dt(cond_pred), _stream()),
                "fino_cfg_euler_step")
     return lat
+
+
+# ------------------------------------------------------------------------------------------------ Wan VAE (channels-last)
+_ZERO_PAGE = {}
+
+
+def zero_page(device):
+    z = _ZERO_PAGE.get(str(device))
+    if z is None:
+        z = _ZERO_PAGE[str(device)] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return z
+
+
+def conv3d_cl(x, w2, bias, kernel, stride=(1, 1, 1), pad=(0, 0, 0), out_thw=None, upsample2x=False, residual=None,
+              out=None):
+    """x [T,H,W,Cin_pad] channels-last; w2 [Cout_pad, kt*kh*kw*Cin_pad] (tap-major); pad = FRONT pads (t,h,w)."""
+    assert x.dim() == 4 and x.is_contiguous() and w2.is_contiguous()
+    t, h, w, cin = x.shape
+    kt, kh, kw = kernel
+    cout = w2.shape[0]
+    assert w2.shape[1] == kt * kh * kw * cin, (w2.shape, kernel, cin)
+    if out_thw is None:
+        up = 2 if upsample2x else 1
+        out_thw = ((t + pad[0] - kt) // stride[0] + 1, (h * up + 2 * pad[1] - kh) // stride[1] + 1,
+                   (w * up + 2 * pad[2] - kw) // stride[2] + 1)
+    to, ho, wo = out_thw
+    if out is None:
+        out = torch.empty((to, ho, wo, cout), dtype=x.dtype, device=x.device)
+    ev = _timed("conv3d")
+    _lib.check(_lib.lib().fino_conv3d(_p(x), _p(w2), _p(bias), _p(out), t, h, w, cin, to, ho, wo, cout, kt, kh, kw,
+                                     stride[0], stride[1], stride[2], pad[0], pad[1], pad[2], int(upsample2x),
+                                     EPI_RESIDUAL if residual is not None else EPI_NONE, _p(residual),
+                                     _p(zero_page(x.device)), _dt(x), _stream()), "fino_conv3d")
+    if ev is not None:
+        ev.record()
+        kt_ = KernelTimer.active
+        kt_.flops["conv3d"] = kt_.flops.get("conv3d", 0.0) + 2.0 * to * ho * wo * cout * w2.shape[1]
+    return out
+
+
+def rmsnorm_silu_cl(x, gamma, c_valid, silu=True, out=None):
+    assert x.is_contiguous() and gamma.dtype == torch.float32
+    cpad = x.shape[-1]
+    rows = x.numel() // cpad
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().fino_rmsnorm_silu_cl(_p(x), _p(out), rows, c_valid, cpad, _p(gamma), int(silu), _dt(x),
+                                              _stream()), "fino_rmsnorm_silu_cl")
+    return out
+
+
+def softmax_rows_(s, n, scale):
+    assert s.dim() == 2 and s.stride(1) == 1
+    _lib.check(_lib.lib().fino_softmax_rows(_p(s), s.shape[0], n, s.stride(0), float(scale), _dt(s), _stream()),
+               "fino_softmax_rows")
+    return s
+
+
+def dup_up3d_add(main, x, c_in, c_out, factor_t, factor_s):
+    t, h, w, cin_pad = x.shape
+    out = torch.empty_like(main)
+    assert main.shape == (1 + (t - 1) * factor_t, h * factor_s, w * factor_s, main.shape[3])
+    _lib.check(_lib.lib().fino_dup_up3d_add(_p(main), _p(x), _p(out), t, h, w, c_in, cin_pad, c_out, main.shape[3],
+                                           factor_t, factor_s, _dt(x), _stream()), "fino_dup_up3d_add")
+    return out
+
+
+def avg_down3d_add(main, x, c_in, c_out, factor_t, factor_s):
+    t, h, w, cin_pad = x.shape
+    out = torch.empty_like(main)
+    _lib.check(_lib.lib().fino_avg_down3d_add(_p(main), _p(x), _p(out), t, h, w, c_in, cin_pad, c_out, main.shape[3],
+                                             factor_t, factor_s, _dt(x), _stream()), "fino_avg_down3d_add")
+    return out
+
+
+def vae_unpatchify_clamp(y, channels, patch):
+    t, h, w, cpad = y.shape
+    out = torch.empty((channels, t, h * patch, w * patch), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().fino_vae_unpatchify_clamp(_p(y), _p(out), t, h, w, cpad, channels, patch, _dt(y), _stream()),
+               "fino_vae_unpatchify_clamp")
+    return out
+
+
+def vae_patchify(x, c_pad, patch, dtype):
+    c, t, hp, wp = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty((t, hp // patch, wp // patch, c_pad), dtype=dtype, device=x.device)
+    _lib.check(_lib.lib().fino_vae_patchify(_p(x), _p(y), t, hp // patch, wp // patch, c_pad, c, patch, _dt(y),
+                                           _stream()), "fino_vae_patchify")
+    return y

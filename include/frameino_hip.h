@@ -125,6 +125,38 @@ int fino_cfg_euler_step(const void* cond_pred, const void* uncond_pred, float* l
                         int total_frames, int height, int width, float guidance, const float* dt_dev, int round_out,
                         int dtype, void* stream);
 
+/* ---- Wan 3D causal VAE (architecture/autoencoder_kl_wan.py) ------------------------------------------------------
+ * Activations are channels-last [T, H, W, Cpad] of `dtype`, Cpad = channels zero-padded to a multiple of 64.
+ * fino_conv3d: implicit-GEMM convolution (MFMA-bound) -- WanCausalConv3d (:134-176), the Conv2d of WanResample
+ * (:244-260) and its nearest-exact 2x upsample (:205-217, fused into the gather when upsample2x != 0).
+ *   y[t,h,w,o] = bias[o] + sum_{dt,dh,dw,c} w[o][((dt*kh+dh)*kw+dw)*c_in_pad + c] *
+ *                x[t*st+dt-pt, (h*sh+dh-ph) >> up, (w*sw+dw-pw) >> up, c]     (taps outside the input read zeros)
+ * Causal convs pass pt = kt-1 (zeros in FRONT of the whole sequence -- the reference's feat_cache streaming is only a
+ * schedule of the same causal conv).  epilogue: FINO_EPI_NONE or FINO_EPI_RESIDUAL (y += r, r like y; ResBlock :382).
+ * zero_page: >= 128 bytes of zeros in device memory. */
+int fino_conv3d(const void* x, const void* w, const void* bias, void* y, int t_in, int h_in, int w_in, int c_in_pad,
+                int t_out, int h_out, int w_out, int c_out_pad, int kt, int kh, int kw, int st, int sh, int sw, int pt,
+                int ph, int pw, int upsample2x, int epilogue, const void* r, const void* zero_page, int dtype,
+                void* stream);
+/* WanRMS_norm (:179-202) [+ SiLU]: y = act(x / max(||x||_2, 1e-12) * sqrt(c_valid) * gamma), gamma fp32 [c_pad]. */
+int fino_rmsnorm_silu_cl(const void* x, void* y, int64_t rows, int c_valid, int c_pad, const float* gamma, int silu,
+                         int dtype, void* stream);
+/* in-place softmax over the first n columns of each row of s [rows, ld] of softmax(scale * s) (mid-block attention
+ * :402-427: one head of dim C, computed as S = Q.K^T -> softmax -> P.V with the GEMM kernel). */
+int fino_softmax_rows(void* s, int64_t rows, int n, int64_t ld, float scale, int dtype, void* stream);
+/* out = main + DupUp3D(x) (:90-131; frame 0 keeps only its last temporal copy = the reference's first_chunk). */
+int fino_dup_up3d_add(const void* main_in, const void* x, void* out, int t_in, int h_in, int w_in, int c_in,
+                      int c_in_pad, int c_out, int c_out_pad, int factor_t, int factor_s, int dtype, void* stream);
+/* out = main + AvgDown3D(x) (:37-87; one zero frame in front when t_in is not a multiple of factor_t). */
+int fino_avg_down3d_add(const void* main_in, const void* x, void* out, int t_in, int h_in, int w_in, int c_in,
+                        int c_in_pad, int c_out, int c_out_pad, int factor_t, int factor_s, int dtype, void* stream);
+/* decoder tail: unpatchify (:935-952) + clamp(-1,1) (:1221): y [T,H,W,c_pad] -> out fp32 [channels, T, H*p, W*p]. */
+int fino_vae_unpatchify_clamp(const void* y, float* out, int t, int h, int w, int c_pad, int channels, int patch,
+                              int dtype, void* stream);
+/* encoder head: patchify (:912-932): x fp32 [channels, T, H*p, W*p] -> y [T,H,W,c_pad]. */
+int fino_vae_patchify(const float* x, void* y, int t, int h, int w, int c_pad, int channels, int patch, int dtype,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

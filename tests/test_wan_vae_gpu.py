@@ -1,0 +1,121 @@
+"""Wan VAE on the HIP path: conv kernel vs F.conv3d for every geometry the VAE uses, and whole-model encode / decode
+vs the golden vectors recorded from the reference's chunked streaming run (bf16 storage vs the fp32 reference:
+stated tolerance rel-RMS <= 3e-2 on the latent moments, PSNR >= 35 dB on the decoded video in [-1, 1])."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.parity import rel_rms
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _pack(w, cin_pad, cout_pad):
+    co, ci, kt, kh, kw = w.shape
+    w2 = torch.zeros(cout_pad, kt * kh * kw, cin_pad)
+    w2[:co, :, :ci] = w.permute(0, 2, 3, 4, 1).reshape(co, kt * kh * kw, ci)
+    return w2.reshape(cout_pad, -1)
+
+
+@pytest.mark.parametrize("name,ci,co,k,stride,pad,up,thw", [
+    ("causal3x3x3", 48, 72, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, (5, 6, 7)),
+    ("1x1x1", 100, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (3, 5, 4)),
+    ("time_conv", 64, 128, (3, 1, 1), (1, 1, 1), (2, 0, 0), False, (4, 5, 6)),
+    ("up2x+conv2d", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, (3, 5, 6)),
+    ("down conv2d s2", 40, 40, (1, 3, 3), (1, 2, 2), (0, 0, 0), False, (3, 8, 10)),
+    ("down time s2", 64, 64, (3, 1, 1), (2, 1, 1), (0, 0, 0), False, (9, 4, 5)),
+])
+def test_conv3d_geometries_vs_torch(name, ci, co, k, stride, pad, up, thw):
+    from frameino_amd import ops
+    from frameino_amd.autoencoder_kl_wan import cpad
+    g = torch.Generator().manual_seed(1)
+    t, h, w = thw
+    x = torch.randn(1, ci, t, h, w, generator=g)
+    wt = torch.randn(co, ci, *k, generator=g) / math.sqrt(ci * k[0] * k[1] * k[2])
+    b = torch.randn(co, generator=g) * 0.1
+    xb, wb, bb = x.bfloat16().float(), wt.bfloat16().float(), b.bfloat16().float()
+    xin = xb
+    if up:
+        xin = F.interpolate(xb[0].permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact")
+        xin = xin.permute(1, 0, 2, 3)[None]
+    if name == "down conv2d s2":
+        xin = F.pad(xin, (0, 1, 0, 1))
+        ref = F.conv3d(xin, wb, bb, stride=stride)
+    else:
+        ref = F.conv3d(F.pad(xin, (pad[2], pad[2], pad[1], pad[1], pad[0], 0)), wb, bb, stride=stride)
+    xcl = torch.zeros(t, h, w, cpad(ci))
+    xcl[..., :ci] = xb[0].permute(1, 2, 3, 0)
+    w2 = _pack(wb, cpad(ci), cpad(co))
+    b2 = torch.zeros(cpad(co))
+    b2[:co] = bb
+    out_thw = tuple(ref.shape[2:])
+    y = ops.conv3d_cl(xcl.to(DEV).bfloat16(), w2.to(DEV).bfloat16(), b2.to(DEV).bfloat16(), k, stride, pad, out_thw,
+                      up)
+    got = y[..., :co].permute(3, 0, 1, 2).float().cpu()[None]
+    assert got.shape == ref.shape
+    assert rel_rms(got, ref) < 6e-3, (name, rel_rms(got, ref))
+    if cpad(co) > co:
+        assert y[..., co:].abs().max().item() == 0              # pad channels stay exactly zero
+    # fused residual epilogue
+    r = torch.randn_like(y)
+    y2 = ops.conv3d_cl(xcl.to(DEV).bfloat16(), w2.to(DEV).bfloat16(), b2.to(DEV).bfloat16(), k, stride, pad, out_thw,
+                       up, residual=r)
+    assert rel_rms(y2, (y.float() + r.float())) < 4e-3
+
+
+def _vae(golden, name, prefix=""):
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    cfg, sd, a = golden(name)
+    if prefix:
+        cfg = {k[4:]: v for k, v in cfg.items() if k.startswith("vae_")}
+        sd = {k[4:]: v for k, v in sd.items() if k.startswith("vae.")}
+    keys = ("base_dim", "decoder_base_dim", "z_dim", "dim_mult", "num_res_blocks", "temperal_downsample",
+            "latents_mean", "latents_std", "is_residual", "in_channels", "out_channels", "patch_size",
+            "scale_factor_temporal", "scale_factor_spatial")
+    kw = {k: (list(cfg[k]) if isinstance(cfg[k], (list, tuple)) else cfg[k]) for k in keys}
+    kw["is_residual"] = bool(kw["is_residual"])
+    vae = AutoencoderKLWan(**kw).to(DEV)
+    vae.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    return vae, a
+
+
+def psnr(a, b, peak=2.0):
+    mse = (a.float().cpu() - b.float().cpu()).pow(2).mean().item()
+    return 10 * math.log10(peak * peak / max(mse, 1e-20))
+
+
+def test_decode_matches_reference_streaming_decode(golden):
+    vae, a = _vae(golden, "wan_vae_tiny")
+    for nl in (1, 2, 3):
+        out = vae.decode(a[f"dec_in_{nl}"].to(DEV), return_dict=False)[0]
+        ref = a[f"dec_out_{nl}"]
+        assert out.shape == ref.shape
+        assert psnr(out, ref) > 35.0, (nl, psnr(out, ref))
+
+
+def test_encode_matches_reference_streaming_encode(golden):
+    vae, a = _vae(golden, "wan_vae_tiny")
+    for nf in (1, 5, 9):
+        post = vae.encode(a[f"enc_in_{nf}"].to(DEV)).latent_dist
+        ref = a[f"enc_out_{nf}"]
+        assert post.parameters.shape == ref.shape
+        z = ref.shape[1] // 2
+        assert rel_rms(post.mode(), ref[:, :z]) < 3e-2, (nf, rel_rms(post.mode(), ref[:, :z]))
+        assert rel_rms(post.parameters, ref) < 3e-2
+
+
+def test_pipeline_conditions_and_video_of_the_recorded_reference_run(golden):
+    """prepare_latents (:400-553) + decode (:916-927) of the reference pipeline run, on the HIP VAE."""
+    vae, a = _vae(golden, "wan_pipe_tiny", prefix="vae")
+    z = vae.config.z_dim
+    mean = torch.tensor(vae.config.latents_mean).view(1, z, 1, 1, 1).to(DEV)
+    inv_std = (1.0 / torch.tensor(vae.config.latents_std)).view(1, z, 1, 1, 1).to(DEV)
+    traj = a["traj"].unsqueeze(0).permute(0, 2, 1, 3, 4).to(DEV)
+    tl = (vae.encode(traj).latent_dist.mode() - mean) * inv_std
+    assert rel_rms(tl, a["traj_latents"][:, :, :tl.shape[2]]) < 3e-2
+    video = vae.decode(a["out_latents"].to(DEV) / inv_std + mean, return_dict=False)[0]
+    got = (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
+    assert psnr(got, a["out_video"], peak=1.0) > 35.0
