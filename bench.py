@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--workload", default="wan2.2-5b-49f-704x1280", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the once-per-clip VAE encode/decode timing")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
     a = ap.parse_args()
 
@@ -200,6 +201,25 @@ def main():
                 one_step(i)
         sync()
         elapsed = time.perf_counter() - t0
+    # ---- once-per-clip stages (rank 0, outside the timed region): Wan VAE encode of the conditions + decode ----
+    vae_times = None
+    if rank == 0 and a.workload != "tiny" and not a.no_vae:
+        from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+        vae = AutoencoderKLWan(base_dim=160, decoder_base_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
+                               temperal_downsample=[False, True, True], is_residual=True, in_channels=12,
+                               out_channels=12, patch_size=2, scale_factor_temporal=4,
+                               scale_factor_spatial=16).random_init_(seed=2, device=dev)
+        vid = torch.rand(1, 3, 1 + 4 * (fg - 1), lh * 16, lw * 16, device=dev) * 2 - 1
+        with torch.no_grad():
+            for rep in range(2):                          # first pass warms the kernels
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                vae.encode(vid).latent_dist.mode()        # trajectory video (49 frames)
+                vae.encode(vid[:, :, :1]); vae.encode(vid[:, :, :1])   # first frame + ID frame
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                vae.decode(st.lat[None], return_dict=False)
+                torch.cuda.synchronize(); t3 = time.perf_counter()
+        vae_times = (t2 - t1, t3 - t2)
+        del vae, vid
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,6 +240,10 @@ def main():
                        "sec_per_50_step_clip_denoise_only": 50 * ms_step / 1e3,
                        "model_tflops_per_s": flops_step / (ms_step * 1e-3) / 1e12},
         }
+        if vae_times is not None:
+            enc_s, dec_s = vae_times
+            out["config"].update({"vae_encode_conditions_s": enc_s, "vae_decode_s": dec_s,
+                                  "sec_per_clip_50_steps": enc_s + 50 * ms_step / 1e3 + dec_s})
         if a.layers:
             out["config"]["INVALID_reduced_layers"] = a.layers
         ks = timer.summary().get("attn_self") if not a.graph else None

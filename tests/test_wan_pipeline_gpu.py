@@ -67,3 +67,43 @@ def test_callback_and_interrupt(golden):
     pipe.denoise(d("latents0"), d("condition"), d("traj_latents"), d("id_latent"), d("mask"), d("prompt_embeds"),
                  d("negative_embeds"), 5.0, 4, callback_on_step_end=cb)
     assert [s[0] for s in seen] == [0, 1] and seen[0][2] == (1, 4, 3, 4, 6)
+
+
+def test_full_call_image_to_video_vs_reference_run(golden):
+    """pipe(image=..., traj_tensor=..., ID_tensor=..., latents=...) end to end -- VAE encodes of the conditions, the
+    4-step loop and the VAE decode all on the HIP path -- against the frames the reference pipeline produced."""
+    import math
+    import PIL.Image
+    from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
+    from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from tests.test_wan_vae_gpu import _vae
+    cfg, sd, a = golden("wan_pipe_tiny")
+    m = hip_wan_model(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}, DEV)
+    vae, _ = _vae(golden, "wan_pipe_tiny", prefix="vae")
+    pipe = WanImageToVideoPipeline(vae=vae, scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=m,
+                                   expand_timesteps=True)
+    img = PIL.Image.fromarray(a["image"].numpy() if hasattr(a["image"], "numpy") else a["image"])
+    h, w = img.size[1], img.size[0]
+    out = pipe(image=img, prompt_embeds=a["prompt_embeds"], negative_prompt_embeds=a["negative_embeds"],
+               traj_tensor=a["traj"], ID_tensor=a["id_tensor"], height=h, width=w, num_frames=a["traj"].shape[0],
+               num_inference_steps=int(a["steps"]), guidance_scale=float(a["guidance"]), latents=a["latents0"].clone(),
+               output_type="np")
+    frames = torch.from_numpy(out.frames)
+    ref = a["out_video"]
+    assert frames.shape == ref.shape
+    mse = (frames - ref).pow(2).mean().item()
+    psnr = 10 * math.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 30.0, psnr            # tiny random-weight VAE amplifies latent error; real check is the latent test above
+    lat = pipe(image=img, prompt_embeds=a["prompt_embeds"], negative_prompt_embeds=a["negative_embeds"],
+               traj_tensor=a["traj"], ID_tensor=a["id_tensor"], height=h, width=w, num_frames=a["traj"].shape[0],
+               num_inference_steps=int(a["steps"]), guidance_scale=float(a["guidance"]), latents=a["latents0"].clone(),
+               output_type="latent").frames
+    assert rel_rms(lat, a["out_latents"]) < 6e-2
+
+
+def test_check_inputs_errors_match_reference_messages(golden):
+    pipe, a = _pipe(golden)
+    with pytest.raises(ValueError, match="divisible by 16"):
+        pipe.check_inputs(None, None, torch.zeros(1, 3, 8, 8), 100, 96, a["prompt_embeds"], None)
+    with pytest.raises(ValueError, match="Provide either `prompt` or `prompt_embeds`"):
+        pipe.check_inputs(None, None, torch.zeros(1, 3, 8, 8), 64, 96, None, None)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Full-size Wan2.2 VAE decode / encode timing on one MI355X (random weights, synthetic latents)."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from frameino_amd import ops
+from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+
+WAN22_VAE = dict(base_dim=160, decoder_base_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
+                 temperal_downsample=[False, True, True], is_residual=True, in_channels=12, out_channels=12,
+                 patch_size=2, scale_factor_temporal=4, scale_factor_spatial=16)
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=13)
+ap.add_argument("--h", type=int, default=44)
+ap.add_argument("--w", type=int, default=80)
+ap.add_argument("--encode", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda")
+vae = AutoencoderKLWan(**WAN22_VAE).random_init_(seed=0, device=dev)
+z = torch.randn(1, 48, a.frames, a.h, a.w, device=dev)
+for it in range(2):
+    torch.cuda.synchronize(); t0 = time.time()
+    with ops.KernelTimer({"conv3d"}) as kt:
+        out = vae.decode(z, return_dict=False)[0]
+    torch.cuda.synchronize(); dt = time.time() - t0
+    s = kt.summary().get("conv3d", {})
+    print(f"decode {tuple(z.shape)} -> {tuple(out.shape)}: {dt:.3f} s; conv launches {s.get('launches')} "
+          f"total {s.get('total_ms', 0):.1f} ms, {kt.flops.get('conv3d', 0) / max(s.get('total_ms', 1), 1e-9) / 1e9:.1f} TFLOP/s "
+          f"(padded FLOPs {kt.flops.get('conv3d', 0):.3e}); peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+assert torch.isfinite(out).all()
+if a.encode:
+    vid = torch.rand(1, 3, 1 + 4 * (a.frames - 1), a.h * 16, a.w * 16, device=dev) * 2 - 1
+    for it in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        m = vae.encode(vid).latent_dist.mode()
+        torch.cuda.synchronize()
+        print(f"encode {tuple(vid.shape)} -> {tuple(m.shape)}: {time.time() - t0:.3f} s", flush=True)
