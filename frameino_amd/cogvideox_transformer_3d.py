@@ -1,0 +1,313 @@
+"""MI355X-native CogVideoXTransformer3DModel (CogVideoX-5B-I2V as FrameINO fine-tunes it: 48 input channels,
+`use_FrameIn=True`, learned positional embedding + 3D RoPE).
+
+Mirror of /root/reference/architecture/cogvideox_transformer_3d.py: same constructor arguments, parameter names,
+`forward(hidden_states, encoder_hidden_states, timestep, timestep_cond=None, ofs=None, image_rotary_emb=None,
+attention_kwargs=None, return_dict=True)`, `attn_processors` / `set_attn_processor` / `fuse_qkv_projections` /
+`unfuse_qkv_projections` (:346-444).  Arithmetic runs in libframeino_hip.so.
+
+Layout: text and video tokens of a batch element live in ONE row-major buffer `[B, Lt+Lv, D]` (text first) -- the
+reference concatenates them for attention and for the feed-forward in every block anyway (:155, attention_processor
+:2826).  Per-row modulation uses a `[2B, D]` table (row 2b = video params, 2b+1 = text params) + an int32 selector, so
+LayerNormZero / gates are single kernels over all rows; the gate multiply + residual is the GEMM epilogue.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .attention_processor import Attention, MI355CogVideoXAttnProcessor, MI355FusedCogVideoXAttnProcessor
+from .transformer_wan import FeedForward, _Config, _MLP2
+
+
+class _LayerNormZero(nn.Module):
+    def __init__(self, cond_dim, dim, affine, eps):
+        super().__init__()
+        self.linear = nn.Linear(cond_dim, 6 * dim)
+        self.norm = nn.LayerNorm(dim, eps=eps, elementwise_affine=affine)
+
+
+class _AdaLayerNorm(nn.Module):
+    def __init__(self, cond_dim, out_dim, affine, eps):
+        super().__init__()
+        self.linear = nn.Linear(cond_dim, out_dim)
+        self.norm = nn.LayerNorm(out_dim // 2, eps, affine)
+
+
+class CogVideoXPatchEmbed(nn.Module):
+    def __init__(self, patch_size, in_channels, embed_dim, text_embed_dim, bias, pos_shape, persistent):
+        super().__init__()
+        self.proj = nn.Conv2d(in_channels, embed_dim, kernel_size=(patch_size, patch_size), stride=patch_size, bias=bias)
+        self.text_proj = nn.Linear(text_embed_dim, embed_dim)
+        self.register_buffer("pos_embedding", torch.zeros(pos_shape), persistent=persistent)
+
+
+class CogVideoXBlock(nn.Module):
+    def __init__(self, dim, heads, head_dim, time_embed_dim, attention_bias, affine, eps):
+        super().__init__()
+        self.norm1 = _LayerNormZero(time_embed_dim, dim, affine, eps)
+        self.attn1 = Attention(dim, heads=heads, dim_head=head_dim, qk_norm="layer_norm", eps=1e-6,
+                               bias=attention_bias, out_bias=True, processor=MI355CogVideoXAttnProcessor())
+        self.norm2 = _LayerNormZero(time_embed_dim, dim, affine, eps)
+        self.ff = FeedForward(dim, 4 * dim)
+
+
+def _sincos_1d(dim, pos):
+    omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+    out = torch.outer(pos.reshape(-1).double(), omega)
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1).float()
+
+
+def cog_sincos_pos_embed(embed_dim, pw, ph, frames, spatial_scale, temporal_scale):
+    """architecture/embeddings.py:81-150 (get_3d_sincos_pos_embed, pt path) -> [frames*ph*pw, embed_dim]."""
+    ds, dtm = 3 * embed_dim // 4, embed_dim // 4
+    gh = torch.arange(ph, dtype=torch.float32) / spatial_scale
+    gw = torch.arange(pw, dtype=torch.float32) / spatial_scale
+    grid = torch.stack(torch.meshgrid(gw, gh, indexing="xy"), dim=0).reshape(2, 1, ph, pw)
+    emb_h = _sincos_1d(ds // 2, grid[0])
+    emb_w = _sincos_1d(ds // 2, grid[1])
+    spatial = torch.cat([emb_h, emb_w], dim=1)                                       # [ph*pw, ds]
+    temporal = _sincos_1d(dtm, torch.arange(frames, dtype=torch.float32) / temporal_scale)
+    spatial = spatial[None].repeat_interleave(frames, dim=0)
+    temporal = temporal[:, None].repeat_interleave(ph * pw, dim=1)
+    return torch.cat([temporal, spatial], dim=-1).flatten(0, 1)
+
+
+class CogVideoXTransformer3DModel(nn.Module):
+    def __init__(self, num_attention_heads=30, attention_head_dim=64, in_channels=16, out_channels=16,
+                 flip_sin_to_cos=True, freq_shift=0, time_embed_dim=512, ofs_embed_dim=None, text_embed_dim=4096,
+                 num_layers=30, dropout=0.0, attention_bias=True, sample_width=90, sample_height=60, sample_frames=49,
+                 patch_size=2, patch_size_t=None, temporal_compression_ratio=4, max_text_seq_length=226,
+                 activation_fn="gelu-approximate", timestep_activation_fn="silu", norm_elementwise_affine=True,
+                 norm_eps=1e-5, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0,
+                 use_rotary_positional_embeddings=False, use_learned_positional_embeddings=False, patch_bias=True,
+                 extra_encoder_cond_channels=-1, use_FrameIn=False):
+        super().__init__()
+        if patch_size_t is not None or ofs_embed_dim:
+            raise NotImplementedError("CogVideoX-1.5 (patch_size_t / ofs) is not on FrameINO's path")
+        if not use_rotary_positional_embeddings:
+            raise NotImplementedError("FrameINO fine-tunes CogVideoX-5B (RoPE); the 2B variant is not on its path")
+        inner = num_attention_heads * attention_head_dim
+        self.inner_dim = inner
+        self.config = _Config(num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                              in_channels=in_channels, out_channels=out_channels, flip_sin_to_cos=flip_sin_to_cos,
+                              freq_shift=freq_shift, time_embed_dim=time_embed_dim, ofs_embed_dim=ofs_embed_dim,
+                              text_embed_dim=text_embed_dim, num_layers=num_layers, sample_width=sample_width,
+                              sample_height=sample_height, sample_frames=sample_frames, patch_size=patch_size,
+                              patch_size_t=patch_size_t, temporal_compression_ratio=temporal_compression_ratio,
+                              max_text_seq_length=max_text_seq_length, norm_elementwise_affine=norm_elementwise_affine,
+                              norm_eps=norm_eps, spatial_interpolation_scale=spatial_interpolation_scale,
+                              temporal_interpolation_scale=temporal_interpolation_scale,
+                              use_rotary_positional_embeddings=use_rotary_positional_embeddings,
+                              use_learned_positional_embeddings=use_learned_positional_embeddings,
+                              use_FrameIn=use_FrameIn)
+        pph, ppw = sample_height // patch_size, sample_width // patch_size
+        ptf = (sample_frames - 1) // temporal_compression_ratio + 1
+        self.patch_embed = CogVideoXPatchEmbed(patch_size, in_channels, inner, text_embed_dim, patch_bias,
+                                               (1, max_text_seq_length + pph * ppw * ptf, inner),
+                                               use_learned_positional_embeddings)
+        if not use_learned_positional_embeddings:
+            pe = cog_sincos_pos_embed(inner, ppw, pph, ptf, spatial_interpolation_scale, temporal_interpolation_scale)
+            self.patch_embed.pos_embedding[:, max_text_seq_length:].copy_(pe)
+        self.time_embedding = _MLP2(inner, time_embed_dim)
+        self.transformer_blocks = nn.ModuleList([
+            CogVideoXBlock(inner, num_attention_heads, attention_head_dim, time_embed_dim, attention_bias,
+                           norm_elementwise_affine, norm_eps) for _ in range(num_layers)])
+        self.norm_final = nn.LayerNorm(inner, norm_eps, norm_elementwise_affine)
+        self.norm_out = _AdaLayerNorm(time_embed_dim, 2 * inner, norm_elementwise_affine, norm_eps)
+        self.proj_out = nn.Linear(inner, patch_size * patch_size * out_channels)
+        self._packed = None
+        self._pos_cache = {}
+        self.original_attn_processors = None
+
+    # ---- reference surface (:346-444) ----
+    @property
+    def dtype(self):
+        return self.proj_out.weight.dtype
+
+    @property
+    def device(self):
+        return self.proj_out.weight.device
+
+    @property
+    def attn_processors(self):
+        return {f"transformer_blocks.{i}.attn1.processor": b.attn1.processor
+                for i, b in enumerate(self.transformer_blocks)}
+
+    def set_attn_processor(self, processor):
+        count = len(self.transformer_blocks)
+        if isinstance(processor, dict) and len(processor) != count:
+            raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not "
+                             f"match the number of attention layers: {count}. Please make sure to pass {count} "
+                             f"processor classes.")
+        for i, b in enumerate(self.transformer_blocks):
+            b.attn1.set_processor(processor[f"transformer_blocks.{i}.attn1.processor"] if isinstance(processor, dict)
+                                  else processor)
+        self._packed = None
+
+    def fuse_qkv_projections(self):
+        self.original_attn_processors = self.attn_processors
+        for b in self.transformer_blocks:
+            b.attn1.fuse_projections(fuse=True)
+        self.set_attn_processor(MI355FusedCogVideoXAttnProcessor())
+
+    def unfuse_qkv_projections(self):
+        if self.original_attn_processors is not None:
+            self.set_attn_processor(self.original_attn_processors)
+
+    def load_reference_state_dict(self, sd, dtype=None):
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"state-dict is missing {missing[:5]}")
+        with torch.no_grad():
+            for k, t in list(self.named_parameters()) + list(self.named_buffers()):
+                t.data = sd[k].to(dtype or sd[k].dtype).to(t.device).contiguous()
+        self._packed = None
+        self._pos_cache.clear()
+        return self
+
+    # ---- packing ----
+    def _pack(self):
+        pk = SimpleNamespace(layers=[])
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()     # noqa: E731
+        for b in self.transformer_blocks:
+            a = b.attn1
+            e = SimpleNamespace()
+            e.wqkv = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]).detach().contiguous()
+            e.bqkv = torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias]).detach().contiguous() \
+                if a.to_q.bias is not None else None
+            e.n1w, e.n1b = f32(b.norm1.norm.weight), f32(b.norm1.norm.bias)
+            e.n2w, e.n2b = f32(b.norm2.norm.weight), f32(b.norm2.norm.bias)
+            pk.layers.append(e)
+        # all 2*layers LayerNormZero projections + norm_out as ONE skinny GEMM weight
+        ws = [m.linear.weight for b in self.transformer_blocks for m in (b.norm1, b.norm2)] + [self.norm_out.linear.weight]
+        bs = [m.linear.bias for b in self.transformer_blocks for m in (b.norm1, b.norm2)] + [self.norm_out.linear.bias]
+        pk.wmod = torch.cat(ws).detach().contiguous()
+        pk.bmod = torch.cat(bs).detach().contiguous()
+        pk.w_patch = self.patch_embed.proj.weight.detach().reshape(self.inner_dim, -1).contiguous()
+        pk.nfw, pk.nfb = f32(self.norm_final.weight), f32(self.norm_final.bias)
+        pk.now, pk.nob = f32(self.norm_out.norm.weight), f32(self.norm_out.norm.bias)
+        pk.default_procs = all(type(b.attn1.processor) in (MI355CogVideoXAttnProcessor, MI355FusedCogVideoXAttnProcessor)
+                               for b in self.transformer_blocks)
+        self._packed = pk
+        return pk
+
+    def _pos_embeds(self, num_frames, height, width, text_len, dtype):
+        """architecture/embeddings.py:764-802 (FrameIn first-frame PE reuse, trilinear resize off the default size).
+        Step-invariant: built once per geometry (the reference rebuilds and re-interpolates it every forward)."""
+        key = (num_frames, height, width, text_len, dtype)
+        if key in self._pos_cache:
+            return self._pos_cache[key]
+        c = self.config
+        pos = self.patch_embed.pos_embedding
+        ps, tcr, maxt = c.patch_size, c.temporal_compression_ratio, c.max_text_seq_length
+        post = (c.sample_frames - 1) // tcr + 1
+        pph, ppw = c.sample_height // ps, c.sample_width // ps
+        seq = height * width * num_frames // (ps * ps)
+        if c.use_FrameIn:
+            first = (pos.shape[1] - maxt) // (num_frames - 1)
+            pos = torch.cat([pos, pos[:, text_len:text_len + first].clone()], dim=1)
+        if c.sample_height != height or c.sample_width != width or c.sample_frames != (num_frames - 1) * tcr + 1:
+            if c.use_FrameIn:
+                post += 1
+            d = pos.shape[-1]
+            pw_ = pos[:, text_len:].view(1, post, pph, ppw, d).permute(0, 4, 1, 2, 3)
+            pw_ = F.interpolate(pw_, size=[post, height // ps, width // ps], mode="trilinear", align_corners=False)
+            pw_ = pw_.permute(0, 2, 3, 4, 1).reshape(1, -1, d)
+            pos = torch.cat([pos[:, :text_len], pw_], dim=1)[:, :text_len + seq]
+        out = pos[0].to(dtype).contiguous()
+        self._pos_cache[key] = out
+        return out
+
+    # ---- forward (:446-562) ----
+    @torch.no_grad()
+    def forward(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, ofs=None,
+                image_rotary_emb=None, attention_kwargs=None, return_dict=True):
+        if timestep_cond is not None:
+            raise NotImplementedError("timestep_cond is never passed on the FrameINO path")
+        if attention_kwargs is not None:
+            attention_kwargs = dict(attention_kwargs)
+            attention_kwargs.pop("scale", None)
+        pk = self._packed or self._pack()
+        c = self.config
+        b, nf, ch, hh, ww = hidden_states.shape
+        d, heads, dh, ps = self.inner_dim, c.num_attention_heads, c.attention_head_dim, c.patch_size
+        dev, dt = hidden_states.device, hidden_states.dtype
+        lt = encoder_hidden_states.shape[1]
+        lv = nf * (hh // ps) * (ww // ps)
+        L = lt + lv
+
+        # 1. time embedding (:477-483): sinusoid fp32 -> T -> MLP in T
+        half = d // 2
+        expo = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=dev) / (half - c.freq_shift))
+        ang = timestep.reshape(-1).float()[:, None] * expo[None]
+        t_emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
+        if c.flip_sin_to_cos:
+            t_emb = torch.cat([t_emb[:, half:], t_emb[:, :half]], dim=-1)
+        te = self.time_embedding
+        h1 = ops.skinny_linear(t_emb.to(dt).float().contiguous(), te.linear_1.weight, te.linear_1.bias).to(dt)
+        emb = ops.skinny_linear(F.silu(h1).float().contiguous(), te.linear_2.weight, te.linear_2.bias).to(dt)   # [B, E]
+        # every LayerNormZero / AdaLayerNorm projection of silu(emb) in one launch -> [B, (2*layers*6 + 2) * D] in T
+        mods = ops.skinny_linear(F.silu(emb).float().contiguous(), pk.wmod, pk.bmod).to(dt).float()
+        nl = c.num_layers
+        lnz = mods[:, :2 * nl * 6 * d].view(b, 2 * nl, 2, 3, d)                      # [B, norm, video|text, (shift,scale,gate), D]
+        tables = lnz.permute(1, 0, 2, 3, 4).reshape(2 * nl, 2 * b, 3, d).contiguous()   # row 2b = video, 2b+1 = text
+        out_mod = mods[:, 2 * nl * 6 * d:].view(b, 2, d).contiguous()                # (shift, scale) of norm_out
+        sel = torch.zeros(b, L, dtype=torch.int32, device=dev)
+        sel[:, :lt] = 1
+        sel += 2 * torch.arange(b, device=dev, dtype=torch.int32)[:, None]
+        sel = sel.reshape(-1).contiguous()
+
+        # 2. patch embedding (:494) into the joint buffer [B, Lt+Lv, D]
+        x = torch.empty(b, L, d, dtype=dt, device=dev)
+        pe = self.patch_embed
+        pos = self._pos_embeds(nf, hh, ww, lt, dt)
+        for i in range(b):
+            ops.gemm(encoder_hidden_states[i], pe.text_proj.weight, pe.text_proj.bias, out=x[i, :lt])
+            a = ops.patchify(hidden_states[i].permute(1, 0, 2, 3).contiguous(), (1, ps, ps))
+            ops.gemm(a, pk.w_patch, pe.proj.bias, out=x[i, lt:])
+            ops.gated_residual(x[i], pos, out=x[i])
+        x2 = x.view(b * L, d)
+        cos = sin = None
+        if image_rotary_emb is not None:
+            cos, sin = (t.to(dev).float().contiguous() for t in image_rotary_emb)
+
+        # 3. blocks (:503-529)
+        for li, (blk, e) in enumerate(zip(self.transformer_blocks, pk.layers)):
+            t1, t2 = tables[2 * li], tables[2 * li + 1]                              # [2B, 3, D]
+            n = ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
+            if pk.default_procs:
+                qkv = ops.gemm(n, e.wqkv, e.bqkv).view(b, L, 3 * d)
+                nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
+                ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt)
+                ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
+                att = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads)
+                ops.gemm(att.view(b * L, d), blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
+                         ops.EPI_GATED_RESIDUAL_STAGED, residual=x2, gate=t1[:, 2], sel=sel, out=x2)
+            else:
+                n3 = n.view(b, L, d)
+                ah, ae = blk.attn1(hidden_states=n3[:, lt:], encoder_hidden_states=n3[:, :lt],
+                                   image_rotary_emb=image_rotary_emb, **(attention_kwargs or {}))
+                y = torch.cat([ae, ah], dim=1).reshape(b * L, d)
+                ops.gated_residual(x2, y, t1[:, 2], sel, out=x2, staged=True)
+            n = ops.layernorm_zero(x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
+            ff = ops.gemm(n, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
+            ops.gemm(ff, blk.ff.net[2].weight, blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED, residual=x2,
+                     gate=t2[:, 2], sel=sel, out=x2)
+
+        # 4. final norms + projection (:531-542) on the video rows
+        outs = []
+        for i in range(b):
+            v = ops.layernorm(x[i, lt:], pk.nfw, pk.nfb, c.norm_eps)
+            v = ops.layernorm_zero(v, pk.now, pk.nob, out_mod[i, 0], out_mod[i, 1], None, c.norm_eps)
+            y = ops.gemm(v, self.proj_out.weight, self.proj_out.bias)                # [Lv, p*p*Cout] (c, dh, dw) columns
+            y = y.view(nf, hh // ps, ww // ps, c.out_channels, ps, ps).permute(0, 3, 1, 4, 2, 5)
+            outs.append(y.reshape(nf, c.out_channels, hh, ww))
+        out = torch.stack(outs)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)

@@ -60,12 +60,15 @@ __device__ __forceinline__ void ln_stats(const float (&v)[NP][8], int dim, int l
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// MODE 0: y = LN(x)*(1+scale)+shift (table rows), MODE 1: y = LN(x)*w+b (w/b may be null)
+// MODE 0: y = T(LN(x)*(1+scale)+shift)                        (Wan AdaLN-zero: fp32 math, one rounding)
+// MODE 1: y = T(LN(x)*w+b)                                    (affine LayerNorm; w/b may be null)
+// MODE 2: y = T(T(T(LN(x)*w+b) * T(1+scale)) + shift)         (CogVideoXLayerNormZero / AdaLayerNorm executed in T:
+//                                                              the reference rounds after every tensor op)
 template <typename T, int NP, int MODE>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
     const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
-    const float* __restrict__ p_shift, const float* __restrict__ p_scale, int64_t mod_stride,
-    const int32_t* __restrict__ sel, float eps) {
+    const float* __restrict__ p_w, const float* __restrict__ p_b, const float* __restrict__ p_shift,
+    const float* __restrict__ p_scale, int64_t mod_stride, const int32_t* __restrict__ sel, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -73,32 +76,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
     load_row<T, NP>(x + row * ldx, dim, lane, v);
     float mean, rstd;
     ln_stats<NP>(v, dim, lane, eps, mean, rstd);
-    const int64_t moff = (MODE == 0 && sel) ? (int64_t)sel[row] * mod_stride : 0;
+    const int64_t moff = (MODE != 1 && sel) ? (int64_t)sel[row] * mod_stride : 0;
+    auto ld8 = [](const float* p, float (&o)[8]) {
+        const float4 a0 = *reinterpret_cast<const float4*>(p);
+        const float4 a1 = *reinterpret_cast<const float4*>(p + 4);
+        o[0] = a0.x; o[1] = a0.y; o[2] = a0.z; o[3] = a0.w; o[4] = a1.x; o[5] = a1.y; o[6] = a1.z; o[7] = a1.w;
+    };
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c >= dim) continue;
-        float o[8];
-        float a[8], b[8];
-        if (MODE == 0 || p_scale) {
-            const float4 a0 = *reinterpret_cast<const float4*>(p_scale + moff + c);
-            const float4 a1 = *reinterpret_cast<const float4*>(p_scale + moff + c + 4);
-            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-        }
-        if (MODE == 0 || p_shift) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p_shift + moff + c);
-            const float4 b1 = *reinterpret_cast<const float4*>(p_shift + moff + c + 4);
-            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-        }
+        float o[8], w[8], b[8], sc[8], sh[8];
+        if (MODE != 0 && p_w) ld8(p_w + c, w);
+        if (MODE != 0 && p_b) ld8(p_b + c, b);
+        if (MODE != 1) { ld8(p_scale + moff + c, sc); ld8(p_shift + moff + c, sh); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float n = (v[i][j] - mean) * rstd;
             if (MODE == 0) {
-                o[j] = n * (1.0f + a[j]) + b[j];
+                o[j] = n * (1.0f + sc[j]) + sh[j];
             } else {
                 float t = n;
-                if (p_scale) t = t * a[j];
-                if (p_shift) t = t + b[j];
+                if (p_w) t = t * w[j];
+                if (p_b) t = t + b[j];
+                if (MODE == 2) t = round_to<T>(round_to<T>(t) * round_to<T>(1.0f + sc[j])) + sh[j];
                 o[j] = t;
             }
         }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void gated_residual_kernel(const uint16_t* __r
                                                              uint16_t* __restrict__ out, int64_t rows, int dim,
                                                              int64_t ldx, int64_t ldy, int64_t ldo,
                                                              const float* __restrict__ gate, int64_t mod_stride,
-                                                             const int32_t* __restrict__ sel) {
+                                                             const int32_t* __restrict__ sel, int staged) {
     const int chunks = dim >> 3;
     const int64_t total = rows * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void gated_residual_kernel(const uint16_t* __r
             const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
             const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = a[j] + b[j] * gg[j];
+            for (int j = 0; j < 8; ++j) o[j] = a[j] + (staged ? round_to<T>(b[j] * gg[j]) : b[j] * gg[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = a[j] + b[j];
@@ -357,6 +358,31 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const uint16_t* __restri
     }
 }
 
+// CogVideoX sampler step (pipeline_cogvideox_i2v_motion_FrameINO.py:893-927 with a v-prediction DDIM step):
+//   v = u + g*(c - u) in fp32 (the reference upcasts noise_pred, :896);  x0 = T(sa*x) - sb*v;  x' = T(T(ca*x) + cb*x0)
+//   (x is the T-typed latent; products of x with the scheduler's 0-dim coefficients stay in T under torch promotion).
+// coef = {sa, sb, ca, cb, g} on the device.  pred: [2, Ft, C*HW] (uncond, cond), lat: [Fg, C*HW] in place.
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_vpred_step_kernel(const uint16_t* __restrict__ pred,
+                                                             uint16_t* __restrict__ lat, int64_t n_lat,
+                                                             int64_t batch_stride, const float* __restrict__ coef,
+                                                             int has_uncond) {
+    const float sa = coef[0], sb = coef[1], ca = coef[2], cb = coef[3], g = coef[4];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lat; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (has_uncond) {
+            const float u = T::to_f32(pred[i]);
+            const float c = T::to_f32(pred[batch_stride + i]);
+            v = u + g * (c - u);
+        } else {
+            v = T::to_f32(pred[i]);
+        }
+        const float x = T::to_f32(lat[i]);
+        const float x0 = round_to<T>(sa * x) - sb * v;
+        lat[i] = T::from_f32(round_to<T>(ca * x) + cb * x0);
+    }
+}
+
 template <int NPmax, typename F>
 inline bool dispatch_np(int dim, F&& f) {
     const int np = (dim + 511) / 512;
@@ -380,17 +406,18 @@ inline int grid_1d(int64_t total, int block = 256) {
 }
 
 template <int MODE>
-int launch_ln(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy, const float* shift,
-              const float* scale, int64_t mod_stride, const int32_t* sel, float eps, int dtype, hipStream_t st) {
+int launch_ln(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy, const float* w, const float* b,
+              const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel, float eps, int dtype,
+              hipStream_t st) {
     const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
     const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if (dtype == FINO_BF16)
             ln_modulate_kernel<BF16, NP, MODE><<<grid, block, 0, st>>>((const uint16_t*)x, (uint16_t*)y, rows, dim,
-                                                                     ldx, ldy, shift, scale, mod_stride, sel, eps);
+                                                                     ldx, ldy, w, b, shift, scale, mod_stride, sel, eps);
         else
             ln_modulate_kernel<F16, NP, MODE><<<grid, block, 0, st>>>((const uint16_t*)x, (uint16_t*)y, rows, dim,
-                                                                    ldx, ldy, shift, scale, mod_stride, sel, eps);
+                                                                    ldx, ldy, w, b, shift, scale, mod_stride, sel, eps);
     });
     FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "layernorm: dim %d > %d unsupported", dim, kMaxPasses * 512);
     FINO_LAUNCH_CHECK();
@@ -413,7 +440,8 @@ extern "C" int fino_adaln_modulate(const void* x, void* y, int64_t rows, int dim
     FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && mod_stride % 4 == 0 && fino_aligned16(x) && fino_aligned16(y) &&
                    fino_aligned16(shift) && fino_aligned16(scale),
                FINO_ERR_ARG, "fino_adaln_modulate: 16-byte alignment required");
-    return launch_ln<0>(x, y, rows, dim, ldx, ldy, shift, scale, mod_stride, sel, eps, dtype, (hipStream_t)stream);
+    return launch_ln<0>(x, y, rows, dim, ldx, ldy, nullptr, nullptr, shift, scale, mod_stride, sel, eps, dtype,
+                        (hipStream_t)stream);
 }
 
 extern "C" int fino_layernorm(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
@@ -423,12 +451,39 @@ extern "C" int fino_layernorm(const void* x, void* y, int64_t rows, int dim, int
     FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && fino_aligned16(x) && fino_aligned16(y) && fino_aligned16(w) &&
                    fino_aligned16(b),
                FINO_ERR_ARG, "fino_layernorm: 16-byte alignment required");
-    return launch_ln<1>(x, y, rows, dim, ldx, ldy, b, w, 0, nullptr, eps, dtype, (hipStream_t)stream);
+    return launch_ln<1>(x, y, rows, dim, ldx, ldy, w, b, nullptr, nullptr, 0, nullptr, eps, dtype, (hipStream_t)stream);
 }
+
+extern "C" int fino_layernorm_zero(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                                   const float* w, const float* b, const float* shift, const float* scale,
+                                   int64_t mod_stride, const int32_t* sel, float eps, int dtype, void* stream) {
+    CHECK_ROWS_DIM("fino_layernorm_zero");
+    FINO_CHECK(x && y && shift && scale, FINO_ERR_ARG, "fino_layernorm_zero: null pointer");
+    FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && mod_stride % 4 == 0 && fino_aligned16(x) && fino_aligned16(y) &&
+                   fino_aligned16(shift) && fino_aligned16(scale) && fino_aligned16(w) && fino_aligned16(b),
+               FINO_ERR_ARG, "fino_layernorm_zero: 16-byte alignment required");
+    return launch_ln<2>(x, y, rows, dim, ldx, ldy, w, b, shift, scale, mod_stride, sel, eps, dtype, (hipStream_t)stream);
+}
+
+static int gated_residual_impl(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                               int64_t ldo, const float* gate, int64_t mod_stride, const int32_t* sel, int staged,
+                               int dtype, void* stream);
 
 extern "C" int fino_gated_residual(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx,
                                    int64_t ldy, int64_t ldo, const float* gate, int64_t mod_stride,
                                    const int32_t* sel, int dtype, void* stream) {
+    return gated_residual_impl(x, y, out, rows, dim, ldx, ldy, ldo, gate, mod_stride, sel, 0, dtype, stream);
+}
+
+extern "C" int fino_gated_residual_staged(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx,
+                                          int64_t ldy, int64_t ldo, const float* gate, int64_t mod_stride,
+                                          const int32_t* sel, int dtype, void* stream) {
+    return gated_residual_impl(x, y, out, rows, dim, ldx, ldy, ldo, gate, mod_stride, sel, 1, dtype, stream);
+}
+
+static int gated_residual_impl(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                               int64_t ldo, const float* gate, int64_t mod_stride, const int32_t* sel, int staged,
+                               int dtype, void* stream) {
     CHECK_ROWS_DIM("fino_gated_residual");
     FINO_CHECK(x && y && out, FINO_ERR_ARG, "fino_gated_residual: null pointer");
     FINO_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && mod_stride % 4 == 0 && fino_aligned16(x) &&
@@ -438,10 +493,10 @@ extern "C" int fino_gated_residual(const void* x, const void* y, void* out, int6
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FINO_BF16)
         gated_residual_kernel<BF16><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)y, (uint16_t*)out,
-                                                          rows, dim, ldx, ldy, ldo, gate, mod_stride, sel);
+                                                          rows, dim, ldx, ldy, ldo, gate, mod_stride, sel, staged);
     else
         gated_residual_kernel<F16><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)y, (uint16_t*)out,
-                                                         rows, dim, ldx, ldy, ldo, gate, mod_stride, sel);
+                                                         rows, dim, ldx, ldy, ldo, gate, mod_stride, sel, staged);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -546,6 +601,22 @@ extern "C" int fino_wan_model_input(const float* lat, const float* cond, const f
     else
         wan_model_input_kernel<F16><<<grid_1d(total), 256, 0, st>>>(lat, cond, id_lat, traj, (uint16_t*)out, channels,
                                                                     gen_frames, id_frames, height * width);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_cfg_vpred_step(const void* pred, void* lat, int64_t n_lat, int64_t batch_stride, const float* coef_dev,
+                                   int has_uncond, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_cfg_vpred_step: dtype %d", dtype);
+    FINO_CHECK(pred && lat && coef_dev && n_lat > 0 && (!has_uncond || batch_stride >= n_lat), FINO_ERR_ARG,
+               "fino_cfg_vpred_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        cfg_vpred_step_kernel<BF16><<<grid_1d(n_lat), 256, 0, st>>>((const uint16_t*)pred, (uint16_t*)lat, n_lat,
+                                                                   batch_stride, coef_dev, has_uncond);
+    else
+        cfg_vpred_step_kernel<F16><<<grid_1d(n_lat), 256, 0, st>>>((const uint16_t*)pred, (uint16_t*)lat, n_lat,
+                                                                  batch_stride, coef_dev, has_uncond);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

@@ -233,17 +233,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
         const int64_t gm = m0 + row, gn = n0 + ch * 8;
         if (gm >= p.m || gn >= p.n) continue;
         uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
-        if (EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL) {
+        if (EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED) {
             float y[8], rv[8], o[8];
             unpack8<T>(yv, y);
             unpack8<T>(*reinterpret_cast<const uint4*>(p.r + gm * p.ldr + gn), rv);
-            if (EPI == FINO_EPI_GATED_RESIDUAL) {
+            if (EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED) {
                 const float* g = p.gate + (p.sel ? (int64_t)p.sel[gm] * p.mod_stride : 0) + gn;
                 const float4 g0 = *reinterpret_cast<const float4*>(g);
                 const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
                 const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e] * gg[e];
+                for (int e = 0; e < 8; ++e)
+                    o[e] = rv[e] + (EPI == FINO_EPI_GATED_RESIDUAL_STAGED ? round_to<T>(y[e] * gg[e]) : y[e] * gg[e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
@@ -277,6 +278,7 @@ int launch_gemm_e(const GemmParams& p, int epi, hipStream_t st) {
         case FINO_EPI_NONE: return launch_gemm_t<T, FINO_EPI_NONE, GENERIC>(p, st);
         case FINO_EPI_GELU_TANH: return launch_gemm_t<T, FINO_EPI_GELU_TANH, GENERIC>(p, st);
         case FINO_EPI_RESIDUAL: return launch_gemm_t<T, FINO_EPI_RESIDUAL, GENERIC>(p, st);
+        case FINO_EPI_GATED_RESIDUAL_STAGED: return launch_gemm_t<T, FINO_EPI_GATED_RESIDUAL_STAGED, GENERIC>(p, st);
         default: return launch_gemm_t<T, FINO_EPI_GATED_RESIDUAL, GENERIC>(p, st);
     }
 }
@@ -336,11 +338,11 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
                "fino_gemm: leading dimensions must be multiples of 8 and cover the row");
     FINO_CHECK(fino_aligned16(a) && fino_aligned16(w) && fino_aligned16(c), FINO_ERR_ARG,
                "fino_gemm: A/W/C must be 16-byte aligned");
-    FINO_CHECK(epilogue >= FINO_EPI_NONE && epilogue <= FINO_EPI_GATED_RESIDUAL, FINO_ERR_ARG,
+    FINO_CHECK(epilogue >= FINO_EPI_NONE && epilogue <= FINO_EPI_GATED_RESIDUAL_STAGED, FINO_ERR_ARG,
                "fino_gemm: epilogue %d", epilogue);
-    if (epilogue == FINO_EPI_RESIDUAL || epilogue == FINO_EPI_GATED_RESIDUAL)
+    if (epilogue >= FINO_EPI_RESIDUAL)
         FINO_CHECK(r && ldr % 8 == 0 && ldr >= n && fino_aligned16(r), FINO_ERR_ARG, "fino_gemm: residual operand");
-    if (epilogue == FINO_EPI_GATED_RESIDUAL)
+    if (epilogue == FINO_EPI_GATED_RESIDUAL || epilogue == FINO_EPI_GATED_RESIDUAL_STAGED)
         FINO_CHECK(gate && fino_aligned16(gate) && mod_stride % 4 == 0, FINO_ERR_ARG, "fino_gemm: gate operand");
     if (m == 0) return FINO_OK;
     GemmParams p = {};

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 BF16, F16 = 0, 1
-EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_GATED_RESIDUAL = 0, 1, 2, 3
+EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_GATED_RESIDUAL, EPI_GATED_RESIDUAL_STAGED = 0, 1, 2, 3, 4
 
 
 class KernelTimer:
@@ -106,15 +106,29 @@ def layernorm(x, weight=None, bias=None, eps=1e-5, out=None):
     return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
 
 
-def gated_residual(x, y, gate=None, sel=None, out=None):
-    """out = T(float(x) + float(y)*gate[sel]) (gate None => T(x+y))."""
+def layernorm_zero(x, weight, bias, shift, scale, sel=None, eps=1e-5, out=None):
+    """y = T(T(T(LN(x)*w+b) * T(1+scale[sel])) + shift[sel]) -- CogVideoXLayerNormZero / AdaLayerNorm in T."""
+    x2, rows, dim, ldx = _rows2d(x)
+    out = torch.empty_like(x2) if out is None else out
+    o2, _, _, ldy = _rows2d(out)
+    for t in (weight, bias, shift, scale):
+        assert t is None or t.dtype == torch.float32
+    ms = shift.stride(0) if shift.dim() == 2 else 0
+    _lib.check(_lib.lib().fino_layernorm_zero(_p(x2), _p(o2), rows, dim, ldx, ldy, _p(weight), _p(bias), _p(shift),
+                                             _p(scale), ms, _p(sel), eps, _dt(x), _stream()), "fino_layernorm_zero")
+    return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
+
+
+def gated_residual(x, y, gate=None, sel=None, out=None, staged=False):
+    """out = T(float(x) + float(y)*gate[sel]) (gate None => T(x+y)); staged: T(x + T(y*gate))."""
     x2, rows, dim, ldx = _rows2d(x)
     y2, _, _, ldy = _rows2d(y)
     out = torch.empty_like(x2) if out is None else out
     o2, _, _, ldo = _rows2d(out)
     ms = gate.stride(0) if (gate is not None and gate.dim() == 2) else 0
-    _lib.check(_lib.lib().fino_gated_residual(_p(x2), _p(y2), _p(o2), rows, dim, ldx, ldy, ldo, _p(gate), ms, _p(sel),
-                                             _dt(x), _stream()), "fino_gated_residual")
+    fn = _lib.lib().fino_gated_residual_staged if staged else _lib.lib().fino_gated_residual
+    _lib.check(fn(_p(x2), _p(y2), _p(o2), rows, dim, ldx, ldy, ldo, _p(gate), ms, _p(sel), _dt(x), _stream()),
+               "fino_gated_residual")
     return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
 
 
@@ -243,6 +257,14 @@ def cfg_euler_step_(lat, cond_pred, uncond_pred, guidance, dt_dev, round_out=Tru
     _lib.check(_lib.lib().fino_cfg_euler_step(_p(cond_pred), _p(uncond_pred), _p(lat), c, fg, ft, h, w, float(guidance),
                                              _p(dt_dev), int(round_out), _dt(cond_pred), _stream()),
                "fino_cfg_euler_step")
+    return lat
+
+
+def cfg_vpred_step_(lat, pred, coef_dev, has_uncond=True):
+    """lat [Fg, C, H, W] of T in place; pred [2|1, Ft, C, H, W] of T; coef_dev fp32[5] = {sa, sb, ca, cb, g}."""
+    assert lat.is_contiguous() and pred.is_contiguous() and coef_dev.dtype == torch.float32 and lat.dtype == pred.dtype
+    _lib.check(_lib.lib().fino_cfg_vpred_step(_p(pred), _p(lat), lat.numel(), pred[0].numel(), _p(coef_dev),
+                                             int(has_uncond), _dt(lat), _stream()), "fino_cfg_vpred_step")
     return lat
 
 

@@ -1,0 +1,151 @@
+"""MI355X-native FrameINO CogVideoX image-to-video pipeline (mirror of the reference's
+pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py::CogVideoXImageToVideoPipeline, denoising side).
+
+What is built: the CFG-batched denoise loop (:848-944) -- model-input assembly
+`[noisy + ID | first-frame + 0 | trajectory + 0]` on the channel axis (:856-881), one B=2 DiT forward per step on HIP
+kernels, ID-frame drop (:901-902), (dynamic) guidance (:906-911), v-prediction DDIM update (:916) in one kernel --
+plus `_prepare_rotary_positional_embeddings` (:540-584) with the FrameIn extension (:834-839).
+
+What is NOT here: the CogVideoX VAE.  The reference takes it from diffusers (`AutoencoderKLCogVideoX`, third-party,
+no source in the reference tree, not installable offline), so `__call__` needs a user-supplied `vae` object with the
+diffusers interface for the condition encodes / final decode; `denoise()` works on latents alone.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .schedulers import CogVideoXDDIMScheduler  # noqa: F401  (re-export)
+
+
+def get_resize_crop_region_for_grid(src, tgt_width, tgt_height):
+    """reference :72-89"""
+    tw, th = tgt_width, tgt_height
+    h, w = src
+    r = h / w
+    if r > (th / tw):
+        resize_height = th
+        resize_width = int(round(th / h * w))
+    else:
+        resize_width = tw
+        resize_height = int(round(tw / w * h))
+    crop_top = int(round((th - resize_height) / 2.0))
+    crop_left = int(round((tw - resize_width) / 2.0))
+    return (crop_top, crop_left), (crop_top + resize_height, crop_left + resize_width)
+
+
+def _rope_1d(dim, pos, theta=10000.0):
+    """architecture/embeddings.py:1153-1216 (use_real, repeat_interleave_real, fp32 freqs)"""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim))
+    ang = torch.outer(pos, freqs)
+    return ang.cos().repeat_interleave(2, dim=1).float(), ang.sin().repeat_interleave(2, dim=1).float()
+
+
+def get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size, theta=10000):
+    """architecture/embeddings.py:864-962, grid_type="linspace" (CogVideoX 1.0)."""
+    start, stop = crops_coords
+    gh, gw = grid_size
+    grid_h = torch.linspace(start[0], stop[0] * (gh - 1) / gh, gh, dtype=torch.float32)
+    grid_w = torch.linspace(start[1], stop[1] * (gw - 1) / gw, gw, dtype=torch.float32)
+    grid_t = torch.linspace(0, temporal_size * (temporal_size - 1) / temporal_size, temporal_size, dtype=torch.float32)
+    dim_t, dim_h, dim_w = embed_dim // 4, embed_dim // 8 * 3, embed_dim // 8 * 3
+    ft, fh, fw = _rope_1d(dim_t, grid_t, theta), _rope_1d(dim_h, grid_h, theta), _rope_1d(dim_w, grid_w, theta)
+
+    def combine(a, b, c):
+        a = a[:, None, None, :].expand(-1, gh, gw, -1)
+        b = b[None, :, None, :].expand(temporal_size, -1, gw, -1)
+        c = c[None, None, :, :].expand(temporal_size, gh, -1, -1)
+        return torch.cat([a, b, c], dim=-1).reshape(temporal_size * gh * gw, -1)
+
+    return combine(ft[0], fh[0], fw[0]), combine(ft[1], fh[1], fw[1])
+
+
+class CogVideoXPipelineOutput(SimpleNamespace):
+    pass
+
+
+class CogVideoXImageToVideoPipeline:
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None):
+        self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
+        self.transformer, self.scheduler = transformer, scheduler
+        self.vae_scale_factor_spatial = 8
+        self.vae_scale_factor_temporal = 4
+        self.vae_scaling_factor_image = getattr(getattr(vae, "config", None), "scaling_factor", 0.7)
+        self._interrupt = False
+
+    def enable_model_cpu_offload(self, *a, **k):
+        return self
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    def _prepare_rotary_positional_embeddings(self, height, width, num_frames, device):
+        """reference :540-584 (patch_size_t None) + the FrameIn first-frame extension :834-839."""
+        c = self.transformer.config
+        gh = height // (self.vae_scale_factor_spatial * c.patch_size)
+        gw = width // (self.vae_scale_factor_spatial * c.patch_size)
+        crops = get_resize_crop_region_for_grid((gh, gw), c.sample_width // c.patch_size, c.sample_height // c.patch_size)
+        cos, sin = get_3d_rotary_pos_embed(c.attention_head_dim, crops, (gh, gw), num_frames)
+        n1 = cos.shape[0] // num_frames
+        cos = torch.cat([cos, cos[:n1]], dim=0)
+        sin = torch.cat([sin, sin[:n1]], dim=0)
+        return cos.to(device), sin.to(device)
+
+    @torch.no_grad()
+    def denoise(self, latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_prompt_embeds,
+                guidance_scale=6.0, num_inference_steps=50, use_dynamic_cfg=False, image_rotary_emb=None,
+                attention_kwargs=None, callback_on_step_end=None):
+        """reference :848-944.  latents / image_latents / traj_latents [1, F, C, h, w], id_latent [1, 1, C, h, w] or
+        None; returns the final latents [1, F, C, h, w] in the transformer dtype."""
+        tr = self.transformer
+        dev, dt = latents.device, tr.dtype
+        if latents.shape[0] != 1:
+            raise NotImplementedError("one video per call")
+        cfg_on = guidance_scale > 1.0 and negative_prompt_embeds is not None
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        ts = self.scheduler.timesteps
+        nlf = latents.shape[1]
+        lat = (latents * self.scheduler.init_noise_sigma).to(dt)[0].contiguous().clone()      # [F, C, h, w]
+        img, trj = image_latents.to(dt), traj_latents.to(dt)
+        if id_latent is not None:
+            idl = id_latent.to(dt)
+            pad = torch.zeros_like(idl)
+            img, trj = torch.cat([img, pad], dim=1), torch.cat([trj, pad], dim=1)              # :874-876
+        nb = 2 if cfg_on else 1
+        cond = torch.cat([img, trj], dim=2).expand(nb, -1, -1, -1, -1)
+        prompt = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dt) if cfg_on else prompt_embeds.to(dt)
+        if image_rotary_emb is None:
+            h = latents.shape[3] * self.vae_scale_factor_spatial
+            w = latents.shape[4] * self.vae_scale_factor_spatial
+            image_rotary_emb = self._prepare_rotary_positional_embeddings(h, w, nlf, dev)
+        # host-side schedule of the guidance weight (:906-909; the reference calls t.item() per step)
+        n = num_inference_steps
+        gs = [1 + guidance_scale * ((1 - math.cos(math.pi * ((n - int(t)) / n) ** 5.0)) / 2) if use_dynamic_cfg
+              else guidance_scale for t in ts.tolist()]
+        coefs = torch.cat([self.scheduler.coefs.to(dev), torch.tensor(gs, dtype=torch.float32, device=dev)[:, None]], 1)
+        for i, t in enumerate(ts):
+            if self._interrupt:
+                continue
+            x = lat[None].expand(nb, -1, -1, -1, -1)
+            if id_latent is not None:
+                x = torch.cat([x, idl.expand(nb, -1, -1, -1, -1)], dim=1)                       # :868
+            x = torch.cat([x, cond], dim=2).contiguous()                                       # :880
+            pred = tr(hidden_states=x, encoder_hidden_states=prompt, timestep=t.expand(nb),
+                      image_rotary_emb=image_rotary_emb, attention_kwargs=attention_kwargs, return_dict=False)[0]
+            ops.cfg_vpred_step_(lat, pred.contiguous(), coefs[i], has_uncond=cfg_on)            # :896-927
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": lat[None]})
+                if "latents" in out and out["latents"] is not None:
+                    lat.copy_(out["latents"][0])
+        return lat[None]
+
+    @torch.no_grad()
+    def __call__(self, *args, **kwargs):
+        raise NotImplementedError(
+            "CogVideoXImageToVideoPipeline.__call__ needs diffusers' AutoencoderKLCogVideoX (third-party, not part of "
+            "the reference tree) for the condition encodes and the final decode; use .denoise() with latents, or wrap "
+            "it with your VAE: see DESIGN.md section 7.")

@@ -64,3 +64,44 @@ class FlowMatchEulerDiscreteScheduler:
         self._step_index += 1
         prev = lat.reshape(shp).to(model_output.dtype)
         return (prev,) if not return_dict else _Cfg(prev_sample=prev)
+
+
+class CogVideoXDDIMScheduler:
+    """diffusers' CogVideoXDDIMScheduler as the CogVideoX-5B-I2V repo configures it (third-party, restated, unpinned):
+    scaled-linear betas, SNR shift, zero-terminal-SNR rescale, trailing spacing, v-prediction, eta = 0.
+    Call sites: pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:771 (retrieve_timesteps), :916 (step)."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.0120, snr_shift_scale=1.0,
+                 rescale_betas_zero_snr=True, set_alpha_to_one=True, **unused):
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, prediction_type="v_prediction",
+                           timestep_spacing="trailing")
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0)
+        ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+        if rescale_betas_zero_snr:
+            s = ac.sqrt()
+            a0, at = s[0].clone(), s[-1].clone()
+            ac = ((s - at) * (a0 / (a0 - at))) ** 2
+        self.alphas_cumprod = ac
+        self.final_alpha_cumprod = torch.tensor(1.0, dtype=torch.float64) if set_alpha_to_one else ac[0]
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None, **unused):
+        n = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ts = np.round(np.arange(n, 0, -n / num_inference_steps)).astype(np.int64) - 1
+        self.timesteps = torch.from_numpy(ts).to(device)
+        # per-step coefficients {sa, sb, ca, cb} of  x0 = sa*x - sb*v ; x' = ca*x + cb*x0  (device-resident table)
+        rows = []
+        for t in ts.tolist():
+            prev = t - n // num_inference_steps
+            a_t = self.alphas_cumprod[t]
+            a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+            ca = ((1 - a_p) / (1 - a_t)) ** 0.5
+            cb = a_p ** 0.5 - a_t ** 0.5 * ca
+            rows.append([float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(ca), float(cb)])
+        self.coefs = torch.tensor(rows, dtype=torch.float32, device=device)

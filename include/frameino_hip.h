@@ -54,6 +54,18 @@ int fino_gated_residual(const void* x, const void* y, void* out, int64_t rows, i
                         int64_t ldo, const float* gate, int64_t mod_stride, const int32_t* sel, int dtype,
                         void* stream);
 
+/* out = T( x + T(y * gate[r]) ): the gate multiply rounded to T first (CogVideoX block, all-T arithmetic). */
+int fino_gated_residual_staged(const void* x, const void* y, void* out, int64_t rows, int dim, int64_t ldx, int64_t ldy,
+                               int64_t ldo, const float* gate, int64_t mod_stride, const int32_t* sel, int dtype,
+                               void* stream);
+
+/* y = T( T( T(LN(x)*w + b) * T(1 + scale[r]) ) + shift[r] ): diffusers CogVideoXLayerNormZero / AdaLayerNorm executed in T
+ * (cogvideox_transformer_3d.py:134-136, :150-152, :541); w/b fp32 copies of the T affine parameters (NULL => none),
+ * scale/shift fp32 copies of the T modulation rows selected by sel (one row per (batch, text|video)). */
+int fino_layernorm_zero(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy, const float* w,
+                        const float* b, const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel,
+                        float eps, int dtype, void* stream);
+
 /* In-place q/k preparation: RMSNorm over the whole row (all heads), weight multiply in T, then RoPE on adjacent
  * channel pairs with per-token tables cos/sin [rows, head_dim/2] fp32 (NULL => no RoPE).
  * transformer_wan.py:64-67 (norm_q / norm_k, "rms_norm_across_heads") and :73-90 (apply_rotary_emb).
@@ -89,8 +101,11 @@ int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batc
  *   FINO_EPI_RESIDUAL        C = T(R + y)                              (transformer_wan.py:341)
  *   FINO_EPI_GATED_RESIDUAL  C = T(float(R) + float(y) * gate[r][n])   (transformer_wan.py:336, :348)
  * gate rows as in fino_adaln_modulate. C may alias R.  Replaces nn.Linear at transformer_wan.py:60-62, :117,
- * diffusers FeedForward (:347), patch_embedding (:486) and proj_out (:537) after patchify. */
-enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EPI_GATED_RESIDUAL = 3 };
+ * diffusers FeedForward (:347), patch_embedding (:486) and proj_out (:537) after patchify.
+ *   FINO_EPI_GATED_RESIDUAL_STAGED  C = T(R + T(y * gate[r][n]))    (cogvideox_transformer_3d.py:146-147, :158-159:
+ *                                   the CogVideoX block does the gate multiply and the add in T) */
+enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EPI_GATED_RESIDUAL = 3,
+       FINO_EPI_GATED_RESIDUAL_STAGED = 4 };
 int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
               int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
@@ -124,6 +139,13 @@ int fino_wan_model_input(const float* lat, const float* cond, const float* id_la
 int fino_cfg_euler_step(const void* cond_pred, const void* uncond_pred, float* lat, int channels, int gen_frames,
                         int total_frames, int height, int width, float guidance, const float* dt_dev, int round_out,
                         int dtype, void* stream);
+
+/* CogVideoX sampler step (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:893-927, v-prediction DDIM):
+ *   v = u + g*(c-u) in fp32;  x0 = T(sa*x) - sb*v;  x' = T(T(ca*x) + cb*x0);  coef_dev = {sa, sb, ca, cb, g} (device).
+ * pred [2, batch_stride] of T (uncond, cond; the first n_lat elements of each are the generated frames -- ID frames
+ * come after, :901-902), lat [n_lat] of T, updated in place.  has_uncond == 0: v = pred[0]. */
+int fino_cfg_vpred_step(const void* pred, void* lat, int64_t n_lat, int64_t batch_stride, const float* coef_dev,
+                        int has_uncond, int dtype, void* stream);
 
 /* ---- Wan 3D causal VAE (architecture/autoencoder_kl_wan.py) ------------------------------------------------------
  * Activations are channels-last [T, H, W, Cpad] of `dtype`, Cpad = channels zero-padded to a multiple of 64.

@@ -1,0 +1,51 @@
+"""Oracle restatement of the CogVideoX FrameINO denoise loop (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py
+:848-944) with a v-prediction DDIM step (diffusers CogVideoXDDIMScheduler, third-party, restated: unpinned).
+Test infrastructure."""
+import math
+
+import numpy as np
+import torch
+
+from .cog_dit import cog_forward
+
+
+def ddim_tables(num_inference_steps, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.0120,
+                snr_shift_scale=1.0):
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+    s = ac.sqrt()
+    a0, at = s[0].clone(), s[-1].clone()
+    ac = ((s - at) * (a0 / (a0 - at))) ** 2                        # zero-terminal-SNR rescale
+    ts = np.round(np.arange(num_train_timesteps, 0, -num_train_timesteps / num_inference_steps)).astype(np.int64) - 1
+    return ac, ts
+
+
+def cog_denoise_loop(sd, cfg, latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_embeds,
+                     rotary, guidance, steps, dynamic_cfg=False):
+    ac, ts = ddim_tables(steps)
+    nlf = latents.shape[1]
+    prompt = torch.cat([negative_embeds, prompt_embeds], dim=0)                    # :768
+    lat = latents.clone()
+    for t in ts.tolist():
+        x = torch.cat([lat] * 2)
+        lid = torch.cat([id_latent] * 2)
+        pad = torch.zeros_like(lid)
+        x = torch.cat([x, lid], dim=1)                                             # :868
+        img = torch.cat([torch.cat([image_latents] * 2), pad], dim=1)
+        trj = torch.cat([torch.cat([traj_latents] * 2), pad], dim=1)
+        x = torch.cat([x, img, trj], dim=2)                                        # :880
+        pred = cog_forward(sd, cfg, x, prompt, torch.full((2,), float(t)), rotary).float()[:, :nlf]
+        g = guidance
+        if dynamic_cfg:
+            g = 1 + guidance * ((1 - math.cos(math.pi * ((steps - t) / steps) ** 5.0)) / 2)
+        u, c = pred.chunk(2)
+        v = u + g * (c - u)
+        prev = t - 1000 // steps
+        a_t = ac[t]
+        a_p = ac[prev] if prev >= 0 else torch.tensor(1.0, dtype=torch.float64)
+        x0 = (a_t ** 0.5) * lat - ((1 - a_t) ** 0.5) * v
+        ca = ((1 - a_p) / (1 - a_t)) ** 0.5
+        cb = a_p ** 0.5 - a_t ** 0.5 * ca
+        lat = (ca * lat + cb * x0).to(latents.dtype)
+    return lat

@@ -1,0 +1,89 @@
+"""CogVideoX FrameIn DiT on the HIP path vs the golden vectors recorded from the reference model (tiny, B=2,
+RoPE extended by the first frame's rows; default and resized resolution), the plugin surface of
+cogvideox_transformer_3d.py:346-444, and the oracle run in bf16."""
+import pytest
+import torch
+
+from tests.parity import rel_rms
+from tests.test_oracle_golden import _cog_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(golden):
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    cfg, sd, a = golden("cog_dit_tiny")
+    cfg = _cog_cfg(cfg)
+    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    return m.eval(), cfg, sd, a
+
+
+def _run(m, a, tag):
+    return m(hidden_states=a[f"x_{tag}"].to(DEV).bfloat16(), encoder_hidden_states=a[f"txt_{tag}"].to(DEV).bfloat16(),
+             timestep=a[f"ts_{tag}"].to(DEV), image_rotary_emb=(a[f"cos_{tag}"].to(DEV), a[f"sin_{tag}"].to(DEV)),
+             return_dict=False)[0]
+
+
+@pytest.mark.parametrize("tag", ["def", "rsz"])
+def test_cog_forward_vs_reference_golden(golden, tag):
+    m, cfg, sd, a = _model(golden)
+    out = _run(m, a, tag)
+    ref = a[f"y_{tag}"]
+    assert out.shape == ref.shape
+    # all-bf16 reference arithmetic (CogVideoX has no fp32 islands): stated tolerance rel-RMS <= 4e-2 vs fp32
+    from oracle import cog_dit as C
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    refb = C.cog_forward(sdb, cfg, a[f"x_{tag}"].bfloat16(), a[f"txt_{tag}"].bfloat16(), a[f"ts_{tag}"],
+                         (a[f"cos_{tag}"], a[f"sin_{tag}"])).float()
+    r32, rb, rr = rel_rms(out, ref), rel_rms(out, refb), rel_rms(refb, ref)
+    print(f"[{tag}] hip-vs-fp32 {r32:.4f}  hip-vs-bf16-oracle {rb:.4f}  bf16-oracle-vs-fp32 {rr:.4f}")
+    assert r32 < 4e-2 and rb < 3e-2
+
+
+def test_fused_projections_and_custom_processor(golden):
+    from frameino_amd.attention_processor import MI355CogVideoXAttnProcessor
+    m, cfg, sd, a = _model(golden)
+    base = _run(m, a, "def")
+    m.fuse_qkv_projections()
+    assert all(type(p).__name__ == "MI355FusedCogVideoXAttnProcessor" for p in m.attn_processors.values())
+    fused = _run(m, a, "def")
+    m.unfuse_qkv_projections()
+    assert torch.equal(base, fused)
+
+    calls = []
+
+    class Spy(MI355CogVideoXAttnProcessor):
+        def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None):
+            calls.append(tuple(hidden_states.shape))
+            return super().__call__(attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb)
+
+    m.set_attn_processor(Spy())
+    out = _run(m, a, "def")
+    assert len(calls) == cfg["num_layers"] and calls[0] == (2, 64, 128)
+    assert rel_rms(out, base) < 1e-2
+    with pytest.raises(ValueError, match="number of processors"):
+        m.set_attn_processor({"transformer_blocks.0.attn1.processor": Spy()})
+
+
+def test_cog_denoise_loop_and_rope_prep_vs_golden(golden):
+    """The CFG-batched FrameIn loop (:848-944) on the HIP path vs the loop recorded around the reference transformer."""
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    cfg, sd, a = golden("cog_loop_tiny")
+    cfg = _cog_cfg(cfg)
+    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDDIMScheduler())
+    # rotary tables built by the pipeline == the reference's get_3d_rotary_pos_embed + first-frame extension
+    cos, sin = pipe._prepare_rotary_positional_embeddings(64, 64, 3, "cpu")
+    torch.testing.assert_close(cos, a["cos"], atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(sin, a["sin"], atol=1e-6, rtol=1e-6)
+    d = lambda k: a[k].to(DEV)          # noqa: E731
+    for dyn, key in ((False, "out"), (True, "out_dyn")):
+        out = pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+                           d("negative_embeds"), float(a["guidance"]), int(a["steps"]), use_dynamic_cfg=dyn)
+        r = rel_rms(out, a[key])
+        assert out.shape == a[key].shape and r < 6e-2, (key, r)

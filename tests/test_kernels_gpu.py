@@ -279,3 +279,46 @@ def test_sampler_glue_matches_reference_arithmetic(ops):
     lat3 = lat.clone()
     ops.cfg_euler_step_(lat3, pc, None, 1.0, dt, round_out=False)
     assert torch.equal(lat3, lat + dt * pc[:, :fg])
+
+
+def test_layernorm_zero_staged_rounding(ops):
+    """CogVideoXLayerNormZero executed in bf16: every tensor op rounds (cogvideox_transformer_3d.py:134-136)."""
+    b, L, d = 2, 37, 3072
+    x = rnd(b * L, d, seed=60)
+    w, bb = rnd(d, seed=61).float() * 0.1 + 1, rnd(d, seed=62).float() * 0.1
+    tab = rnd(2 * b, 3, d, seed=63, scale=0.3).float()            # bf16-representable values
+    sel = (torch.arange(b * L, device=DEV) % 4).to(torch.int32)
+    y = ops.layernorm_zero(x, w, bb, tab[:, 0], tab[:, 1], sel, 1e-5)
+    n = F.layer_norm(x, (d,), w.bfloat16(), bb.bfloat16(), 1e-5)
+    ref = n * (1 + tab[:, 1].bfloat16())[sel.long()] + tab[:, 0].bfloat16()[sel.long()]
+    ulp_close(y, ref, torch.bfloat16, max_ulp_frac=0.02)
+
+
+def test_gated_residual_staged_and_gemm_epilogue(ops):
+    m, n, k = 300, 512, 256
+    x, y = rnd(m, n, seed=64), rnd(m, n, seed=65)
+    gate = rnd(4, 3, n, seed=66).float()
+    sel = (torch.arange(m, device=DEV) % 4).to(torch.int32)
+    out = ops.gated_residual(x, y, gate[:, 2], sel, staged=True)
+    ref = x + gate[:, 2].bfloat16()[sel.long()] * y
+    assert torch.equal(out, ref)
+    a, w = rnd(m, k, seed=67), rnd(n, k, seed=68, scale=0.06)
+    bias = rnd(n, seed=69)
+    out = ops.gemm(a, w, bias, ops.EPI_GATED_RESIDUAL_STAGED, residual=x, gate=gate[:, 2], sel=sel)
+    lin = (a.float() @ w.float().t() + bias.float()).bfloat16()
+    ref = x + gate[:, 2].bfloat16()[sel.long()] * lin
+    ulp_close(out, ref, torch.bfloat16, max_ulp_frac=0.02)
+
+
+def test_cfg_vpred_step(ops):
+    f, ft, c, h, w_ = 3, 4, 2, 4, 6
+    lat = rnd(f, c, h, w_, seed=70)
+    pred = rnd(2, ft, c, h, w_, seed=71)
+    coef = torch.tensor([0.83, 0.55, 0.91, 0.12, 6.0], device=DEV)
+    lat2 = lat.clone()
+    ops.cfg_vpred_step_(lat2, pred, coef, True)
+    p = pred.float()[:, :f]
+    v = p[0] + 6.0 * (p[1] - p[0])
+    x0 = (coef[0] * lat.float()).bfloat16().float() - coef[1] * v
+    ref = ((coef[2] * lat.float()).bfloat16().float() + coef[3] * x0).bfloat16()
+    assert torch.equal(lat2, ref)

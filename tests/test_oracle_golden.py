@@ -110,3 +110,37 @@ def test_wan_vae_in_reference_pipeline_run(golden):
     ref = a["out_video"]                                   # [1, F, H, W, 3] in [0, 1]
     got = (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
     torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- CogVideoX DiT
+def _cog_cfg(cfg):
+    out = dict(cfg)
+    for k in ("flip_sin_to_cos", "norm_elementwise_affine", "use_rotary_positional_embeddings",
+              "use_learned_positional_embeddings", "use_FrameIn"):
+        out[k] = bool(out[k])
+    return out
+
+
+def test_cog_forward_frame_in_default_and_resized_resolution(golden):
+    from oracle import cog_dit as C
+    cfg, sd, a = golden("cog_dit_tiny")
+    cfg = _cog_cfg(cfg)
+    for tag in ("def", "rsz"):
+        out = C.cog_forward(sd, cfg, a[f"x_{tag}"], a[f"txt_{tag}"], a[f"ts_{tag}"], (a[f"cos_{tag}"], a[f"sin_{tag}"]))
+        torch.testing.assert_close(out, a[f"y_{tag}"], atol=5e-5, rtol=5e-5)
+    # FusedCogVideoXAttnProcessor2_0 == CogVideoXAttnProcessor2_0 in the reference (G7)
+    torch.testing.assert_close(a["y_def_fused"], a["y_def"], atol=1e-5, rtol=1e-5)
+
+
+def test_cog_denoise_loop_restatement(golden):
+    from oracle.cog_pipeline import cog_denoise_loop, ddim_tables
+    cfg, sd, a = golden("cog_loop_tiny")
+    cfg = _cog_cfg(cfg)
+    ac, ts = ddim_tables(int(a["steps"]))
+    assert ts.tolist() == a["timesteps"].tolist()
+    torch.testing.assert_close(ac.float(), a["alphas_cumprod"], atol=1e-7, rtol=1e-6)
+    for dyn, key in ((False, "out"), (True, "out_dyn")):
+        out = cog_denoise_loop(sd, cfg, a["latents"], a["image_latents"], a["traj_latents"], a["id_latent"],
+                               a["prompt_embeds"], a["negative_embeds"], (a["cos"], a["sin"]), float(a["guidance"]),
+                               int(a["steps"]), dynamic_cfg=dyn)
+        torch.testing.assert_close(out, a[key], atol=1e-4, rtol=1e-4)

@@ -210,7 +210,104 @@ def gen_wan_vae():
          **arrays)
 
 
-GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae}
+# ----------------------------------------------------------------------------------- CogVideoX DiT (FrameIn)
+COG_TINY = dict(num_attention_heads=2, attention_head_dim=64, in_channels=6, out_channels=2, flip_sin_to_cos=True,
+                freq_shift=0, time_embed_dim=32, text_embed_dim=16, num_layers=2, sample_width=8, sample_height=8,
+                sample_frames=9, patch_size=2, temporal_compression_ratio=4, max_text_seq_length=8,
+                norm_elementwise_affine=True, norm_eps=1e-5, use_rotary_positional_embeddings=True,
+                use_learned_positional_embeddings=True, use_FrameIn=True)
+
+
+def gen_cog_dit():
+    """G7-G9: tiny CogVideoX FrameIn transformer (B=2, RoPE extended by the first frame's rows as the pipeline does
+    :834-839), at the default resolution and at a resized one (trilinear PE resize), fused == unfused processors."""
+    from architecture.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from architecture.embeddings import get_3d_rotary_pos_embed
+    torch.manual_seed(0)
+    m = CogVideoXTransformer3DModel(**COG_TINY).eval()
+    randomize_(m, 31, std=0.15)
+    with torch.no_grad():
+        m.patch_embed.pos_embedding.copy_(torch.randn(m.patch_embed.pos_embedding.shape,
+                                                      generator=torch.Generator().manual_seed(32)) * 0.3)
+    g = torch.Generator().manual_seed(33)
+    arrays = {}
+    for tag, (hh, ww) in (("def", (8, 8)), ("rsz", (8, 12))):
+        x = torch.randn(2, 4, 6, hh, ww, generator=g)
+        txt = torch.randn(2, 8, 16, generator=g)
+        ts = torch.tensor([601.0, 601.0])
+        cos, sin = get_3d_rotary_pos_embed(64, ((0, 0), (hh // 2, ww // 2)), (hh // 2, ww // 2), 3)
+        n1 = cos.shape[0] // 3
+        cos = torch.cat([cos, cos[:n1]], dim=0)
+        sin = torch.cat([sin, sin[:n1]], dim=0)
+        y = m(hidden_states=x, encoder_hidden_states=txt, timestep=ts, image_rotary_emb=(cos, sin),
+              return_dict=False)[0]
+        arrays.update({f"x_{tag}": x, f"txt_{tag}": txt, f"ts_{tag}": ts, f"cos_{tag}": cos, f"sin_{tag}": sin,
+                       f"y_{tag}": y})
+    m.fuse_qkv_projections()
+    yf = m(hidden_states=arrays["x_def"], encoder_hidden_states=arrays["txt_def"], timestep=arrays["ts_def"],
+           image_rotary_emb=(arrays["cos_def"], arrays["sin_def"]), return_dict=False)[0]
+    m.unfuse_qkv_projections()
+    arrays["y_def_fused"] = yf
+    sd = {k: v for k, v in m.state_dict().items() if "to_qkv" not in k}
+    save("cog_dit_tiny", cfg=COG_TINY, sd=sd, **arrays)
+
+
+def gen_cog_loop():
+    """G10 (Cog): the denoise loop of pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944 re-created around
+    the REFERENCE transformer (latents passed explicitly; the third-party CogVideoX VAE is not available offline, so
+    the loop starts from latents).  DDIM from the restated stand-in scheduler."""
+    import math
+    from diffusers.schedulers import CogVideoXDDIMScheduler
+    from architecture.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from architecture.embeddings import get_3d_rotary_pos_embed
+    torch.manual_seed(0)
+    m = CogVideoXTransformer3DModel(**COG_TINY).eval()
+    randomize_(m, 41, std=0.15)
+    with torch.no_grad():
+        m.patch_embed.pos_embedding.copy_(torch.randn(m.patch_embed.pos_embedding.shape,
+                                                      generator=torch.Generator().manual_seed(42)) * 0.3)
+    g = torch.Generator().manual_seed(43)
+    nlf, C, hh, ww = 3, 2, 8, 8
+    latents = torch.randn(1, nlf, C, hh, ww, generator=g)
+    image_latents = torch.cat([torch.randn(1, 1, C, hh, ww, generator=g), torch.zeros(1, nlf - 1, C, hh, ww)], dim=1)
+    traj_latents = torch.randn(1, nlf, C, hh, ww, generator=g)
+    id_latent = torch.randn(1, 1, C, hh, ww, generator=g)
+    pe, ne = torch.randn(1, 8, 16, generator=g), torch.randn(1, 8, 16, generator=g)
+    prompt = torch.cat([ne, pe], dim=0)                                          # :768
+    steps, gs = 4, 6.0
+    cos, sin = get_3d_rotary_pos_embed(64, ((0, 0), (hh // 2, ww // 2)), (hh // 2, ww // 2), nlf)
+    n1 = cos.shape[0] // nlf
+    rot = (torch.cat([cos, cos[:n1]], 0), torch.cat([sin, sin[:n1]], 0))         # :834-839
+    outs = {}
+    for dyn in (False, True):
+        sched = CogVideoXDDIMScheduler()
+        sched.set_timesteps(steps)
+        lat = latents.clone()
+        for t in sched.timesteps:
+            x = torch.cat([lat] * 2)
+            img = torch.cat([image_latents] * 2)
+            trj = torch.cat([traj_latents] * 2)
+            lid = torch.cat([id_latent] * 2)
+            x = torch.cat([x, lid], dim=1)
+            pad = x.new_zeros(lid.shape)
+            x = torch.cat([x, torch.cat([img, pad], 1), torch.cat([trj, pad], 1)], dim=2)
+            npred = m(hidden_states=x, encoder_hidden_states=prompt, timestep=t.expand(2), image_rotary_emb=rot,
+                      return_dict=False)[0].float()[:, :nlf]
+            scale = gs
+            if dyn:
+                scale = 1 + gs * ((1 - math.cos(math.pi * ((steps - t.item()) / steps) ** 5.0)) / 2)
+            u, c = npred.chunk(2)
+            lat = sched.step(u + scale * (c - u), int(t), lat)[0]
+        outs["out_dyn" if dyn else "out"] = lat
+    sched.set_timesteps(steps)
+    save("cog_loop_tiny", cfg=COG_TINY, sd={k: v for k, v in m.state_dict().items()}, latents=latents,
+         image_latents=image_latents, traj_latents=traj_latents, id_latent=id_latent, prompt_embeds=pe,
+         negative_embeds=ne, cos=rot[0], sin=rot[1], timesteps=sched.timesteps,
+         alphas_cumprod=sched.alphas_cumprod.float(), steps=np.array(steps), guidance=np.array(gs), **outs)
+
+
+GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae, "cog_dit": gen_cog_dit,
+        "cog_loop": gen_cog_loop}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
