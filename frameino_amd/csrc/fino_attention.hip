@@ -106,6 +106,27 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     int st_off[kLoadsPerThread];
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; ++i) st_off[i] = lds_off<D>(st_row[i], st_ch[i]);
+#ifdef FINO_ATTN_DMA
+    // LDS-DMA staging: wave-instruction wi = wave + 8*i writes 1 KiB (lane-linear) = 1024/rowbytes tile rows; the
+    // XOR swizzle goes on the per-lane SOURCE chunk (same involution as the reads).
+    constexpr int kRowsPerInstr = 1024 / (D * 2);
+    int dma_row[kLoadsPerThread], dma_ch[kLoadsPerThread];
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        const int wi = wave + kWaves * i;
+        dma_row[i] = wi * kRowsPerInstr + lane / kChunksPerRow;
+        const int cphys = lane % kChunksPerRow;
+        dma_ch[i] = (lds_off<D>(dma_row[i], cphys) - dma_row[i] * D * 2) >> 4;   // logical chunk stored at cphys
+    }
+#define DMA_TILE(BASE_PTR_, ROW_STRIDE_, T_, SLOT_)                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                              \
+        int row_ = (T_) * kKV + dma_row[i_];                                                                      \
+        row_ = row_ < p.lk ? row_ : p.lk - 1;                                                                     \
+        __builtin_amdgcn_global_load_lds(                                                                         \
+            (const FINO_GLB void*)((BASE_PTR_) + (int64_t)row_ * (ROW_STRIDE_) + dma_ch[i_] * 8),                 \
+            (FINO_LDS void*)(smem + (SLOT_) * kTileBytes + (wave + kWaves * i_) * 1024), 16, 0, 0);               \
+    }
+#endif
 #define STAGE_LOAD(T_)                                                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
         int row_ = (T_) * kKV + st_row[i_];                                                           \
@@ -152,9 +173,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     // while the VALU does the softmax of S(t); then O += V(t)^T.P(t).  LDS: K[2] ring + V[2] ring; K(t+2) and
     // V(t+1) travel global -> registers during the iteration and are written to LDS at its end; 1 barrier / tile.
     const int nt = (p.lk + kKV - 1) / kKV;
+#ifdef FINO_ATTN_DMA
+    DMA_TILE(kp, p.k_rs, 0, 0)
+    DMA_TILE(vp, p.v_rs, 0, 2)
+    if (nt > 1) { DMA_TILE(kp, p.k_rs, 1, 1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (false) {
+#else
     STAGE_LOAD(0)
     STAGE_WRITE(0)
     if (nt > 1) {
+#endif
         // K(1) only
 #pragma unroll
         for (int i = 0; i < kLoadsPerThread; ++i) {
@@ -168,6 +197,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
 
     f32x16_t sc0, sc1;   // S(t)
     QK_TILE(0, sc0, sc1)
+#ifdef FINO_ATTN_PRIO
+    // static priority for the later-dispatched half (waves 4-7 lose VALU arbitration to their SIMD partners otherwise)
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // row max of a tile (query on the lane; partner half-wave holds the other 32 keys) -> MX_
 #define ROW_MAX(S0_, S1_, MX_)                                                                               \
@@ -206,7 +239,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     {                                                                                                        \
         const int cur = t & 1;                                                                               \
         /* global -> registers: K(t+2), V(t+1) (clamped rows; dead data is never written to LDS) */          \
-        if (HAS_NEXT_) {                                                                                     \
+        if (HAS_NEXT_ && kDma) {                                                                             \
+            DMA_TILE_OR_NOTHING(kp, p.k_rs, t + 2, cur)                                                      \
+            DMA_TILE_OR_NOTHING(vp, p.v_rs, t + 1, 2 + (cur ^ 1))                                            \
+        }                                                                                                    \
+        if (HAS_NEXT_ && !kDma) {                                                                            \
             _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i) {                                    \
                 int rk = (t + 2) * kKV + st_row[i];                                                          \
                 int rv = (t + 1) * kKV + st_row[i];                                                          \
@@ -262,12 +299,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             float mxn;                                                                                       \
             ROW_MAX(sn0, sn1, mxn)                                                                           \
             /* registers -> LDS: K(t+2) into the K slot S(t) came from, V(t+1) into the other V slot */      \
-            if (t + 2 < nt) {                                                                                \
+            if (!kDma && t + 2 < nt) {                                                                       \
                 _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
                     *reinterpret_cast<u32x4_t*>(smem + cur * kTileBytes + st_off[i]) = kreg[i];              \
             }                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                      \
-                *reinterpret_cast<u32x4_t*>(smem + (2 + (cur ^ 1)) * kTileBytes + st_off[i]) = vreg[i];      \
+            if (!kDma) {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
+                    *reinterpret_cast<u32x4_t*>(smem + (2 + (cur ^ 1)) * kTileBytes + st_off[i]) = vreg[i];  \
+            }                                                                                                \
+            if (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
             sc0 = sn0;                                                                                       \
             sc1 = sn1;                                                                                       \
             MAYBE_RESCALE(mxn)                                                                               \
@@ -276,6 +316,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     }
 
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
+#ifdef FINO_ATTN_DMA
+    constexpr bool kDma = true;
+#define DMA_TILE_OR_NOTHING(A_, B_, C_, D_) DMA_TILE(A_, B_, C_, D_)
+#else
+    constexpr bool kDma = false;
+#define DMA_TILE_OR_NOTHING(A_, B_, C_, D_)
+#endif
     int t = 0;
     for (; t < nt - 1; ++t) TILE_BODY(true, false)
     TILE_BODY(false, true)

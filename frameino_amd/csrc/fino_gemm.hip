@@ -10,44 +10,15 @@
 // The epilogue stages the bf16 tile through LDS so that global stores (and the fused residual reads) are whole
 // 512-byte rows.  Workgroup ids are remapped per XCD (8 L2s) in 4-tile-high groups for operand reuse in L2.
 // A generic variant (register-staged, predicated, zero-filled) covers ragged K and is used for tiny shapes.
+#include <stdlib.h>
+
 #include <type_traits>
 
-#include "fino_common.h"
+#include "fino_gemm_common.h"
+
+using namespace fino_gemm_ns;
 
 namespace {
-
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int kThreads = 512;
-constexpr int kTileBytes = BM * BK * 2;        // 32 KiB per operand tile
-constexpr int kStageBytes = 2 * kTileBytes;    // A + W
-constexpr int kCsStride = BN * 2 + 16;         // padded epilogue row (bytes)
-constexpr int kSmemBytes = (2 * kStageBytes > BM * kCsStride) ? 2 * kStageBytes : BM * kCsStride;
-
-struct GemmParams {
-    const uint16_t* a;
-    const uint16_t* w;
-    const uint16_t* bias;
-    uint16_t* c;
-    const uint16_t* r;
-    const float* gate;
-    const int32_t* sel;
-    int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
-    int tiles_m, tiles_n;
-    // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
-    // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
-    int to, ho, wo, ti, hi, wi;      // output / input extents
-    int kt, kh, kw, st, sh, sw, pt, ph, pw, up, cin_chunks;
-    const uint16_t* zero_page;       // >= 128 B of zeros: source of out-of-range taps (LDS-DMA cannot zero-fill)
-};
-
-__device__ __forceinline__ float gelu_tanh_f32(float x) {
-    // 0.5*x*(1+tanh(u)) == x*sigmoid(2u),  u = sqrt(2/pi)*(x + 0.044715 x^3)
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
-}
-
-// swizzle of the 16-byte chunk index inside a 128-byte tile row
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 template <typename T, int EPI, bool GENERIC, bool CONV>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
@@ -157,6 +128,37 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
         }
     };
 
+    // one LDS-DMA piece (one wave-instruction = 8 tile rows) of K-tile `kt`: pieces 0..3 = A rounds, 4..7 = W rounds
+    auto stage_piece = [&](int buf, int kt, int piece) {
+        char* ab = smem + buf * kStageBytes;
+        char* wb = ab + kTileBytes;
+        const int64_t k0 = (int64_t)kt * BK;
+        const int j = piece & 3;
+        if (piece >= 4) {
+            __builtin_amdgcn_global_load_lds((const FINO_GLB void*)(w_src[j] + k0),
+                                             (FINO_LDS void*)(wb + j * 8192 + wave * 1024), 16, 0, 0);
+        } else if constexpr (CONV) {
+            const int tap = kt / p.cin_chunks;
+            const int c0 = (kt - tap * p.cin_chunks) * BK;
+            const int dw = tap % p.kw;
+            const int dh = (tap / p.kw) % p.kh;
+            const int dt = tap / (p.kw * p.kh);
+            const int hlim = p.up ? 2 * p.hi : p.hi, wlim = p.up ? 2 * p.wi : p.wi;
+            const int ti = pos_t[j] * p.st + dt - p.pt;
+            int hi = pos_h[j] * p.sh + dh - p.ph;
+            int wi = pos_w[j] * p.sw + dw - p.pw;
+            const bool ok = a_ok[j] && ti >= 0 && ti < p.ti && hi >= 0 && hi < hlim && wi >= 0 && wi < wlim;
+            if (p.up) { hi >>= 1; wi >>= 1; }
+            const uint16_t* src = ok ? p.a + (((int64_t)ti * p.hi + hi) * p.wi + wi) * p.lda + c0 + sk[j]
+                                     : p.zero_page + sk[j];
+            __builtin_amdgcn_global_load_lds((const FINO_GLB void*)src, (FINO_LDS void*)(ab + j * 8192 + wave * 1024),
+                                             16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((const FINO_GLB void*)(a_src[j] + k0),
+                                             (FINO_LDS void*)(ab + j * 8192 + wave * 1024), 16, 0, 0);
+        }
+    };
+
     // ---- fragment read addressing: row = base + 16*tile + (lane&15), chunk = (4*kk + (lane>>4)) ^ swz(row) ----
     const int frow = lane & 15;
     const int pch0 = (lane >> 4) ^ (frow >> 1);  // physical chunk for kk = 0; kk = 1 flips bit 2
@@ -170,30 +172,91 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)((p.k + BK - 1) / BK);
-    stage(0, 0);
-    __syncthreads();  // (drains the LDS-DMA: vmcnt(0) + barrier)
+#define LOAD_FRAGS(SB_, KK_, WF_, AF_)                                                                           \
+    {                                                                                                            \
+        const int pch_ = (pch0 ^ ((KK_) << 2)) << 4;                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                         \
+            WF_[j_] = *reinterpret_cast<const u32x4_t*>((SB_) + w_base + j_ * 2048 + pch_);                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                         \
+            AF_[i_] = *reinterpret_cast<const u32x4_t*>((SB_) + a_base + i_ * 2048 + pch_);                      \
+    }
+#define MFMA_BLOCK(WF_, AF_)                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                         \
+            acc[i_][j_] = T::mfma16(__builtin_bit_cast(vec8, WF_[j_]), __builtin_bit_cast(vec8, AF_[i_]), acc[i_][j_]);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sb = smem + cur * kStageBytes;
+    if constexpr (GENERIC) {
+        // simple loop (register-staged, predicated): ragged K / tiny shapes
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const char* sb = smem + cur * kStageBytes;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int pch = (pch0 ^ (kk << 2)) << 4;
-            vec8 wf[4], af[8];
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4_t wf[4], af[8];
+                LOAD_FRAGS(sb, kk, wf, af)
+                MFMA_BLOCK(wf, af)
+            }
+            __syncthreads();
+        }
+    } else {
+        // Software-pipelined loop.  A K-tile is two k-steps (kk = 0, 1) of 32 MFMAs per wave; fragments of the NEXT
+        // k-step are fetched from LDS one row-group at a time into the registers the current k-step has just finished
+        // with (A fragment i is dead after its 4 MFMAs), so ds_reads always fly under MFMAs and the register peak is
+        // ~1.3 fragment sets instead of 2.  ONE barrier per K-tile, between the two MFMA blocks: it (1) publishes
+        // K-tile t+1 (LDS-DMA issued one iteration earlier, so the vmcnt(0) in front of it is free) and (2) retires
+        // every wave's reads of K-tile t, so the DMA of K-tile t+2 may overwrite that buffer.
+        u32x4_t wfa[4], wfb[4], af[8], an;   // an: the A fragment in flight for the next k-step
+#define LD_W(SB_, KK_, WF_)                                                                                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                              \
+        WF_[j_] = *reinterpret_cast<const u32x4_t*>((SB_) + w_base + j_ * 2048 + ((pch0 ^ ((KK_) << 2)) << 4));
+#define LD_A(SB_, KK_, I_) (*reinterpret_cast<const u32x4_t*>((SB_) + a_base + (I_) * 2048 + ((pch0 ^ ((KK_) << 2)) << 4)))
+        // one k-step: 8 groups of {4 MFMAs on af[i]; af[i] <- fragment i of the next k-step (loaded one group early)}
+#define K_STEP(WF_, SBN_, KKN_, HAS_NEXT_, DMA_)                                                                  \
+    {                                                                                                             \
+        if (HAS_NEXT_) an = LD_A(SBN_, KKN_, 0);                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
+            if (DMA_) stage_piece(cur, kt + 2, i_); /* LDS-DMA issue spread over the MFMA groups */                \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                      \
+                acc[i_][j_] = T::mfma16(__builtin_bit_cast(vec8, WF_[j_]), __builtin_bit_cast(vec8, af[i_]),      \
+                                        acc[i_][j_]);                                                             \
+            if (HAS_NEXT_) {                                                                                      \
+                af[i_] = an;                                                                                      \
+                if (i_ < 7) an = LD_A(SBN_, KKN_, i_ + 1);                                                        \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    }
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        LD_W(smem, 0, wfa)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wf[j] = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4*>(sb + w_base + j * 2048 + pch));
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                af[i] = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4*>(sb + a_base + i * 2048 + pch));
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(wf[j], af[i], acc[i][j]);
+        for (int i = 0; i < 8; ++i) af[i] = LD_A(smem, 0, i);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const char* sb = smem + cur * kStageBytes;
+            const char* sbn = smem + (cur ^ 1) * kStageBytes;
+            LD_W(sb, 1, wfb)
+            K_STEP(wfa, sb, 1, true, false)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // (on the last K-tile these fragment loads read the stale other buffer: valid LDS, values never used)
+            LD_W(sbn, 0, wfa)
+            const bool dma = kt + 2 < nk;          // wave-uniform: a scalar branch around each DMA piece
+            K_STEP(wfb, sbn, 0, true, dma)
         }
         __syncthreads();
     }
+#undef LD_W
+#undef LD_A
+#undef K_STEP
+#undef LOAD_FRAGS
+#undef MFMA_BLOCK
 
     // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
     // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*128 + i*16 + (lane&15)
