@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libframeino_hip.so")
+# FINO_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("FINO_LIB_PATH") or os.path.join(_HERE, "lib", "libframeino_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "frameino_hip.h")
 
 c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float

@@ -18,6 +18,14 @@
 
 using namespace fino_gemm_ns;
 
+#ifdef FINO_GEMM_STAMP
+__device__ unsigned long long fino_gemm_dbg[8 * 8];
+extern "C" int fino_gemm_debug_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_gemm_dbg), sizeof(unsigned long long) * 64);
+}
+#define STAMP(V_) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); }
+#endif
+
 namespace {
 
 template <typename T, int EPI, bool GENERIC, bool CONV>
@@ -236,20 +244,45 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
         LD_W(smem, 0, wfa)
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = LD_A(smem, 0, i);
+#ifdef FINO_GEMM_STAMP
+        unsigned long long t0, t1, t2, t3, t4, acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             const char* sb = smem + cur * kStageBytes;
             const char* sbn = smem + (cur ^ 1) * kStageBytes;
+#ifdef FINO_GEMM_STAMP
+            __builtin_amdgcn_sched_barrier(0); STAMP(t0) __builtin_amdgcn_sched_barrier(0);
+#endif
             LD_W(sb, 1, wfb)
             K_STEP(wfa, sb, 1, true, false)
+#ifdef FINO_GEMM_STAMP
+            __builtin_amdgcn_sched_barrier(0); STAMP(t1) __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0); STAMP(t2) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0); STAMP(t3) __builtin_amdgcn_sched_barrier(0);
+#else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // (on the last K-tile these fragment loads read the stale other buffer: valid LDS, values never used)
             LD_W(sbn, 0, wfa)
             const bool dma = kt + 2 < nk;          // wave-uniform: a scalar branch around each DMA piece
             K_STEP(wfb, sbn, 0, true, dma)
+#ifdef FINO_GEMM_STAMP
+            __builtin_amdgcn_sched_barrier(0); STAMP(t4) __builtin_amdgcn_sched_barrier(0);
+            acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t3 - t2; acc3 += t4 - t3;
+#endif
         }
+#ifdef FINO_GEMM_STAMP
+        if (blockIdx.x == 17 && lane == 0) {
+            fino_gemm_dbg[wave * 8 + 0] = acc0; fino_gemm_dbg[wave * 8 + 1] = acc1;
+            fino_gemm_dbg[wave * 8 + 2] = acc2; fino_gemm_dbg[wave * 8 + 3] = acc3;
+            fino_gemm_dbg[wave * 8 + 4] = (unsigned long long)nk;
+        }
+#endif
         __syncthreads();
     }
 #undef LD_W
