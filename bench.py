@@ -249,13 +249,14 @@ def main():
         ks = timer.summary().get("attn_self") if not a.graph else None
         heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
         if ks:
-            lq = L // max(1, getattr(pipe, "token_shards", 1))
-            fl = 4.0 * lq * L * heads * dh               # 4.Lq.Lk.D per launch
-            ach = fl / (ks["avg_us"] * 1e-6) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<BF16,128> (3D self-attention)",
+            # algorithmic FLOPs of the timed launches (4.Lq.Lk.H.Dh per batch element) / their summed duration
+            total_fl = timer.flops["attn_self"]
+            ach = total_fl / (ks["total_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<BF16,128,0> (3D self-attention)",
                                "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                                "traffic": None, "launches": ks["launches"], "avg_us": ks["avg_us"],
-                               "flops_per_launch": fl}
+                               "flops_per_launch": total_fl / ks["launches"],
+                               "batch_per_launch": 2 if (pipe.batch_cfg and world == 1) else 1}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, L)
         print(json.dumps(out), flush=True)

@@ -171,6 +171,9 @@ def attention(q, k, v, heads, out=None, scale=None):
                                        float(scale), _dt(q), _stream()), "fino_attn_fwd")
     if ev is not None:
         ev.record()
+        kt_ = KernelTimer.active
+        nm = "attn_self" if lq == lk else "attn_cross"
+        kt_.flops[nm] = kt_.flops.get(nm, 0.0) + 4.0 * b * lq * lk * hd      # 4.Lq.Lk.(H.Dh) per batch element
     return out
 
 

@@ -88,6 +88,7 @@ class WanImageToVideoPipeline:
         self.vae_scale_factor_spatial = vae.config.scale_factor_spatial if vae is not None else 8
         self.video_processor = VideoProcessor(vae_scale_factor=self.vae_scale_factor_spatial)
         self.use_hip_graph = False
+        self.batch_cfg = True            # run cond+uncond as one batch-2 forward when not CFG-parallel
         self._interrupt = False
         self._graph = None
 
@@ -262,6 +263,13 @@ class WanImageToVideoPipeline:
             # CFG branches on two rank groups; one exchange of noise_pred per step (frameino_amd/parallel.py)
             mine = fwd("cond", st.pe) if plan.cfg_idx == 0 else fwd("uncond", st.ne)
             pc, pu = plan.exchange_cfg(mine)
+        elif st.cfg and self.batch_cfg and st.pe_ne is not None and getattr(tr, "parallel", None) is None:
+            # both CFG branches as ONE batch-2 forward (rows of the same GEMMs: identical per-row arithmetic, twice
+            # the tiles per launch, weights streamed once).  The reference makes two calls (:862-882).
+            with tr.cache_context("cfg"):
+                both = tr(hidden_states=x.expand(2, -1, -1, -1, -1), timestep=None, encoder_hidden_states=st.pe_ne,
+                          return_dict=False, attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0]
+            pc, pu = both[0], both[1]
         else:
             pc = fwd("cond", st.pe)
             pu = fwd("uncond", st.ne) if st.cfg else None
@@ -293,6 +301,7 @@ class WanImageToVideoPipeline:
         st.pe = prompt_embeds.to(tr.dtype)
         st.ne = None if negative_prompt_embeds is None else negative_prompt_embeds.to(tr.dtype)
         st.cfg = guidance_scale > 1 and st.ne is not None
+        st.pe_ne = torch.cat([st.pe, st.ne], dim=0).contiguous() if st.cfg and st.pe.shape == st.ne.shape else None
         st.guidance = float(guidance_scale)
         st.attention_kwargs = attention_kwargs
         return st
@@ -336,8 +345,10 @@ class WanImageToVideoPipeline:
                 out = callback_on_step_end(self, i, timesteps[i], {k: loc[k] for k in callback_on_step_end_tensor_inputs})
                 if "latents" in out and out["latents"] is not latents:
                     st.lat.copy_(out["latents"][0])
-                st.pe = out.pop("prompt_embeds", st.pe)
-                st.ne = out.pop("negative_prompt_embeds", st.ne)
+                pe, ne = out.pop("prompt_embeds", st.pe), out.pop("negative_prompt_embeds", st.ne)
+                if pe is not st.pe or ne is not st.ne:
+                    st.pe, st.ne = pe, ne
+                    st.pe_ne = torch.cat([pe, ne], dim=0).contiguous() if st.cfg and pe.shape == ne.shape else None
         self._current_timestep = None
         return (1 - first_frame_mask) * condition + first_frame_mask * st.lat[None]          # :913
 

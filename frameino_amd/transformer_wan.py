@@ -283,12 +283,6 @@ class WanTransformer3DModel(nn.Module):
             attention_kwargs = dict(attention_kwargs)
             attention_kwargs.pop("scale", None)                                    # LoRA scale (:463-476): no PEFT here
         b = hidden_states.shape[0]
-        if b != 1:
-            outs = [self.forward(hidden_states[i:i + 1], timestep[i:i + 1] if timestep is not None else None,
-                                 encoder_hidden_states[i:i + 1], None, False, attention_kwargs, timestep_rows)[0]
-                    for i in range(b)]
-            out = torch.cat(outs)
-            return SimpleNamespace(sample=out) if return_dict else (out,)
         pk = self._packed or self._pack()
         o = self.ops
         cfg = self.config
@@ -298,38 +292,61 @@ class WanTransformer3DModel(nn.Module):
         L = ppf * pph * ppw
         d, heads, dh = self.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim
         dev, dt = hidden_states.device, hidden_states.dtype
-        cos, sin = self._rope(ppf, pph, ppw, dev)
+        cos1, sin1 = self._rope(ppf, pph, ppw, dev)
 
         # ---- token shard of this rank (frameino_amd/parallel.py); single GPU: the whole sequence ----
         sh = self.parallel if (self.parallel is not None and self.parallel.ways > 1) else None
         if sh is not None:
+            if b != 1:
+                raise NotImplementedError("token-sharded execution runs one sample per call")
             lo, n, lpad = sh.rows(L)              # first row, valid rows, padded shard length (equal on all ranks)
-            cos, sin = cos[lo:lo + n].contiguous(), sin[lo:lo + n].contiguous()
+            cos1, sin1 = cos1[lo:lo + n].contiguous(), sin1[lo:lo + n].contiguous()
         else:
             lo, n, lpad = 0, L, L
-        ws = self._workspace(lpad, dt, dev)
+        # Batch elements are extra ROWS of the token-major buffers ([B*n, D]): every GEMM / norm is one launch over
+        # both CFG branches (twice the tiles per launch, weights read once); attention and RoPE index rows per batch.
+        nr = b * n
+        ws = self._workspace(b * lpad, dt, dev)
+        if b == 1:
+            cos, sin = cos1, sin1
+        else:
+            key = ("rope_b", ppf, pph, ppw, b, str(dev))
+            if key not in self._rope_cache:
+                self._rope_cache[key] = (cos1.repeat(b, 1).contiguous(), sin1.repeat(b, 1).contiguous())
+            cos, sin = self._rope_cache[key]
 
         # ---- timestep rows + selector (F7) ----
         if timestep_rows is not None:
             t_rows, sel = timestep_rows
+            if sel is not None and sh is not None:
+                sel = sel[lo:lo + n].contiguous()
+            if sel is not None and b > 1:
+                sel = sel.repeat(b)
         elif timestep.ndim == 2:
-            t_rows, inv = torch.unique(timestep[0], return_inverse=True)
+            t_rows, inv = torch.unique(timestep.reshape(-1), return_inverse=True)
             sel = inv.to(torch.int32).contiguous()
+            if sh is not None:
+                sel = sel[lo:lo + n].contiguous()
         else:
-            t_rows, sel = timestep.reshape(1), None
-        if sel is not None and sh is not None:
-            sel = sel[lo:lo + n].contiguous()
+            t_rows = timestep.reshape(-1)
+            sel = None if b == 1 else torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(n)
+            if t_rows.numel() == 1 and b > 1:
+                sel = None
         temb, tproj = self._time_rows(t_rows.to(dev), encoder_hidden_states.dtype)       # [R,D], [R,6,D]
         # per-layer modulation tables: scale_shift_table + temb.float()  (:317-319)  -> [R, layers, 6, D] fp32
         mod = (pk.sst[None] + tproj.float()[:, None]).contiguous()
         head = (self.scale_shift_table.float() + temb.float()[:, None]).contiguous()     # [R, 2, D]  (:522/:527)
 
         text = self._text_kv(encoder_hidden_states, pk)
+        lt = encoder_hidden_states.shape[1]
 
         # ---- patch embedding (:486-487): gather + GEMM (the gather is 9 MB; every rank builds it, keeps its rows) ----
-        a_full = o.patchify(hidden_states[0], cfg.patch_size)
-        x = o.gemm(a_full[lo:lo + n], pk.w_patch, self.patch_embedding.bias, out=ws.x[:n])
-        nrm, att, q2, ff = ws.n[:n], ws.att[:n], ws.q2[:n], ws.ff[:n]
+        if b == 1:
+            a_rows = o.patchify(hidden_states[0], cfg.patch_size)[lo:lo + n]
+        else:
+            a_rows = torch.cat([o.patchify(hidden_states[i], cfg.patch_size) for i in range(b)])
+        x = o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=ws.x[:nr])
+        nrm, att, q2, ff = ws.n[:nr], ws.att[:nr], ws.q2[:nr], ws.ff[:nr]
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
@@ -338,16 +355,16 @@ class WanTransformer3DModel(nn.Module):
             if not pk.default_procs:
                 if sh is not None:
                     raise NotImplementedError("token-sharded execution needs the built-in MI355WanAttnProcessor")
-                rot = _CompactRope((cos, sin))
-                a = blk.attn1(nrm.view(1, n, d), rotary_emb=rot, **(attention_kwargs or {}))
-                o.gated_residual(x, a.reshape(n, d), m[:, 2], sel, out=x)
+                rot = _CompactRope((cos1, sin1))
+                a = blk.attn1(nrm.view(b, n, d), rotary_emb=rot, **(attention_kwargs or {}))
+                o.gated_residual(x, a.reshape(nr, d), m[:, 2], sel, out=x)
             elif sh is None:
-                qkv = ws.qkv[:n]
+                qkv = ws.qkv[:nr]
                 o.gemm(nrm, e.wqkv, e.bqkv, out=qkv)
                 o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
                 o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
-                q3 = qkv.view(1, n, 3 * d)
-                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(1, n, d))
+                q3 = qkv.view(b, n, 3 * d)
+                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d))
             else:
                 # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
@@ -372,12 +389,13 @@ class WanTransformer3DModel(nn.Module):
             if pk.default_procs:
                 o.gemm(nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=q2)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
-                kv = text.kv[li].view(1, -1, 2 * d)
-                o.attention(q2.view(1, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(1, n, d))
+                kv = text.kv[li].view(b, lt, 2 * d)
+                o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
                 o.gemm(att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=x, out=x)
             else:
-                a = blk.attn2(nrm.view(1, n, d), encoder_hidden_states=text.txt[None], **(attention_kwargs or {}))
-                o.gated_residual(x, a.reshape(n, d), out=x)
+                a = blk.attn2(nrm.view(b, n, d), encoder_hidden_states=text.txt.view(b, lt, d),
+                              **(attention_kwargs or {}))
+                o.gated_residual(x, a.reshape(nr, d), out=x)
             # 3. feed-forward (:344-348)
             o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
             o.gemm(nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
@@ -387,12 +405,16 @@ class WanTransformer3DModel(nn.Module):
         # ---- output head (:519-543) ----
         o.adaln_modulate(x, head[:, 0], head[:, 1], sel, cfg.eps, out=nrm)
         if sh is None:
-            po = o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=ws.po[:n])
+            po = o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=ws.po[:nr])
         else:
             po_loc = sh.out_local(lpad, ws.po.shape[1], dt, dev)
             o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=po_loc[:n])
             po = sh.all_gather_out(po_loc)[:L]
-        out = o.unpatchify(po, cfg.out_channels, nf, hh, ww, cfg.patch_size)[None]
+        if b == 1:
+            out = o.unpatchify(po, cfg.out_channels, nf, hh, ww, cfg.patch_size)[None]
+        else:
+            po3 = po.view(b, L, -1)
+            out = torch.stack([o.unpatchify(po3[i], cfg.out_channels, nf, hh, ww, cfg.patch_size) for i in range(b)])
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
