@@ -18,6 +18,16 @@
 //     that head's K/V while its 32 CUs sweep it.
 #include "fino_common.h"
 
+#ifdef FINO_ATTN_STAMP
+__device__ unsigned long long fino_attn_dbg[64];
+extern "C" int fino_attn_debug_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_attn_dbg), sizeof(unsigned long long) * 64);
+}
+#define ASTAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ASTAMP(V_)
+#endif
+
 namespace {
 
 struct AttnParams {
@@ -33,7 +43,10 @@ struct AttnParams {
 };
 
 constexpr int kQRowsPerWave = 32;
-constexpr int kWaves = 8;
+#ifndef FINO_ATTN_WAVES
+#define FINO_ATTN_WAVES 8
+#endif
+constexpr int kWaves = FINO_ATTN_WAVES;   // waves (32 query rows each) per workgroup
 constexpr int kQBlock = kQRowsPerWave * kWaves;  // 256
 constexpr int kKV = 64;
 constexpr float kRescaleThr = 8.0f;  // log2 units: P <= 256 between rescales
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
 #define TILE_BODY(HAS_NEXT_, LAST_)                                                                          \
     {                                                                                                        \
         const int cur = t & 1;                                                                               \
+        ASTAMP(ts0)                                                                                          \
         /* global -> registers: K(t+2), V(t+1) (clamped rows; dead data is never written to LDS) */          \
         if (HAS_NEXT_ && kDma) {                                                                             \
             DMA_TILE_OR_NOTHING(kp, p.k_rs, t + 2, cur)                                                      \
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             psum1 += sc1[j];                                                                                 \
         }                                                                                                    \
         l_run += psum0 + psum1;                                                                              \
+        ASTAMP(ts1)                                                                                          \
         /* matrix pipe: O^T += V(t)^T . P(t)^T   ||   VALU: bf16 packing, row max of S(t+1) */               \
         const char* vb = smem + (2 + cur) * kTileBytes;                                                      \
         _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                   \
@@ -298,6 +313,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
         if (HAS_NEXT_) {                                                                                     \
             float mxn;                                                                                       \
             ROW_MAX(sn0, sn1, mxn)                                                                           \
+            ASTAMP(ts2)                                                                                      \
             /* registers -> LDS: K(t+2) into the K slot S(t) came from, V(t+1) into the other V slot */      \
             if (!kDma && t + 2 < nt) {                                                                       \
                 _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
@@ -311,7 +327,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             sc0 = sn0;                                                                                       \
             sc1 = sn1;                                                                                       \
             MAYBE_RESCALE(mxn)                                                                               \
+            ASTAMP(ts3)                                                                                      \
             __syncthreads();                                                                                 \
+            ASTAMP(ts4)                                                                                      \
+            ASTAMP_ACC                                                                                       \
         }                                                                                                    \
     }
 
@@ -323,9 +342,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     constexpr bool kDma = false;
 #define DMA_TILE_OR_NOTHING(A_, B_, C_, D_)
 #endif
+#ifdef FINO_ATTN_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
+#define ASTAMP_ACC { sa0 += ts1 - ts0; sa1 += ts2 - ts1; sa2 += ts3 - ts2; sa3 += ts4 - ts3; }
+#else
+#define ASTAMP_ACC
+#endif
     int t = 0;
     for (; t < nt - 1; ++t) TILE_BODY(true, false)
     TILE_BODY(false, true)
+#ifdef FINO_ATTN_STAMP
+    if (blockIdx.x == 40 && lane == 0 && VAR == 0) {
+        fino_attn_dbg[wave * 8 + 0] = sa0; fino_attn_dbg[wave * 8 + 1] = sa1; fino_attn_dbg[wave * 8 + 2] = sa2;
+        fino_attn_dbg[wave * 8 + 3] = sa3; fino_attn_dbg[wave * 8 + 4] = (unsigned long long)(nt - 1);
+    }
+#endif
 #undef TILE_BODY
 #undef ROW_MAX
 #undef MAYBE_RESCALE

@@ -285,13 +285,20 @@ def test_layernorm_zero_staged_rounding(ops):
     """CogVideoXLayerNormZero executed in bf16: every tensor op rounds (cogvideox_transformer_3d.py:134-136)."""
     b, L, d = 2, 37, 3072
     x = rnd(b * L, d, seed=60)
-    w, bb = rnd(d, seed=61).float() * 0.1 + 1, rnd(d, seed=62).float() * 0.1
+    # affine parameters are T tensors in the reference: bf16-representable values, passed to the kernel as fp32 copies
+    w, bb = (rnd(d, seed=61).float() * 0.1 + 1).bfloat16().float(), (rnd(d, seed=62).float() * 0.1).bfloat16().float()
     tab = rnd(2 * b, 3, d, seed=63, scale=0.3).float()            # bf16-representable values
     sel = (torch.arange(b * L, device=DEV) % 4).to(torch.int32)
     y = ops.layernorm_zero(x, w, bb, tab[:, 0], tab[:, 1], sel, 1e-5)
     n = F.layer_norm(x, (d,), w.bfloat16(), bb.bfloat16(), 1e-5)
-    ref = n * (1 + tab[:, 1].bfloat16())[sel.long()] + tab[:, 0].bfloat16()[sel.long()]
-    ulp_close(y, ref, torch.bfloat16, max_ulp_frac=0.02)
+    sc, sh = (1 + tab[:, 1].bfloat16())[sel.long()], tab[:, 0].bfloat16()[sel.long()]
+    ref = n * sc + sh
+    # a 1-ulp flip of the normalised value (reduction order) propagates through the product; with cancellation in
+    # "+ shift" the bound is 2 ulp of the LARGER intermediate, not of the result
+    mag = (n.float() * sc.float()).abs() + sh.float().abs()
+    bad = (y.float() - ref.float()).abs() > 2 * 2.0 ** -8 * mag + 1e-6
+    assert bad.float().mean().item() < 0.01
+    assert rel_rms(y, ref) < 2.0 ** -7
 
 
 def test_gated_residual_staged_and_gemm_epilogue(ops):

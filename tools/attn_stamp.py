@@ -1,0 +1,17 @@
+"""Diagnostic (not a benchmark): per-segment s_memtime stamps of the attention tile loop (FINO_ATTN_STAMP build)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["FINO_LIB_PATH"] = os.path.join(ROOT, "frameino_amd/lib/libframeino_stamp.so")
+import torch
+from frameino_amd import ops
+L, D, H = 12320, 3072, 24
+qkv = torch.randn(1, L, 3 * D, device="cuda").bfloat16()
+for _ in range(3): ops.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 64)()
+lib = ctypes.CDLL(os.environ["FINO_LIB_PATH"]); lib.fino_attn_debug_read(buf)
+for wv in range(8):
+    v = [buf[wv * 8 + i] for i in range(5)]
+    nt = max(v[4], 1)
+    print(f"wave {wv}: per tile cycles: QK(t+1)||exp {v[0]/nt:6.0f}  PV||cvt,max {v[1]/nt:6.0f}  ds_write+rescale {v[2]/nt:6.0f}  barrier {v[3]/nt:6.0f}  total {sum(v[:4])/nt:6.0f}")
