@@ -37,6 +37,7 @@ SIGNATURES = {
     "fino_unpatchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
     "fino_wan_model_input": [c_void_p] * 5 + [c_int] * 6 + [c_void_p],
     "fino_cfg_euler_step": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_int, c_int, c_void_p],
+    "fino_cfg_unipc_step": [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_int, c_void_p],
     "fino_cfg_vpred_step": [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_void_p],
     "fino_conv3d": [c_void_p] * 4 + [c_int] * 19 + [c_void_p, c_void_p, c_int, c_void_p],
     "fino_rmsnorm_silu_cl": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],

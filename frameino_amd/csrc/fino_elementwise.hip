@@ -383,6 +383,43 @@ __global__ __launch_bounds__(256) void cfg_vpred_step_kernel(const uint16_t* __r
     }
 }
 
+// UniPC (bh2, predict-x0, flow sigmas) multistep update fused with CFG, one pass over the latents
+// (diffusers UniPCMultistepScheduler.step as Wan2.2-TI2V-5B-Diffusers configures it; pipeline :882-891).
+// Every tensor op of the published algorithm is linear in {x, last_sample, m0, m1, v}; the host folds the step's
+// scalars into coef = {g, sigma, use_corr, Cx, C0, C1, Ct, Px, P0, P1}:
+//   v   = T(u + T(g*T(c-u)));  m_t = x - T(sigma*v)                         (convert_model_output, flow prediction)
+//   x_c = use_corr ? Cx*last + C0*m0 + C1*m1 + Ct*m_t : x                    (multistep_uni_c_bh_update)
+//   x'  = Px*x_c + P0*m_t + P1*m0                                            (multistep_uni_p_bh_update)
+//   last <- x_c;  m1 <- m0;  m0 <- m_t;  x <- x'
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_unipc_kernel(const uint16_t* __restrict__ pc, const uint16_t* __restrict__ pu,
+                                                        float* __restrict__ x, float* __restrict__ last,
+                                                        float* __restrict__ m0, float* __restrict__ m1, int C, int Fg,
+                                                        int Ft, int HW, const float* __restrict__ coef) {
+    const float g = coef[0], sigma = coef[1], use_corr = coef[2];
+    const float Cx = coef[3], C0 = coef[4], C1 = coef[5], Ct = coef[6], Px = coef[7], P0 = coef[8], P1 = coef[9];
+    const int64_t total = (int64_t)C * Fg * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % HW);
+        const int f = (int)((i / HW) % Fg);
+        const int c = (int)(i / ((int64_t)HW * Fg));
+        const int64_t pi = ((int64_t)c * Ft + f) * HW + s;
+        float v = T::to_f32(pc[pi]);
+        if (pu) {
+            const float u = T::to_f32(pu[pi]);
+            v = round_to<T>(u + round_to<T>(g * round_to<T>(v - u)));
+        }
+        const float xv = x[i], a0 = m0[i];
+        const float mt = xv - round_to<T>(sigma * v);
+        const float xc = use_corr != 0.f ? Cx * last[i] + C0 * a0 + C1 * m1[i] + Ct * mt : xv;
+        x[i] = Px * xc + P0 * mt + P1 * a0;
+        last[i] = xc;
+        m1[i] = a0;
+        m0[i] = mt;
+    }
+}
+
 template <int NPmax, typename F>
 inline bool dispatch_np(int dim, F&& f) {
     const int np = (dim + 511) / 512;
@@ -617,6 +654,27 @@ extern "C" int fino_cfg_vpred_step(const void* pred, void* lat, int64_t n_lat, i
     else
         cfg_vpred_step_kernel<F16><<<grid_1d(n_lat), 256, 0, st>>>((const uint16_t*)pred, (uint16_t*)lat, n_lat,
                                                                   batch_stride, coef_dev, has_uncond);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_cfg_unipc_step(const void* cond_pred, const void* uncond_pred, float* x, float* last, float* m0,
+                                   float* m1, int channels, int gen_frames, int total_frames, int height, int width,
+                                   const float* coef_dev, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_cfg_unipc_step: dtype %d", dtype);
+    FINO_CHECK(cond_pred && x && last && m0 && m1 && coef_dev, FINO_ERR_ARG, "fino_cfg_unipc_step: null pointer");
+    FINO_CHECK(channels > 0 && gen_frames > 0 && total_frames >= gen_frames && height > 0 && width > 0, FINO_ERR_ARG,
+               "fino_cfg_unipc_step: bad shape");
+    const int64_t total = (int64_t)channels * gen_frames * height * width;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        cfg_unipc_kernel<BF16><<<grid_1d(total), 256, 0, st>>>((const uint16_t*)cond_pred, (const uint16_t*)uncond_pred,
+                                                               x, last, m0, m1, channels, gen_frames, total_frames,
+                                                               height * width, coef_dev);
+    else
+        cfg_unipc_kernel<F16><<<grid_1d(total), 256, 0, st>>>((const uint16_t*)cond_pred, (const uint16_t*)uncond_pred,
+                                                              x, last, m0, m1, channels, gen_frames, total_frames,
+                                                              height * width, coef_dev);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

@@ -263,6 +263,18 @@ def cfg_euler_step_(lat, cond_pred, uncond_pred, guidance, dt_dev, round_out=Tru
     return lat
 
 
+def cfg_unipc_step_(x, last, m0, m1, cond_pred, uncond_pred, coef_dev):
+    """UniPC multistep update fused with CFG; x/last/m0/m1 fp32 [C,Fg,H,W] in place, coef_dev fp32[10] (device)."""
+    c, fg, h, w = x.shape
+    ft = cond_pred.shape[1]
+    for t in (x, last, m0, m1):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == x.shape
+    assert coef_dev.dtype == torch.float32 and coef_dev.numel() >= 10 and cond_pred.is_contiguous()
+    _lib.check(_lib.lib().fino_cfg_unipc_step(_p(cond_pred), _p(uncond_pred), _p(x), _p(last), _p(m0), _p(m1), c, fg,
+                                             ft, h, w, _p(coef_dev), _dt(cond_pred), _stream()), "fino_cfg_unipc_step")
+    return x
+
+
 def cfg_vpred_step_(lat, pred, coef_dev, has_uncond=True):
     """lat [Fg, C, H, W] of T in place; pred [2|1, Ft, C, H, W] of T; coef_dev fp32[5] = {sa, sb, ca, cb, g}."""
     assert lat.is_contiguous() and pred.is_contiguous() and coef_dev.dtype == torch.float32 and lat.dtype == pred.dtype

@@ -273,8 +273,12 @@ class WanImageToVideoPipeline:
         else:
             pc = fwd("cond", st.pe)
             pu = fwd("uncond", st.ne) if st.cfg else None
-        o.cfg_euler_step_(st.lat, pc, pu, st.guidance, st.dt,
-                          round_out=getattr(self.scheduler, "cast_output_to_model_dtype", True))
+        if st.unipc is not None:
+            # the sampler the released Wan2.2 folder ships: corrector + predictor + CFG in one pass
+            o.cfg_unipc_step_(st.lat, *st.unipc, pc, pu, st.coef)
+        else:
+            o.cfg_euler_step_(st.lat, pc, pu, st.guidance, st.dt,
+                              round_out=getattr(self.scheduler, "cast_output_to_model_dtype", True))
 
     def make_state(self, latents, condition, traj_latents, id_latent, first_frame_mask, prompt_embeds,
                    negative_prompt_embeds, guidance_scale, attention_kwargs=None):
@@ -298,6 +302,11 @@ class WanImageToVideoPipeline:
         st.sel = sel
         st.t_rows = torch.zeros(2, dtype=torch.float32, device=dev)
         st.dt = torch.zeros(1, dtype=torch.float32, device=dev)
+        # UniPC multistep history (last corrected sample, two x0 predictions) + this step's coefficient row
+        st.unipc = None
+        if getattr(self.scheduler, "kind", "euler") == "unipc":
+            st.unipc = tuple(torch.zeros_like(st.lat) for _ in range(3))
+            st.coef = torch.zeros(10, dtype=torch.float32, device=dev)
         st.pe = prompt_embeds.to(tr.dtype)
         st.ne = None if negative_prompt_embeds is None else negative_prompt_embeds.to(tr.dtype)
         st.cfg = guidance_scale > 1 and st.ne is not None
@@ -316,7 +325,11 @@ class WanImageToVideoPipeline:
         timesteps = self.scheduler.timesteps
         st = self.make_state(latents, condition, traj_latents, id_latent, first_frame_mask, prompt_embeds,
                              negative_prompt_embeds, guidance_scale, attention_kwargs)
-        dts = self.scheduler.dts.to(dev)
+        if st.unipc is not None:
+            coefs = self.scheduler.coefs.to(dev).clone()
+            coefs[:, 0] = st.guidance
+        else:
+            dts = self.scheduler.dts.to(dev)
         ts_dev = timesteps.to(dev).float()
         self._num_timesteps = len(timesteps)
 
@@ -326,13 +339,18 @@ class WanImageToVideoPipeline:
                 continue
             self._current_timestep = timesteps[i]
             st.t_rows[1:2].copy_(ts_dev[i:i + 1])          # device-to-device: no host sync
-            st.dt.copy_(dts[i:i + 1])
+            if st.unipc is not None:
+                st.coef.copy_(coefs[i])
+            else:
+                st.dt.copy_(dts[i:i + 1])
             if self.use_hip_graph and callback_on_step_end is None:
                 if graph is None:
                     # eager warm-up step fills every lazy cache (text K/V, workspaces, kernel attributes)
-                    snap = st.lat.clone()
+                    keep = [st.lat] + list(st.unipc or ())
+                    snap = [b.clone() for b in keep]
                     self._step(st)
-                    st.lat.copy_(snap)
+                    for b, sv in zip(keep, snap):
+                        b.copy_(sv)
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         self._step(st)

@@ -105,3 +105,93 @@ class CogVideoXDDIMScheduler:
             cb = a_p ** 0.5 - a_t ** 0.5 * ca
             rows.append([float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(ca), float(cb)])
         self.coefs = torch.tensor(rows, dtype=torch.float32, device=device)
+
+
+class UniPCMultistepScheduler:
+    """diffusers' UniPCMultistepScheduler as Wan-AI/Wan2.2-TI2V-5B-Diffusers configures it (third-party, restated from
+    the published algorithm -- parity unpinned): prediction_type="flow_prediction", use_flow_sigmas, flow_shift,
+    solver_order=2, solver_type="bh2", predict_x0, lower_order_final, final_sigmas_type="zero".
+
+    Every tensor operation of its step is linear in {sample, last_sample, model_outputs[-1], model_outputs[-2], v}, so
+    `set_timesteps` folds each step's scalars into a coefficient row (fp64 on the host, one device table) and the
+    update runs as ONE kernel, fused with CFG (fino_cfg_unipc_step)."""
+    order = 1
+    kind = "unipc"
+
+    def __init__(self, num_train_timesteps=1000, solver_order=2, prediction_type="flow_prediction", flow_shift=5.0,
+                 use_flow_sigmas=True, solver_type="bh2", predict_x0=True, lower_order_final=True,
+                 final_sigmas_type="zero", **unused):
+        if not (use_flow_sigmas and prediction_type == "flow_prediction" and predict_x0 and solver_type == "bh2"
+                and solver_order in (1, 2) and final_sigmas_type == "zero"):
+            raise NotImplementedError("only the Wan2.2 configuration of UniPC is implemented")
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, solver_order=solver_order, flow_shift=flow_shift,
+                           prediction_type=prediction_type, solver_type=solver_type)
+
+    def set_timesteps(self, num_inference_steps, device=None, **unused):
+        n_train, shift, order_max = self.config.num_train_timesteps, self.config.flow_shift, self.config.solver_order
+        alphas = np.linspace(1, 1 / n_train, num_inference_steps + 1)
+        sig = 1.0 - alphas
+        sig = np.flip(shift * sig / (1 + (shift - 1) * sig))[:-1].copy()
+        self.timesteps = torch.from_numpy((sig * n_train).copy()).to(device=device, dtype=torch.int64)
+        sig = np.concatenate([sig, [0.0]]).astype(np.float32).astype(np.float64)      # diffusers stores fp32 sigmas
+        self.sigmas = torch.from_numpy(sig.astype(np.float32)).to(device)
+        self.num_inference_steps = n = num_inference_steps
+
+        lam = lambda s: np.log(1.0 - s) - np.log(s) if s > 0 else np.inf               # noqa: E731
+
+        def bh(h, order, rk):
+            """b-vector / R-matrix pieces of the bh2 update for step size h (predict_x0: hh = -h)."""
+            hh = -h
+            h_phi_1 = np.expm1(hh)
+            b_h = np.expm1(hh)
+            h_phi_k = h_phi_1 / hh - 1.0 if np.isfinite(hh) else -1.0
+            b, fact = [], 1.0
+            for i in range(1, order + 1):
+                b.append(h_phi_k * fact / b_h)
+                fact *= i + 1
+                h_phi_k = h_phi_k / hh - 1.0 / fact if np.isfinite(hh) else -1.0 / fact
+            return h_phi_1, b_h, np.array(b)
+
+        rows, lower_order_nums, prev_order = [], 0, 0
+        for i in range(n):
+            s_i, s_n = sig[i], sig[i + 1]
+            # ---- corrector (uses the order chosen at the previous step) ----
+            use_corr, cx, c0, c1, ct = 0.0, 0.0, 0.0, 0.0, 0.0
+            if i > 0:
+                use_corr = 1.0
+                s_p = sig[i - 1]
+                h = lam(s_i) - lam(s_p)
+                a_t = 1.0 - s_i
+                if prev_order == 1:
+                    h_phi_1, b_h, _ = bh(h, 1, None)
+                    rho_t = 0.5
+                    cx, c0, c1, ct = s_i / s_p, -a_t * h_phi_1 + a_t * b_h * rho_t, 0.0, -a_t * b_h * rho_t
+                else:
+                    rk = (lam(sig[i - 2]) - lam(s_p)) / h
+                    h_phi_1, b_h, b = bh(h, 2, rk)
+                    rho = np.linalg.solve(np.array([[1.0, 1.0], [rk, 1.0]]), b)
+                    # x_t = s_i/s_p x - a_t h_phi_1 m0 - a_t B_h (rho0 (m1 - m0)/rk + rho1 (m_t - m0))
+                    cx = s_i / s_p
+                    c0 = -a_t * h_phi_1 + a_t * b_h * (rho[0] / rk + rho[1])
+                    c1 = -a_t * b_h * rho[0] / rk
+                    ct = -a_t * b_h * rho[1]
+            # ---- predictor ----
+            this_order = min(order_max, n - i)                        # lower_order_final
+            this_order = min(this_order, lower_order_nums + 1)
+            a_n = 1.0 - s_n
+            if s_n > 0:
+                h = lam(s_n) - lam(s_i)
+                h_phi_1, b_h = np.expm1(-h), np.expm1(-h)
+            else:
+                h_phi_1, b_h = -1.0, -1.0                             # h = +inf at the final (sigma = 0) step
+            px, p0, p1 = s_n / s_i, -a_n * h_phi_1, 0.0
+            if this_order == 2:
+                rk = (lam(sig[i - 1]) - lam(s_i)) / h
+                # x_t = x_t_ - a_n B_h * 0.5 * (m_{i-1} - m_i)/rk
+                p0 += a_n * b_h * 0.5 / rk
+                p1 = -a_n * b_h * 0.5 / rk
+            if lower_order_nums < order_max:
+                lower_order_nums += 1
+            prev_order = this_order
+            rows.append([0.0, s_i, use_corr, cx, c0, c1, ct, px, p0, p1])
+        self.coefs = torch.tensor(rows, dtype=torch.float32, device=device)       # column 0 (guidance) set by the caller

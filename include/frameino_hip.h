@@ -140,6 +140,15 @@ int fino_cfg_euler_step(const void* cond_pred, const void* uncond_pred, float* l
                         int total_frames, int height, int width, float guidance, const float* dt_dev, int round_out,
                         int dtype, void* stream);
 
+/* CFG + UniPC (bh2, predict-x0, flow sigmas, order <= 2) multistep update -- the sampler Wan2.2-TI2V-5B-Diffusers ships
+ * (diffusers UniPCMultistepScheduler, third-party; call site pipeline_wan_i2v_motion_FrameINO.py:891).  The step is
+ * linear in {x, last_sample, m0, m1, v}; coef_dev = {g, sigma, use_corr, Cx, C0, C1, Ct, Px, P0, P1} (device, computed
+ * on the host from the sigma schedule):  v = CFG;  m_t = x - T(sigma*v);  x_c = use_corr ? Cx*last+C0*m0+C1*m1+Ct*m_t : x;
+ * x' = Px*x_c + P0*m_t + P1*m0;  then last<-x_c, m1<-m0, m0<-m_t, x<-x'.  x/last/m0/m1 fp32 [C,Fg,H,W] in place. */
+int fino_cfg_unipc_step(const void* cond_pred, const void* uncond_pred, float* x, float* last, float* m0, float* m1,
+                        int channels, int gen_frames, int total_frames, int height, int width, const float* coef_dev,
+                        int dtype, void* stream);
+
 /* CogVideoX sampler step (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:893-927, v-prediction DDIM):
  *   v = u + g*(c-u) in fp32;  x0 = T(sa*x) - sb*v;  x' = T(T(ca*x) + cb*x0);  coef_dev = {sa, sb, ca, cb, g} (device).
  * pred [2, batch_stride] of T (uncond, cond; the first n_lat elements of each are the generated frames -- ID frames

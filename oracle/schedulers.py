@@ -38,3 +38,98 @@ class FlowMatchEulerOracle:
         prev = sample.to(torch.float32) + (sn - s) * model_output
         self.step_index += 1
         return prev.to(model_output.dtype)     # diffusers casts back to the model-output dtype
+
+
+class UniPCOracle:
+    """Direct (tensor-op by tensor-op) restatement of diffusers' UniPCMultistepScheduler.step for the Wan2.2
+    configuration (flow sigmas, flow_prediction, predict_x0, bh2, solver_order 2, lower_order_final, final sigma 0).
+    Third-party, from the published algorithm: unpinned.  Used to cross-check the coefficient-folded kernel form."""
+
+    def __init__(self, num_train_timesteps=1000, flow_shift=5.0, solver_order=2):
+        self.n_train, self.shift, self.order_max = num_train_timesteps, flow_shift, solver_order
+
+    def set_timesteps(self, n):
+        alphas = np.linspace(1, 1 / self.n_train, n + 1)
+        sig = 1.0 - alphas
+        sig = np.flip(self.shift * sig / (1 + (self.shift - 1) * sig))[:-1].copy()
+        self.timesteps = torch.from_numpy((sig * self.n_train).copy()).to(torch.int64)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.n = n
+        self.model_outputs = [None] * self.order_max
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self.step_index = 0
+        self.this_order = 0
+
+    @staticmethod
+    def _als(sigma):
+        return 1 - sigma, sigma
+
+    def _lam(self, sigma):
+        a, s = self._als(sigma)
+        return torch.log(a) - torch.log(s)
+
+    def _rb(self, rks, hh, order):
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        b_h = torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / b_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return h_phi_1, b_h, torch.stack(R), torch.stack(b)
+
+    def _predict(self, sample, order):
+        m0, x = self.model_outputs[-1], sample
+        st, s0 = self.sigmas[self.step_index + 1], self.sigmas[self.step_index]
+        at, _ = self._als(st)
+        h = self._lam(st) - self._lam(s0)
+        rks, d1s = [], []
+        for i in range(1, order):
+            mi = self.model_outputs[-(i + 1)]
+            rk = (self._lam(self.sigmas[self.step_index - i]) - self._lam(s0)) / h
+            rks.append(rk)
+            d1s.append((mi - m0) / rk)
+        rks.append(torch.tensor(1.0))
+        hh = -h
+        h_phi_1, b_h = torch.expm1(hh), torch.expm1(hh)
+        x_t_ = st / s0 * x - at * h_phi_1 * m0
+        pred = 0.5 * d1s[0] if d1s else 0           # order 2: rhos_p = [0.5]
+        return x_t_ - at * b_h * pred
+
+    def _correct(self, model_t, last_sample, order):
+        m0, x = self.model_outputs[-1], last_sample
+        st, s0 = self.sigmas[self.step_index], self.sigmas[self.step_index - 1]
+        at, _ = self._als(st)
+        h = self._lam(st) - self._lam(s0)
+        rks, d1s = [], []
+        for i in range(1, order):
+            mi = self.model_outputs[-(i + 1)]
+            rk = (self._lam(self.sigmas[self.step_index - (i + 1)]) - self._lam(s0)) / h
+            rks.append(rk)
+            d1s.append((mi - m0) / rk)
+        rks.append(torch.tensor(1.0))
+        rks = torch.stack(rks)
+        hh = -h
+        h_phi_1, b_h, R, b = self._rb(rks, hh, order)
+        rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+        x_t_ = st / s0 * x - at * h_phi_1 * m0
+        corr = sum(rhos[k] * d1s[k] for k in range(len(d1s))) if d1s else 0
+        return x_t_ - at * b_h * (corr + rhos[-1] * (model_t - m0))
+
+    def step(self, model_output, sample):
+        use_corr = self.step_index > 0 and self.last_sample is not None
+        m_t = sample - self.sigmas[self.step_index] * model_output        # flow prediction -> x0 (sigma*v in the v dtype)
+        if use_corr:
+            sample = self._correct(m_t, self.last_sample, self.this_order)
+        self.model_outputs = self.model_outputs[1:] + [m_t]
+        this_order = min(self.order_max, self.n - self.step_index)
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        prev = self._predict(sample, self.this_order)
+        if self.lower_order_nums < self.order_max:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev

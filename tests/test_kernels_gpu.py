@@ -329,3 +329,30 @@ def test_cfg_vpred_step(ops):
     x0 = (coef[0] * lat.float()).bfloat16().float() - coef[1] * v
     ref = ((coef[2] * lat.float()).bfloat16().float() + coef[3] * x0).bfloat16()
     assert torch.equal(lat2, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("has_uncond", [True, False])
+def test_cfg_unipc_step(dtype, has_uncond):
+    """fino_cfg_unipc_step: the coefficient-folded corrector+predictor on a [C, Fg(+ID), H, W] prediction."""
+    from frameino_amd import ops
+    g = torch.Generator().manual_seed(5)
+    c, fg, ft, h, w = 4, 3, 4, 6, 10
+    pc = torch.randn(c, ft, h, w, generator=g).to(dtype)
+    pu = torch.randn(c, ft, h, w, generator=g).to(dtype) if has_uncond else None
+    x, last, m0, m1 = (torch.randn(c, fg, h, w, generator=g) for _ in range(4))
+    for use_corr in (0.0, 1.0):
+        coef = torch.tensor([5.0, 0.83, use_corr, 0.9, 0.31, -0.07, 0.12, 0.8, 0.25, -0.05])
+        v = pc[:, :fg]
+        if has_uncond:
+            u = pu[:, :fg]
+            v = u + 5.0 * (v - u)                               # every op rounds to the model dtype (:882)
+        mt = x - (coef[1] * v).float()                          # 0-dim fp32 sigma x T tensor -> T, then fp32 subtract
+        xc = coef[3] * last + coef[4] * m0 + coef[5] * m1 + coef[6] * mt if use_corr else x
+        xn = coef[7] * xc + coef[8] * mt + coef[9] * m0
+        bx, bl, b0, b1 = (t.clone().to(DEV) for t in (x, last, m0, m1))
+        ops.cfg_unipc_step_(bx, bl, b0, b1, pc.to(DEV), None if pu is None else pu.to(DEV), coef.to(DEV))
+        torch.testing.assert_close(b0.cpu(), mt, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(b1.cpu(), m0, atol=0, rtol=0)
+        torch.testing.assert_close(bl.cpu(), xc, atol=2e-6, rtol=2e-6)
+        torch.testing.assert_close(bx.cpu(), xn, atol=2e-6, rtol=2e-6)

@@ -107,3 +107,37 @@ def test_check_inputs_errors_match_reference_messages(golden):
         pipe.check_inputs(None, None, torch.zeros(1, 3, 8, 8), 100, 96, a["prompt_embeds"], None)
     with pytest.raises(ValueError, match="Provide either `prompt` or `prompt_embeds`"):
         pipe.check_inputs(None, None, torch.zeros(1, 3, 8, 8), 64, 96, None, None)
+
+
+# ---- UniPC (the sampler the released Wan2.2 folder ships; third-party algorithm, oracle = UniPCOracle) ----
+def _unipc_pipe(golden):
+    from frameino_amd.schedulers import UniPCMultistepScheduler
+    pipe, a = _pipe(golden)
+    pipe.scheduler = UniPCMultistepScheduler(flow_shift=5.0)
+    return pipe, a
+
+
+def test_unipc_loop_vs_oracle_loop(golden):
+    from oracle.schedulers import UniPCOracle
+    from oracle.wan_pipeline import wan_denoise_loop
+    pipe, a = _unipc_pipe(golden)
+    steps = 6                                     # order-1 start, order-2 middle, order-1 final, corrector throughout
+    d = lambda k: a[k].to(DEV)                    # noqa: E731
+    out = pipe.denoise(d("latents0"), d("condition"), d("traj_latents"), d("id_latent"), d("mask"),
+                       d("prompt_embeds"), d("negative_embeds"), float(a["guidance"]), steps)
+    cfg, sd, _ = golden("wan_pipe_tiny")
+    dit_sd = {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}
+    ref = wan_denoise_loop(dit_sd, cfg, UniPCOracle(flow_shift=5.0), a["latents0"], a["condition"], a["traj_latents"],
+                           a["id_latent"], a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]),
+                           steps)
+    r = rel_rms(out, ref)
+    assert r < 5e-2, r
+    assert torch.equal(out[:, :, 0].cpu(), a["condition"][:, :, 0])
+
+
+def test_unipc_hip_graph_replay_equals_eager(golden):
+    pipe, a = _unipc_pipe(golden)
+    eager = _run(pipe, a)
+    pipe.use_hip_graph = True
+    graphed = _run(pipe, a)
+    assert torch.equal(eager, graphed)
