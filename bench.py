@@ -249,12 +249,14 @@ def main():
         ks = timer.summary().get("attn_self") if not a.graph else None
         heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
         if ks:
+            traffic, traffic_src = profiled_traffic("attn_fwd_kernel<BF16, 128, 0>")
             # algorithmic FLOPs of the timed launches (4.Lq.Lk.H.Dh per batch element) / their summed duration
             total_fl = timer.flops["attn_self"]
             ach = total_fl / (ks["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<BF16,128,0> (3D self-attention)",
                                "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                               "traffic": None, "launches": ks["launches"], "avg_us": ks["avg_us"],
+                               "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                               "launches": ks["launches"], "avg_us": ks["avg_us"],
                                "flops_per_launch": total_fl / ks["launches"],
                                "batch_per_launch": 2 if (pipe.batch_cfg and world == 1) else 1}
         if world == 1 and not a.no_cpu_baseline:
@@ -262,6 +264,24 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def profiled_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of this same command
+    (tools/profile_bench.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; counters are in KiB and
+    gfx950's FETCH_SIZE under-counts by 2x -- MI355X_MICROARCH.md, HBM section).  PMC passes cannot run inside the
+    timed bench, so this is the last profiled value, or None when no summary is in the tree."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            pmc = json.load(open(f)).get("pmc_avg_per_dispatch", {})
+        except (OSError, ValueError):
+            continue
+        for name, c in pmc.items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "profiles/" + os.path.basename(f)
+    return None, None
 
 
 if __name__ == "__main__":

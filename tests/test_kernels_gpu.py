@@ -347,7 +347,8 @@ def test_cfg_unipc_step(dtype, has_uncond):
         if has_uncond:
             u = pu[:, :fg]
             v = u + 5.0 * (v - u)                               # every op rounds to the model dtype (:882)
-        mt = x - (coef[1] * v).float()                          # 0-dim fp32 sigma x T tensor -> T, then fp32 subtract
+        # GPU semantics of `sigma_t * model_output` (CPU 0-dim fp32 sigma x device T tensor): fp32 multiply, round to T
+        mt = x - (coef[1].item() * v.float()).to(dtype).float()
         xc = coef[3] * last + coef[4] * m0 + coef[5] * m1 + coef[6] * mt if use_corr else x
         xn = coef[7] * xc + coef[8] * mt + coef[9] * m0
         bx, bl, b0, b1 = (t.clone().to(DEV) for t in (x, last, m0, m1))
