@@ -28,6 +28,11 @@ extern "C" int fino_attn_debug_read(unsigned long long* out) {
 #define ASTAMP(V_)
 #endif
 
+#ifndef FINO_ATTN_WAVES
+#define FINO_ATTN_WAVES 8
+#endif
+#define FINO_ATTN_WAVES_DEFAULT FINO_ATTN_WAVES
+
 namespace {
 
 struct AttnParams {
@@ -40,12 +45,17 @@ struct AttnParams {
     int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
     float scale_log2;
     int nqb;  // q blocks per head
+    // tail split (see plan_split): per XCD the first `full_x` blocks run whole; the key tiles of the remaining `rem_x`
+    // blocks form one stream that `nwg` workgroups cut into ranges of `per` tiles, leaving (O, m, l) partials in `ws`.
+    int full_x, rem_x, nwg, per;
+    float* ws;
 };
 
+// floats per partial: O^T accumulators in thread order + per-thread m and l
+template <int D>
+constexpr int64_t partial_floats() { return (int64_t)(D / 32) * 16 * (FINO_ATTN_WAVES_DEFAULT * 64) + 2 * (FINO_ATTN_WAVES_DEFAULT * 64); }
+
 constexpr int kQRowsPerWave = 32;
-#ifndef FINO_ATTN_WAVES
-#define FINO_ATTN_WAVES 8
-#endif
 constexpr int kWaves = FINO_ATTN_WAVES;   // waves (32 query rows each) per workgroup
 constexpr int kQBlock = kQRowsPerWave * kWaves;  // 256
 constexpr int kKV = 64;
@@ -85,16 +95,40 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     const int id = blockIdx.x;
     const int xcd = id & 7;
     const int slot = id >> 3;
-    const int hb = xcd + 8 * (slot / p.nqb);
-    const int qb = slot % p.nqb;
-    if (hb >= p.batch * p.heads) return;
+    // whole blocks first; then the XCD's last `rem_x` blocks as one stream of rem_x*nt key tiles cut into `nwg` equal
+    // ranges (tail split): a range covers pieces of at most two blocks (per < nt).
+    const int ntall = (p.lk + kKV - 1) / kKV;
+    int npieces = 1, first_b = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (slot >= p.full_x) {
+        g0 = (int64_t)(slot - p.full_x) * p.per;
+        g1 = g0 + p.per < (int64_t)p.rem_x * ntall ? g0 + p.per : (int64_t)p.rem_x * ntall;
+        first_b = (int)(g0 / ntall);
+        npieces = (int)((g1 - 1) / ntall) - first_b + 1;
+    }
+  for (int piece = 0; piece < npieces; ++piece) {
+    if (piece > 0) __syncthreads();                 // every wave is done reading the previous piece's LDS tiles
+    int bx = slot, part = -1, t_begin = 0, t_end = ntall;
+    if (slot >= p.full_x) {
+        const int tb = first_b + piece;
+        const int64_t b0 = (int64_t)tb * ntall;
+        t_begin = g0 > b0 ? (int)(g0 - b0) : 0;
+        t_end = g1 - b0 < ntall ? (int)(g1 - b0) : ntall;
+        bx = p.full_x + tb;
+        if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
+    }
+    const int hb = xcd + 8 * (bx / p.nqb);
+    const int qb = bx % p.nqb;
+    if (hb >= p.batch * p.heads) continue;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
 
     const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
-    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs;
-    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs + (int64_t)t_begin * kKV * p.k_rs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs + (int64_t)t_begin * kKV * p.v_rs;
     uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    // keys of this workgroup's range, re-based to 0 (a multiple of kKV precedes it, so tail masks are unchanged)
+    const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
     const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
@@ -134,7 +168,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
 #define DMA_TILE(BASE_PTR_, ROW_STRIDE_, T_, SLOT_)                                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                              \
         int row_ = (T_) * kKV + dma_row[i_];                                                                      \
-        row_ = row_ < p.lk ? row_ : p.lk - 1;                                                                     \
+        row_ = row_ < lk ? row_ : lk - 1;                                                                     \
         __builtin_amdgcn_global_load_lds(                                                                         \
             (const FINO_GLB void*)((BASE_PTR_) + (int64_t)row_ * (ROW_STRIDE_) + dma_ch[i_] * 8),                 \
             (FINO_LDS void*)(smem + (SLOT_) * kTileBytes + (wave + kWaves * i_) * 1024), 16, 0, 0);               \
@@ -143,7 +177,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
 #define STAGE_LOAD(T_)                                                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
         int row_ = (T_) * kKV + st_row[i_];                                                           \
-        row_ = row_ < p.lk ? row_ : p.lk - 1;                                                         \
+        row_ = row_ < lk ? row_ : lk - 1;                                                         \
         kreg[i_] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)row_ * p.k_rs + st_ch[i_] * 8);      \
         vreg[i_] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)row_ * p.v_rs + st_ch[i_] * 8);      \
     }
@@ -185,7 +219,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     // Software pipeline (K runs one tile ahead of V): iteration t issues S(t+1) = K(t+1).Q^T on the matrix pipe
     // while the VALU does the softmax of S(t); then O += V(t)^T.P(t).  LDS: K[2] ring + V[2] ring; K(t+2) and
     // V(t+1) travel global -> registers during the iteration and are written to LDS at its end; 1 barrier / tile.
-    const int nt = (p.lk + kKV - 1) / kKV;
+    const int nt = (lk + kKV - 1) / kKV;
 #ifdef FINO_ATTN_DMA
     DMA_TILE(kp, p.k_rs, 0, 0)
     DMA_TILE(vp, p.v_rs, 0, 2)
@@ -201,7 +235,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
 #pragma unroll
         for (int i = 0; i < kLoadsPerThread; ++i) {
             int row = kKV + st_row[i];
-            row = row < p.lk ? row : p.lk - 1;
+            row = row < lk ? row : lk - 1;
             kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)row * p.k_rs + st_ch[i] * 8);
             *reinterpret_cast<u32x4_t*>(smem + 1 * kTileBytes + st_off[i]) = kreg[i];
         }
@@ -261,8 +295,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i) {                                    \
                 int rk = (t + 2) * kKV + st_row[i];                                                          \
                 int rv = (t + 1) * kKV + st_row[i];                                                          \
-                rk = rk < p.lk ? rk : p.lk - 1;                                                              \
-                rv = rv < p.lk ? rv : p.lk - 1;                                                              \
+                rk = rk < lk ? rk : lk - 1;                                                              \
+                rv = rv < lk ? rv : lk - 1;                                                              \
                 kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)rk * p.k_rs + st_ch[i] * 8);      \
                 vreg[i] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)rv * p.v_rs + st_ch[i] * 8);      \
             }                                                                                                \
@@ -275,12 +309,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);                                            \
             sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);                                            \
         }                                                                                                    \
-        if (LAST_ && (p.lk & (kKV - 1))) { /* key = (j&3) + 8*(j>>2) + 4*h (+32) */                          \
+        if (LAST_ && (lk & (kKV - 1))) { /* key = (j&3) + 8*(j>>2) + 4*h (+32) */                          \
             const int kbase = t * kKV + 4 * h;                                                               \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                 \
                 const int key = kbase + (j & 3) + 8 * (j >> 2);                                              \
-                if (key >= p.lk) sc0[j] = 0.f;                                                               \
-                if (key + 32 >= p.lk) sc1[j] = 0.f;                                                          \
+                if (key >= lk) sc0[j] = 0.f;                                                               \
+                if (key + 32 >= lk) sc1[j] = 0.f;                                                          \
             }                                                                                                \
         }                                                                                                    \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                     \
@@ -367,6 +401,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
         l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
+    if (part >= 0) {
+        // partial: raw accumulators in thread order (coalesced), m and l per thread; attn_combine_kernel finishes
+        float* w = p.ws + (int64_t)part * partial_floats<D>();
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[(dt * 16 + j) * (kWaves * 64) + tid] = o[dt][j];
+        w[kDT * 16 * (kWaves * 64) + tid] = m_run;
+        w[kDT * 16 * (kWaves * 64) + kWaves * 64 + tid] = l_run;
+        continue;
+    }
     const float inv = 1.0f / l_run;
     if (qrow < p.lq) {
         uint16_t* orow = op + (int64_t)qrow * p.o_rs;
@@ -383,10 +428,97 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             }
         }
     }
+  }   // piece
+}
+
+// Merge the key-range partials of each tail block: m = max m_s, O = sum O_s 2^(m_s-m), l likewise; store bf16.
+template <typename T, int D>
+__global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnParams p) {
+    constexpr int kDT = D / 32;
+    constexpr int NT = kWaves * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, tb = blockIdx.x >> 3;
+    const int bx = p.full_x + tb;
+    const int hb = xcd + 8 * (bx / p.nqb);
+    const int qb = bx % p.nqb;
+    if (hb >= p.batch * p.heads) return;
+    const int ntall = (p.lk + kKV - 1) / kKV;
+    // workgroups (ranges) that hold a piece of this block; one range = the block ran whole and is already stored
+    const int c_first = (int)(((int64_t)tb * ntall) / p.per);
+    const int c_last = (int)((((int64_t)tb + 1) * ntall - 1) / p.per);
+    if (c_first == c_last) return;
+    const int bi = hb / p.heads, head = hb - bi * p.heads;
+    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
+    if (qrow >= p.lq) return;
+#define PART_PTR(C_) (p.ws + (int64_t)(((xcd * p.nwg) + (C_)) * 2 + (tb - (int)(((int64_t)(C_) * p.per) / ntall))) * partial_floats<D>())
+    float m = -INFINITY;
+    for (int c = c_first; c <= c_last; ++c) m = fmaxf(m, PART_PTR(c)[kDT * 16 * NT + tid]);
+    float acc[kDT * 16];
+#pragma unroll
+    for (int i = 0; i < kDT * 16; ++i) acc[i] = 0.f;
+    float l = 0.f;
+    for (int c = c_first; c <= c_last; ++c) {
+        const float* w = PART_PTR(c);
+        const float a = __builtin_amdgcn_exp2f(w[kDT * 16 * NT + tid] - m);
+        l += a * w[kDT * 16 * NT + NT + tid];
+#pragma unroll
+        for (int i = 0; i < kDT * 16; ++i) acc[i] += a * w[i * NT + tid];
+    }
+#undef PART_PTR
+    const float inv = 1.0f / l;
+    uint16_t* orow = p.o + bi * p.o_bs + head * p.o_hs + (int64_t)qrow * p.o_rs;
+#pragma unroll
+    for (int dt = 0; dt < kDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * h;
+            const float* a4 = acc + dt * 16 + 4 * g;
+            uint32_t x0 = (uint32_t)T::from_f32(a4[0] * inv) | ((uint32_t)T::from_f32(a4[1] * inv) << 16);
+            uint32_t x1 = (uint32_t)T::from_f32(a4[2] * inv) | ((uint32_t)T::from_f32(a4[3] * inv) << 16);
+            *reinterpret_cast<uint2*>(orow + d0) = make_uint2(x0, x1);
+        }
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;   // MI355X
+    }
+    return cus;
+}
+
+// Tail split plan.  One workgroup occupies a CU (2 waves/SIMD x 256 registers) and an XCD's CUs take its blocks in
+// rounds.  When the last round holds rem_x < CUs-per-XCD blocks, their rem_x*nt key tiles are dealt to nwg = CUs-per-XCD
+// workgroups in equal contiguous ranges of `per` tiles (stream-K on the key axis), so that round lasts rem_x/CUs of a
+// block instead of a whole one.  Ranges keep >= kMinTiles tiles, and per < nt so a range touches at most two blocks.
+struct SplitPlan { int full_x, rem_x, nwg, per; };
+inline SplitPlan plan_split(int batch, int heads, int nqb, int nt) {
+    constexpr int kMinTiles = 8;
+    const int cus_x = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
+    const int nblk_x = ((batch * heads + 7) / 8) * nqb;
+    SplitPlan sp{nblk_x, 0, 0, 1};
+    const int rem = nblk_x % cus_x;
+    if (rem == 0) return sp;
+    const int64_t total = (int64_t)rem * nt;
+    int nwg = cus_x;
+    if (nwg > total / kMinTiles) nwg = (int)(total / kMinTiles);
+    if (nwg <= rem) return sp;                       // nothing to gain (or too few keys to cut)
+    const int per = (int)((total + nwg - 1) / nwg);
+    if (per >= nt) return sp;
+    sp.full_x = nblk_x - rem;
+    sp.rem_x = rem;
+    sp.per = per;
+    sp.nwg = (int)((total + per - 1) / per);
+    return sp;
 }
 
 template <typename T, int D, int VAR>
-int launch_attn_v(const AttnParams& p, hipStream_t st) {
+int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -400,23 +532,45 @@ int launch_attn_v(const AttnParams& p, hipStream_t st) {
     }
     const int hb = p.batch * p.heads;
     const int groups = (hb + 7) / 8;
-    const dim3 grid((unsigned)(8 * groups * p.nqb));
+    SplitPlan sp{groups * p.nqb, 0, 0, 1};
+    if (p.ws) {
+        sp = plan_split(p.batch, p.heads, p.nqb, (p.lk + kKV - 1) / kKV);
+        const int64_t need = (int64_t)8 * sp.nwg * 2 * partial_floats<D>() * 4;
+        if (sp.rem_x > 0 && need > ws_bytes) {
+            fino_set_error("fino_attn_fwd_ws: workspace %lld B < %lld B", (long long)ws_bytes, (long long)need);
+            return FINO_ERR_ARG;
+        }
+    }
+    p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
+    const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
     attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
+    if (sp.rem_x > 0) {
+        attn_combine_kernel<T, D><<<dim3((unsigned)(8 * sp.rem_x)), kWaves * 64, 0, st>>>(p);
+        FINO_LAUNCH_CHECK();
+    }
     return FINO_OK;
 }
 
 template <typename T, int D>
-int launch_attn(const AttnParams& p, hipStream_t st) {
-    return p.lk > 1024 ? launch_attn_v<T, D, 0>(p, st) : launch_attn_v<T, D, 1>(p, st);
+int launch_attn(const AttnParams& p, int64_t ws_bytes, hipStream_t st) {
+    return p.lk > 1024 ? launch_attn_v<T, D, 0>(p, ws_bytes, st) : launch_attn_v<T, D, 1>(p, ws_bytes, st);
 }
 
 }  // namespace
 
-extern "C" int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
-                             int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
-                             int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
-                             int64_t o_rs, int64_t o_hs, float scale, int dtype, void* stream) {
+extern "C" int64_t fino_attn_workspace_bytes(int batch, int heads, int64_t lq, int64_t lk, int head_dim) {
+    if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0 || (head_dim != 64 && head_dim != 128)) return 0;
+    const SplitPlan sp = plan_split(batch, heads, (int)((lq + kQBlock - 1) / kQBlock), (int)((lk + kKV - 1) / kKV));
+    const int64_t pf = head_dim == 128 ? partial_floats<128>() : partial_floats<64>();
+    return (int64_t)8 * sp.nwg * 2 * pf * 4;
+}
+
+extern "C" int fino_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                                int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
+                                int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
+                                int64_t o_rs, int64_t o_hs, float scale, int dtype, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_fwd: dtype %d", dtype);
     FINO_CHECK(q && k && v && o, FINO_ERR_ARG, "fino_attn_fwd: null pointer");
     FINO_CHECK(batch > 0 && heads > 0 && lq >= 0 && lk > 0, FINO_ERR_ARG,
@@ -437,8 +591,19 @@ extern "C" int fino_attn_fwd(const void* q, const void* k, const void* v, void* 
     p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs; p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = o_hs;
     p.scale_log2 = scale * 1.4426950408889634f;
     p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
+    p.ws = (workspace && workspace_bytes > 0) ? (float*)workspace : nullptr;
+    FINO_CHECK(((uintptr_t)workspace & 15) == 0, FINO_ERR_ARG, "fino_attn_fwd_ws: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const int64_t wb = workspace_bytes;
     if (dtype == FINO_BF16)
-        return head_dim == 128 ? launch_attn<BF16, 128>(p, st) : launch_attn<BF16, 64>(p, st);
-    return head_dim == 128 ? launch_attn<F16, 128>(p, st) : launch_attn<F16, 64>(p, st);
+        return head_dim == 128 ? launch_attn<BF16, 128>(p, wb, st) : launch_attn<BF16, 64>(p, wb, st);
+    return head_dim == 128 ? launch_attn<F16, 128>(p, wb, st) : launch_attn<F16, 64>(p, wb, st);
+}
+
+extern "C" int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                             int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
+                             int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
+                             int64_t o_rs, int64_t o_hs, float scale, int dtype, void* stream) {
+    return fino_attn_fwd_ws(q, k, v, o, batch, heads, lq, lk, head_dim, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs,
+                            v_hs, o_bs, o_rs, o_hs, scale, dtype, nullptr, 0, stream);
 }

@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory and the HIP stream; every op bel
 pointers + strides to libframeino_hip.so on torch's *current* stream (so the calls are capturable in a
 torch.cuda.CUDAGraph == hipGraph).  No op has a torch/CPU fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -153,6 +155,20 @@ def headnorm_rope_(x, heads, head_dim, weight, bias, eps, cos=None, sin=None, ro
     return x
 
 
+SPLIT_ATTENTION_TAIL = os.environ.get("FINO_ATTN_SPLIT", "1") != "0"      # A/B knob; the split is the default
+_attn_ws = {}      # device index -> fp32 workspace of the attention tail split (caller-owned per the C ABI; grown on demand)
+
+
+def _attention_workspace(b, heads, lq, lk, dh, device):
+    need = _lib.lib().fino_attn_workspace_bytes(b, heads, lq, lk, dh)
+    if need <= 0:
+        return None, 0
+    ws = _attn_ws.get(device.index)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _attn_ws[device.index] = torch.empty(need // 4, dtype=torch.float32, device=device)
+    return ws, need
+
+
 def attention(q, k, v, heads, out=None, scale=None):
     """q [B, Lq, H*Dh] (row-strided view), k/v [B, Lk, H*Dh] -> o [B, Lq, H*Dh].  Non-causal SDPA."""
     assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
@@ -165,10 +181,11 @@ def attention(q, k, v, heads, out=None, scale=None):
         out = torch.empty((b, lq, hd), dtype=q.dtype, device=q.device)
     scale = dh ** -0.5 if scale is None else scale
     ev = _timed("attn_self" if lq == lk else "attn_cross")
-    _lib.check(_lib.lib().fino_attn_fwd(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh,
-                                       q.stride(0), q.stride(1), dh, k.stride(0), k.stride(1), dh,
-                                       v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), dh,
-                                       float(scale), _dt(q), _stream()), "fino_attn_fwd")
+    ws, ws_bytes = _attention_workspace(b, heads, lq, lk, dh, q.device) if SPLIT_ATTENTION_TAIL else (None, 0)
+    _lib.check(_lib.lib().fino_attn_fwd_ws(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh,
+                                          q.stride(0), q.stride(1), dh, k.stride(0), k.stride(1), dh,
+                                          v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), dh,
+                                          float(scale), _dt(q), _p(ws), ws_bytes, _stream()), "fino_attn_fwd_ws")
     if ev is not None:
         ev.record()
         kt_ = KernelTimer.active

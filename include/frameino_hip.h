@@ -92,6 +92,18 @@ int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batc
                   int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs,
                   int64_t o_hs, float scale, int dtype, void* stream);
 
+/* Same product with a caller-owned workspace that enables the TAIL SPLIT: one workgroup (256 query rows of one
+ * head) occupies a CU, so an XCD's 32 CUs take its blocks in rounds; when the last round holds fewer blocks than
+ * CUs, each of its blocks is cut along the keys into CUs/blocks ranges whose (O, m, l) partials go to the workspace
+ * and are merged by a second small kernel.  fino_attn_workspace_bytes returns the size to allocate (0 = the shape
+ * has no tail to split).  workspace NULL / 0 bytes => identical to fino_attn_fwd.  Results differ from the unsplit
+ * kernel only by fp32 summation order in the split blocks. */
+int64_t fino_attn_workspace_bytes(int batch, int heads, int64_t lq, int64_t lk, int head_dim);
+int fino_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                     int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs,
+                     int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs, int64_t o_hs,
+                     float scale, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- GEMM with fused epilogue (MFMA-bound) --------------------------------------------------------------
  * C[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] ),  A/W/C/R of `dtype`, bias of `dtype` (NULL => 0), fp32 accumulate.
  * W is the nn.Linear weight as stored ([out, in], K contiguous).  lda/ldw/ldc/ldr in elements, multiples of 8.

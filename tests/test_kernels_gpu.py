@@ -148,6 +148,46 @@ def test_attention_vs_fp32_sdpa(ops, dtype, b, heads, dh, lq, lk):
     assert (o.float() - ref).abs().max().item() < 0.05
 
 
+@pytest.mark.parametrize("b,heads,dh,lq,lk", [
+    (1, 8, 128, 2000, 2000),      # 8 blocks per XCD -> 4 key ranges each
+    (1, 3, 128, 1100, 3000),      # heads not a multiple of 8: some XCDs own nothing; 5 blocks -> 6 ranges (ragged keys)
+    (2, 12, 64, 777, 1500),       # head_dim 64, 3 heads-batches x 4 blocks = 12 per XCD -> 2 ranges
+    (1, 24, 128, 3080, 3080),     # the 4-way token shard's query count (39 blocks per XCD: 32 whole + 7 split)
+])
+def test_attention_tail_split_equals_unsplit(ops, b, heads, dh, lq, lk):
+    """fino_attn_fwd_ws (key-range partials + merge) against the one-pass kernel and fp32 SDPA."""
+    from frameino_amd import _lib
+    q = rnd(b, lq, heads * dh, seed=21)
+    k = rnd(b, lk, heads * dh, seed=22)
+    v = rnd(b, lk, heads * dh, seed=23)
+    k[0, lk - 3] = q[0, 7] * 3.0                       # a late spike: the ranges end with different running maxima
+    assert _lib.lib().fino_attn_workspace_bytes(b, heads, lq, lk, dh) > 0
+    ops.SPLIT_ATTENTION_TAIL = False
+    try:
+        o1 = ops.attention(q, k, v, heads)
+    finally:
+        ops.SPLIT_ATTENTION_TAIL = True
+    o2 = ops.attention(q, k, v, heads)
+    ref = sdpa_ref(q, k, v, heads)
+    assert rel_rms(o2, ref) < 2.0 ** -6
+    assert rel_rms(o2, o1.float()) < 2.0 ** -8        # same P rounding; only the fp32 merge order differs
+    # blocks that run whole are bit-identical
+    full_rows = 256
+    assert torch.equal(o1[:, :full_rows], o2[:, :full_rows]) or rel_rms(o2[:, :full_rows], o1[:, :full_rows].float()) < 2.0 ** -8
+
+
+def test_attention_workspace_too_small_is_an_error(ops):
+    from frameino_amd import _lib
+    q = rnd(1, 2000, 8 * 128, seed=24)
+    out = torch.empty_like(q)
+    ws = torch.empty(64, dtype=torch.float32, device=DEV)
+    rc = _lib.lib().fino_attn_fwd_ws(q.data_ptr(), q.data_ptr(), q.data_ptr(), out.data_ptr(), 1, 8, 2000, 2000, 128,
+                                    q.stride(0), q.stride(1), 128, q.stride(0), q.stride(1), 128, q.stride(0),
+                                    q.stride(1), 128, out.stride(0), out.stride(1), 128, 0.088, 0, ws.data_ptr(), 256,
+                                    0)
+    assert rc != 0 and b"workspace" in _lib.lib().fino_last_error()
+
+
 def test_attention_reads_fused_qkv_in_place(ops):
     L, heads, dh = 450, 4, 128
     d = heads * dh
@@ -347,8 +387,9 @@ def test_cfg_unipc_step(dtype, has_uncond):
         if has_uncond:
             u = pu[:, :fg]
             v = u + 5.0 * (v - u)                               # every op rounds to the model dtype (:882)
-        # GPU semantics of `sigma_t * model_output` (CPU 0-dim fp32 sigma x device T tensor): fp32 multiply, round to T
-        mt = x - (coef[1].item() * v.float()).to(dtype).float()
+        # `sigma_t * model_output` as the sampler evaluates it: a CPU 0-dim fp32 sigma times a device T tensor (the
+        # exact product rounded once to T -- a CPU emulation through fp32 double-rounds ties differently)
+        mt = x - (coef[1] * v.to(DEV)).float().cpu()
         xc = coef[3] * last + coef[4] * m0 + coef[5] * m1 + coef[6] * mt if use_corr else x
         xn = coef[7] * xc + coef[8] * mt + coef[9] * m0
         bx, bl, b0, b1 = (t.clone().to(DEV) for t in (x, last, m0, m1))
