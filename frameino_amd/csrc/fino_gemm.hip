@@ -28,6 +28,85 @@ extern "C" int fino_gemm_debug_read(unsigned long long* out) {
 
 namespace {
 
+// ---- tile id -> (tm, tn): contiguous id range per XCD, 4-tile-high groups inside (operand reuse in that XCD's L2) ----
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    constexpr int GROUP_M = 4;
+    const int group = id / (GROUP_M * p.tiles_n);
+    const int first_m = group * GROUP_M;
+    const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
+    const int in_group = id - group * GROUP_M * p.tiles_n;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+}
+
+// Shared by both main-loop variants.  Every wave must be past its last LDS operand read (barrier) before the call.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[8][4], const GemmParams& p, char* smem, int64_t m0,
+                                              int64_t n0, int tid, int lane, int wm, int wn) {
+    // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
+    // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*128 + i*16 + (lane&15)
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int64_t gn = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + e;
+            if (gn >= p.n) gn = p.n - 1;
+            bv[j][e] = p.bias ? T::to_f32(p.bias[gn]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = acc[i][j][e] + bv[j][e];
+                if (EPI == FINO_EPI_GELU_TANH) y[e] = gelu_tanh_f32(round_to<T>(y[e]));
+            }
+            const uint32_t w0 = (uint32_t)T::from_f32(y[0]) | ((uint32_t)T::from_f32(y[1]) << 16);
+            const uint32_t w1 = (uint32_t)T::from_f32(y[2]) | ((uint32_t)T::from_f32(y[3]) << 16);
+            const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<uint2*>(smem + row * kCsStride + col * 2) = make_uint2(w0, w1);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < (BM * BN / 8) / kThreads; ++it) {
+        const int idx = it * kThreads + tid;
+        const int row = idx >> 5;
+        const int ch = idx & 31;
+        const int64_t gm = m0 + row, gn = n0 + ch * 8;
+        if (gm >= p.m || gn >= p.n) continue;
+        uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
+        if (EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED) {
+            float y[8], rv[8], o[8];
+            unpack8<T>(yv, y);
+            unpack8<T>(*reinterpret_cast<const uint4*>(p.r + gm * p.ldr + gn), rv);
+            if (EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED) {
+                const float* g = p.gate + (p.sel ? (int64_t)p.sel[gm] * p.mod_stride : 0) + gn;
+                const float4 g0 = *reinterpret_cast<const float4*>(g);
+                const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = rv[e] + (EPI == FINO_EPI_GATED_RESIDUAL_STAGED ? round_to<T>(y[e] * gg[e]) : y[e] * gg[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
+            }
+            yv = pack8<T>(o);
+        }
+        *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
+    }
+}
+
 template <typename T, int EPI, bool GENERIC, bool CONV>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,21 +117,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
     const int wm = wave >> 2;  // 0..1
     const int wn = wave & 3;   // 0..3
 
-    // ---- XCD-aware tile id: contiguous id range per XCD, 4-high groups inside ----
-    const int nwg = p.tiles_m * p.tiles_n;
-    int id;
-    {
-        const int orig = blockIdx.x;
-        const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    }
-    constexpr int GROUP_M = 4;
-    const int group = id / (GROUP_M * p.tiles_n);
-    const int first_m = group * GROUP_M;
-    const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
-    const int in_group = id - group * GROUP_M * p.tiles_n;
-    const int tm = first_m + in_group % gsz;
-    const int tn = in_group / gsz;
+    int tm, tn;
+    tile_coords(p, tm, tn);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
     // ---- staging: 4 rounds per operand; wave-instruction = 8 rows x 128 B ----
@@ -291,64 +357,172 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 #undef LOAD_FRAGS
 #undef MFMA_BLOCK
 
-    // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
-    // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*128 + i*16 + (lane&15)
-    float bv[4][4];
+    gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
+}
+
+// ---- ping-pong main loop (aligned K, plain GEMM) ------------------------------------------------------------------
+// The two waves that share a SIMD (wave w of rows 0-127 = group 0, wave w+4 of rows 128-255 = group 1) run HALF A
+// K-TILE OUT OF PHASE: while one issues its 64 MFMAs of K-tile t back to back from registers (no LDS access in that
+// phase), the other fetches its 24 ds_read_b128 fragments of its next K-tile and issues the LDS-DMA of a later one.
+// Phases are separated by s_barrier, so the matrix pipe of each SIMD always has exactly one wave feeding it and the
+// age-based arbitration between co-resident waves (the older wave starving the younger, then idling at the barrier:
+// 2840 cycles per K-tile measured on the one-barrier loop against 2048 of MFMA) has nothing to arbitrate.
+//   phase 2t   : G0 LOAD(t)  + DMA {A rows 0-127, W} of tile t+1     | G1 COMPUTE(t-1) (+ WC pieces of W(t+1))
+//   phase 2t+1 : G0 COMPUTE(t)                                        | G1 LOAD(t) + DMA {A rows 128-255} of tile t+1
+// LDS: two 64-KiB stages.  Stage (t+1)%2 held tile t-1: its A half of a group is dead after that group's LOAD(t-1),
+// its W after G1's LOAD(t-1) (phase 2t-1), so every DMA above starts in a free region and has >= one whole phase to land.
+template <typename T, int EPI, int WC>
+__global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename T::vec8 vec8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;  // group
+    const int wn = wave & 3;
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    // ---- LDS-DMA pieces: 8 tile rows x 128 B per wave-instruction; swizzle on the source chunk ----
+    // buffer_load_dwordx4 ... lds: the per-lane part of the address is ONE 32-bit byte offset per piece (row base +
+    // swizzled chunk, rows past the edge clamped to the last one), the K advance rides in the scalar offset, so the
+    // loop carries 12 address registers and no per-piece vector arithmetic (launch checks the operands span < 4 GiB).
+    const int r8 = lane >> 3;
+    const int sk = ((lane & 7) ^ ((4 * (wn & 1) + (lane >> 4)) & 7)) * 8;   // = (phys chunk ^ swz(row)) * 8 elements
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.a, 0, (int)(((p.m - 1) * p.lda + p.k) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w, 0, (int)(((p.n - 1) * p.ldw + p.k) * 2), 0x00020000);
+    // A piece q (0..3) of my group: tile rows wm*128 + q*32 + wn*8 + r8;  W piece q (0..7): rows q*32 + wn*8 + r8
+    uint32_t a_off[4], w_off[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int64_t gn = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + e;
-            if (gn >= p.n) gn = p.n - 1;
-            bv[j][e] = p.bias ? T::to_f32(p.bias[gn]) : 0.f;
-        }
+    for (int q = 0; q < 4; ++q) {
+        int64_t gm = m0 + wm * 128 + q * 32 + wn * 8 + r8;
+        gm = gm < p.m ? gm : p.m - 1;
+        a_off[q] = (uint32_t)((gm * p.lda + sk) * 2);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wm * 128 + i * 16 + (lane & 15);
+    for (int q = 0; q < 8; ++q) {
+        int64_t gn = n0 + q * 32 + wn * 8 + r8;
+        gn = gn < p.n ? gn : p.n - 1;
+        w_off[q] = (uint32_t)((gn * p.ldw + sk) * 2);
+    }
+#define PP_DMA_A(STAGE_, KT_, Q_)                                                                                 \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
+        a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + (wm * 128 + (Q_) * 32 + wn * 8) * 128), 16,      \
+        a_off[Q_], (KT_) * (BK * 2), 0, 0);
+#define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
+        w_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + kTileBytes + ((Q_) * 32 + wn * 8) * 128), 16,    \
+        w_off[Q_], (KT_) * (BK * 2), 0, 0);
+
+    const int frow = lane & 15;
+    const int pch0 = (lane >> 4) ^ (frow >> 1);
+    const int a_base = (wm * 128 + frow) * 128;
+    const int w_base = kTileBytes + (wn * 64 + frow) * 128;
+
+    f32x4_t acc[8][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float y[4];
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = acc[i][j][e] + bv[j][e];
-                if (EPI == FINO_EPI_GELU_TANH) y[e] = gelu_tanh_f32(round_to<T>(y[e]));
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(p.k / BK);
+    // prologue: tiles 0 and 1 whole (each group its A half and half of W)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        PP_DMA_A(0, 0, q)
+        if (wm == 0) PP_DMA_W(0, 0, q) else PP_DMA_W(0, 0, 4 + q)
+    }
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            PP_DMA_A(1, 1, q)
+            if (wm == 0) PP_DMA_W(1, 1, q) else PP_DMA_W(1, 1, 4 + q)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();       // phase 0: group 1 has nothing to compute yet
+
+    u32x4_t af[2][8], wf[2][4];
+#ifdef FINO_GEMM_STAMP
+    unsigned long long t0, t1, t2, t3, t4, acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#define PSTAMP(V_) { __builtin_amdgcn_sched_barrier(0); STAMP(V_) __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PSTAMP(V_)
+#endif
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const char* sb = smem + cur * kStageBytes;
+        PSTAMP(t0)
+        // ---------------- LOAD(t): all fragments of my 128x64 (A) and 64x64 (W) operand blocks ----------------
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int pch = (pch0 ^ (kk << 2)) << 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[kk][j] = *reinterpret_cast<const u32x4_t*>(sb + w_base + j * 2048 + pch);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(sb + a_base + i * 2048 + pch);
+        }
+        if (t >= 1 && t + 1 < nk) {                  // tile t+1 into the stage tile t-1 has left
+#pragma unroll
+            for (int q = 0; q < 4; ++q) PP_DMA_A(cur ^ 1, t + 1, q)
+            if (wm == 0) {
+#pragma unroll
+                for (int q = 0; q < 8 - WC; ++q) PP_DMA_W(cur ^ 1, t + 1, q)
             }
-            const uint32_t w0 = (uint32_t)T::from_f32(y[0]) | ((uint32_t)T::from_f32(y[1]) << 16);
-            const uint32_t w1 = (uint32_t)T::from_f32(y[2]) | ((uint32_t)T::from_f32(y[3]) << 16);
-            const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
-            *reinterpret_cast<uint2*>(smem + row * kCsStride + col * 2) = make_uint2(w0, w1);
         }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < (BM * BN / 8) / kThreads; ++it) {
-        const int idx = it * kThreads + tid;
-        const int row = idx >> 5;
-        const int ch = idx & 31;
-        const int64_t gm = m0 + row, gn = n0 + ch * 8;
-        if (gm >= p.m || gn >= p.n) continue;
-        uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
-        if (EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED) {
-            float y[8], rv[8], o[8];
-            unpack8<T>(yv, y);
-            unpack8<T>(*reinterpret_cast<const uint4*>(p.r + gm * p.ldr + gn), rv);
-            if (EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED) {
-                const float* g = p.gate + (p.sel ? (int64_t)p.sel[gm] * p.mod_stride : 0) + gn;
-                const float4 g0 = *reinterpret_cast<const float4*>(g);
-                const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        __builtin_amdgcn_sched_barrier(0);
+        if (WC > 0 && wm == 1) {
+            // my W pieces of tile t+1 (issued in COMPUTE(t-1)) are older than the 4 A pieces just issued
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        PSTAMP(t1)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(t2)
+        // ---------------- COMPUTE(t): 64 MFMAs from registers ----------------
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    o[e] = rv[e] + (EPI == FINO_EPI_GATED_RESIDUAL_STAGED ? round_to<T>(y[e] * gg[e]) : y[e] * gg[e]);
-            } else {
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
+            for (int i = 0; i < 8; ++i) {
+                if (WC > 0 && wm == 1 && t + 2 < nk && (kk * 8 + i) < WC) PP_DMA_W(cur, t + 2, 8 - WC + kk * 8 + i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
+                                          acc[i][j]);
             }
-            yv = pack8<T>(o);
         }
-        *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
+        __builtin_amdgcn_sched_barrier(0);
+        if (WC > 0 && wm == 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC) : "memory");     // my A pieces of tile t+1; W(t+2) stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PSTAMP(t3)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef FINO_GEMM_STAMP
+        STAMP(t4)
+        acc0 += t1 - t0; acc1 += t2 - t1; acc2 += t3 - t2; acc3 += t4 - t3;
+#endif
     }
+#ifdef FINO_GEMM_STAMP
+    if (blockIdx.x == 17 && lane == 0) {
+        fino_gemm_dbg[wave * 8 + 0] = acc0; fino_gemm_dbg[wave * 8 + 1] = acc1;
+        fino_gemm_dbg[wave * 8 + 2] = acc2; fino_gemm_dbg[wave * 8 + 3] = acc3;
+        fino_gemm_dbg[wave * 8 + 4] = (unsigned long long)nk;
+    }
+#endif
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PP_DMA_A
+#undef PP_DMA_W
+    gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
 template <typename T, int EPI, bool GENERIC, bool CONV = false>
@@ -368,8 +542,47 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
+#ifndef FINO_GEMM_PP_WC
+#define FINO_GEMM_PP_WC 0
+#endif
+template <typename T, int EPI>
+int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, FINO_GEMM_PP_WC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        if (e != hipSuccess) {
+            fino_set_error("fino_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return FINO_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    gemm_pp_kernel<T, EPI, FINO_GEMM_PP_WC><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+inline bool use_pingpong() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FINO_GEMM_PP");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <typename T, bool GENERIC>
 int launch_gemm_e(const GemmParams& p, int epi, hipStream_t st) {
+    const bool fits32 = ((p.m - 1) * p.lda + p.k) * 2 < (1ll << 31) && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
+    if (!GENERIC && use_pingpong() && fits32) {
+        switch (epi) {
+            case FINO_EPI_NONE: return launch_gemm_pp<T, FINO_EPI_NONE>(p, st);
+            case FINO_EPI_GELU_TANH: return launch_gemm_pp<T, FINO_EPI_GELU_TANH>(p, st);
+            case FINO_EPI_RESIDUAL: return launch_gemm_pp<T, FINO_EPI_RESIDUAL>(p, st);
+            case FINO_EPI_GATED_RESIDUAL_STAGED: return launch_gemm_pp<T, FINO_EPI_GATED_RESIDUAL_STAGED>(p, st);
+            default: return launch_gemm_pp<T, FINO_EPI_GATED_RESIDUAL>(p, st);
+        }
+    }
     switch (epi) {
         case FINO_EPI_NONE: return launch_gemm_t<T, FINO_EPI_NONE, GENERIC>(p, st);
         case FINO_EPI_GELU_TANH: return launch_gemm_t<T, FINO_EPI_GELU_TANH, GENERIC>(p, st);
