@@ -16,6 +16,8 @@
 //     token-major [L, H*Dh]: no transposes anywhere.
 //   * blockIdx -> (head, q-block) is XCD-aware: all q-blocks of a head share blockIdx%8, i.e. one XCD's L2 holds
 //     that head's K/V while its 32 CUs sweep it.
+#include <stdlib.h>
+
 #include "fino_common.h"
 
 #ifdef FINO_ATTN_STAMP
@@ -32,6 +34,17 @@ extern "C" int fino_attn_debug_read(unsigned long long* out) {
 #define FINO_ATTN_WAVES 8
 #endif
 #define FINO_ATTN_WAVES_DEFAULT FINO_ATTN_WAVES
+
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 namespace {
 
@@ -431,6 +444,382 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
   }   // piece
 }
 
+template <typename T, int D, int VAR>
+__global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kTileBytes = kKV * D * 2;
+    constexpr int kChunksPerRow = D / 8;
+    constexpr int kLoadsPerThread = (kKV * kChunksPerRow) / (kWaves * 64);  // 2 (D=128) or 1 (D=64)
+    constexpr int kKS = D / 16;                                             // k-steps of QK^T
+    constexpr int kDT = D / 32;                                             // d-tiles of O^T
+    typedef typename T::vec8 vec8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- XCD-aware block -> (head-batch, q-block) ----
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    // whole blocks first; then the XCD's last `rem_x` blocks as one stream of rem_x*nt key tiles cut into `nwg` equal
+    // ranges (tail split): a range covers pieces of at most two blocks (per < nt).
+    const int ntall = (p.lk + kKV - 1) / kKV;
+    int npieces = 1, first_b = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (slot >= p.full_x) {
+        g0 = (int64_t)(slot - p.full_x) * p.per;
+        g1 = g0 + p.per < (int64_t)p.rem_x * ntall ? g0 + p.per : (int64_t)p.rem_x * ntall;
+        first_b = (int)(g0 / ntall);
+        npieces = (int)((g1 - 1) / ntall) - first_b + 1;
+    }
+  for (int piece = 0; piece < npieces; ++piece) {
+    if (piece > 0) __syncthreads();                 // every wave is done reading the previous piece's LDS tiles
+    int bx = slot, part = -1, t_begin = 0, t_end = ntall;
+    if (slot >= p.full_x) {
+        const int tb = first_b + piece;
+        const int64_t b0 = (int64_t)tb * ntall;
+        t_begin = g0 > b0 ? (int)(g0 - b0) : 0;
+        t_end = g1 - b0 < ntall ? (int)(g1 - b0) : ntall;
+        bx = p.full_x + tb;
+        if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
+    }
+    const int hb = xcd + 8 * (bx / p.nqb);
+    const int qb = bx % p.nqb;
+    if (hb >= p.batch * p.heads) continue;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs + (int64_t)t_begin * kKV * p.k_rs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs + (int64_t)t_begin * kKV * p.v_rs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    // keys of this workgroup's range, re-based to 0 (a multiple of kKV precedes it, so tail masks are unchanged)
+    const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
+    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+    vec8 qf[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        qf[ks] = __builtin_bit_cast(vec8, u);
+    }
+
+    // ---- staging roles: each group (waves 0-3 / 4-7) moves ITS half (32 rows) of a tile ----
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    int st_row[kLoadsPerThread], st_ch[kLoadsPerThread], st_off[kLoadsPerThread];
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        const int cid = (tid & 255) + i * 256;
+        st_row[i] = grp * 32 + cid / kChunksPerRow;
+        st_ch[i] = cid % kChunksPerRow;
+        st_off[i] = lds_off<D>(st_row[i], st_ch[i]);
+    }
+    u32x4_t kreg[kLoadsPerThread], vreg[kLoadsPerThread];
+    // my half of K(W_+1) and V(W_): global -> registers with buffer loads: the per-thread part of the address is a fixed
+    // 32-bit offset (row in tile, chunk), the tile advance is the scalar offset, and rows past the last key fail the
+    // range check and read as zeros (masked in the ragged last tile) -- no per-tile vector address arithmetic.
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)kp, 0, (int)((((int64_t)lk - 1) * p.k_rs + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)vp, 0, (int)((((int64_t)lk - 1) * p.v_rs + D) * 2), 0x00020000);
+    uint32_t kvo[kLoadsPerThread], vvo[kLoadsPerThread];
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        kvo[i] = (uint32_t)((st_row[i] * p.k_rs + st_ch[i] * 8) * 2);
+        vvo[i] = (uint32_t)((st_row[i] * p.v_rs + st_ch[i] * 8) * 2);
+    }
+    const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
+#define PP_LOAD(W_)                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                       \
+        kreg[i_] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(                       \
+                                                   k_rsrc, kvo[i_], ((W_) + 1) * k_tile_bytes, 0));        \
+        vreg[i_] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(                       \
+                                                   v_rsrc, vvo[i_], (W_) * v_tile_bytes, 0));              \
+    }
+    // registers -> LDS: K ring slot (W_+1)&1, V ring slot 2 + (W_&1)
+#define PP_WRITE(W_)                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                       \
+        *reinterpret_cast<u32x4_t*>(smem + (((W_) + 1) & 1) * kTileBytes + st_off[i_]) = kreg[i_];         \
+        *reinterpret_cast<u32x4_t*>(smem + (2 + ((W_) & 1)) * kTileBytes + st_off[i_]) = vreg[i_];         \
+    }
+
+    // ---- per-lane LDS read addressing (as attn_fwd_kernel) ----
+    const int tq = (lane & 15) >> 2;
+    const int tp = lane & 3;
+    const int g1 = (lane >> 4) & 1;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+    f32x16_t o[kDT];
+#pragma unroll
+    for (int i = 0; i < kDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+    const float c2 = p.scale_log2;
+    const int nt = (lk + kKV - 1) / kKV;
+
+    // ---- prologue: K(0), V(0), K(1) into LDS (both groups, each its half) ----
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        const u32x4_t k0v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kvo[i], 0, 0));
+        const u32x4_t v0v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, vvo[i], 0, 0));
+        const u32x4_t k1v =
+            __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kvo[i], k_tile_bytes, 0));
+        *reinterpret_cast<u32x4_t*>(smem + 0 * kTileBytes + st_off[i]) = k0v;
+        *reinterpret_cast<u32x4_t*>(smem + 2 * kTileBytes + st_off[i]) = v0v;
+        *reinterpret_cast<u32x4_t*>(smem + 1 * kTileBytes + st_off[i]) = k1v;
+    }
+    if (grp == 1) { PP_LOAD(1) }          // group 1 writes tile 1 in its first softmax phase
+    __syncthreads();
+
+    f32x16_t sc0, sc1;   // S of the tile in flight
+#define QK_TILE(KB_)                                                                                        \
+    {                                                                                                       \
+        const char* kb_ = smem + (KB_) * kTileBytes;                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) { sc0[j_] = 0.f; sc1[j_] = 0.f; }                 \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < kKS; ++ks_) {                                             \
+            const uint4 a0_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(r, 2 * ks_ + h));            \
+            const uint4 a1_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(32 + r, 2 * ks_ + h));       \
+            sc0 = T::mfma32(__builtin_bit_cast(vec8, a0_), qf[ks_], sc0);                                   \
+            sc1 = T::mfma32(__builtin_bit_cast(vec8, a1_), qf[ks_], sc1);                                   \
+        }                                                                                                   \
+    }
+    QK_TILE(0)
+    // keys past lk (zero K rows in a ragged last tile) stay out of the row max and get p = exp2(-inf) = 0
+#define MASK_RAGGED(T_)                                                                                     \
+    if ((T_) == nt - 1 && (lk & (kKV - 1))) {            /* key = (j&3) + 8*(j>>2) + 4*h (+32) */           \
+        const int kbase_ = (T_) * kKV + 4 * h;                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                 \
+            const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);                                             \
+            if (key_ >= lk) sc0[j_] = -INFINITY;                                                            \
+            if (key_ + 32 >= lk) sc1[j_] = -INFINITY;                                                       \
+        }                                                                                                   \
+    }
+    // row max of 8 accumulator registers (one of four independent chains).  v_max3_f32 through asm: fmaxf on MFMA
+    // results makes the compiler canonicalise every input first (32 extra v_max_f32 per tile).
+#define MAX8(S_, O_) vmax2(vmax3(vmax3(S_[O_], S_[O_ + 1], S_[O_ + 2]), vmax3(S_[O_ + 3], S_[O_ + 4], S_[O_ + 5]), \
+                                 S_[O_ + 6]), S_[O_ + 7])
+#define MAX_FINISH1(MX_, OUT_)                                                                              \
+    {                                                                                                       \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(MX_), __float_as_uint(MX_), false, false); \
+        OUT_ = vmax2(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                     \
+    }
+    float mx_next;
+    {
+        MASK_RAGGED(0)
+        const float m0 = vmax2(vmax3(MAX8(sc0, 0), MAX8(sc0, 8), MAX8(sc1, 0)), MAX8(sc1, 8));
+        MAX_FINISH1(m0, mx_next)
+    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
+
+    // LDS fragment addresses of the matrix phase: three registers.  The swizzle is an XOR on the chunk bits, so k-step
+    // ks / d-tile dt only flip address bits (ks << 5, dt << 6: one v_xor next to the read); the +32 / +16-row operands
+    // are instruction offsets; and the ring slot (K: slot (t+1)&1, V: slot 2 + (t&1)) is the kTileBytes bit, toggled
+    // once per tile.  Raw LDS addresses: the dynamic segment is the kernel's only LDS, so it starts at 0.
+    if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
+    uint32_t ka0 = 1 * kTileBytes + lds_off<D>(r, h);
+    uint32_t vl0 = 2 * kTileBytes + lds_off<D>(4 * h + tq, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+    uint32_t vh0 = 2 * kTileBytes + lds_off<D>(4 * h + tq + 8, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+#define LDS_PTR(TYPE_, ADDR_) ((FINO_LDS TYPE_*)(uintptr_t)(uint32_t)(ADDR_))
+
+    // Ping-pong: per key tile every wave alternates a SOFTMAX phase (VALU: max, exp2, sums, bf16 packing; plus its
+    // share of the K/V staging) with a MATRIX phase (32 MFMAs: S(t+1) = K(t+1).Q^T and O^T += V(t)^T.P(t)^T, LDS
+    // fragment reads in the MFMA gaps).  The two waves of a SIMD are one phase apart, so its matrix pipe and its
+    // VALU each serve one wave at a time instead of being arbitrated by age.
+#ifdef FINO_ATTN_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
+    unsigned long long tsa = 0, tsb = 0, tsc = 0, sa5 = 0, sa6 = 0, sa7 = 0;
+#endif
+    for (int t = 0; t < nt; ++t) {
+        ASTAMP(ts0)
+        // ================= softmax phase =================
+        const int w = t + grp;                      // tile whose V (and K of the next) this group stages now
+        if (w >= 1) { PP_WRITE(w) }
+        ASTAMP(tsa)
+        {
+            // deferred rescale (threshold kRescaleThr): O, l and m move together, between tiles.  mx_next = row max of
+            // this tile's S, computed in the shadow of the previous matrix phase's P.V MFMAs.
+            const float m_cand = fmaxf(m_run, mx_next * c2);
+            if (__any((m_cand - m_run) > kRescaleThr)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+                m_run = m_cand;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < kDT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+            }
+        }
+        ASTAMP(tsb)
+        // p = exp2(c.s - m).  Scalar fp32 on purpose: v_pk_fma_f32 / v_pk_add_f32 measured ~2x SLOWER per element here.
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);
+            sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);
+        }
+        ASTAMP(tsc)
+        PP_LOAD(w + 1)                               // spaced from the ds_writes above by the exp block
+        {
+            float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                psum0 += sc0[j];
+                psum1 += sc1[j];
+            }
+            l_run += psum0 + psum1;
+        }
+        vec8 pb[4];                                  // P(t) packed: pb[2*kt + s2]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pb[0][j] = (typename T::scalar)sc0[j];
+            pb[1][j] = (typename T::scalar)sc0[8 + j];
+            pb[2][j] = (typename T::scalar)sc1[j];
+            pb[3][j] = (typename T::scalar)sc1[8 + j];
+        }
+        // the whole softmax belongs to THIS phase: pin its results in registers here (pure arithmetic would otherwise
+        // be sunk past the barrier into the matrix phase, next to its first use)
+        {
+            u32x4_t p0 = __builtin_bit_cast(u32x4_t, pb[0]), p1 = __builtin_bit_cast(u32x4_t, pb[1]);
+            u32x4_t p2 = __builtin_bit_cast(u32x4_t, pb[2]), p3 = __builtin_bit_cast(u32x4_t, pb[3]);
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(l_run));
+            pb[0] = __builtin_bit_cast(vec8, p0); pb[1] = __builtin_bit_cast(vec8, p1);
+            pb[2] = __builtin_bit_cast(vec8, p2); pb[3] = __builtin_bit_cast(vec8, p3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ASTAMP(ts1)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ASTAMP(ts2)
+        // ================= matrix phase =================
+        // 12 stages: 8 k-steps of S(t+1) (2 K row reads + 2 MFMAs each), then 4 key groups of P.V (8 transposed V reads
+        // + 4 MFMAs each).  A stage's LDS reads are issued two (K) / one (V) stages ahead of its MFMAs, pinned by
+        // sched_barrier, so every MFMA finds its operands in registers.
+#ifndef FINO_ATTN_NOPRIO
+        __builtin_amdgcn_s_setprio(1);               // the matrix-phase wave wins issue arbitration on its SIMD
+#endif
+        u32x4_t ka[3][2];
+        s16x4_t vlo[2][kDT], vhi[2][kDT];
+#define LOADK(KS_, B_)                                                                                      \
+    {                                                                                                       \
+        const uint32_t a_ = ka0 ^ ((KS_) << 5);                                                             \
+        ka[B_][0] = *LDS_PTR(const u32x4_t, a_);                                                            \
+        ka[B_][1] = *LDS_PTR(const u32x4_t, a_ + 32 * D * 2);                                               \
+    }
+#define LOADV(STEP_, B_)                                                                                    \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < kDT; ++dt_) {                                                 \
+        vlo[B_][dt_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                             \
+            LDS_PTR(s16x4_t, (vl0 ^ (dt_ << 6)) + (STEP_) * 16 * D * 2));                                   \
+        vhi[B_][dt_] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                             \
+            LDS_PTR(s16x4_t, (vh0 ^ (dt_ << 6)) + (STEP_) * 16 * D * 2));                                   \
+    }
+        if (t + 1 < nt) {
+            const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            LOADK(0, 0)
+            LOADK(1, 1)
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                if (ks + 2 < kKS) LOADK(ks + 2, (ks + 2) % 3)
+                if (ks == kKS - 2) LOADV(0, 0)
+                sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[ks % 3][0]), qf[ks], ks == 0 ? zero16 : sc0);
+                sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[ks % 3][1]), qf[ks], ks == 0 ? zero16 : sc1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            LOADV(0, 0)
+        }
+        MASK_RAGGED(t + 1)
+        float mxa = -INFINITY;
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            if (step + 1 < 4) LOADV(step + 1, (step + 1) & 1)
+#pragma unroll
+            for (int dt = 0; dt < kDT; ++dt) {
+                const s16x8_t va = __builtin_shufflevector(vlo[step & 1][dt], vhi[step & 1][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = T::mfma32(__builtin_bit_cast(vec8, va), pb[step], o[dt]);
+            }
+            // row max of S(t+1), a quarter per key group, in the shadow of these MFMAs (S(t+1) is complete: its
+            // MFMAs precede these in the pipe)
+            mxa = vmax2(mxa, step == 0 ? MAX8(sc0, 0) : step == 1 ? MAX8(sc0, 8) : step == 2 ? MAX8(sc1, 0) : MAX8(sc1, 8));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MAX_FINISH1(mxa, mx_next)
+#undef LOADK
+#undef LOADV
+        ka0 ^= kTileBytes;
+        vl0 ^= kTileBytes;
+        vh0 ^= kTileBytes;
+#ifndef FINO_ATTN_NOPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ASTAMP(ts3)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef FINO_ATTN_STAMP
+        ASTAMP(ts4)
+        sa0 += ts1 - ts0; sa1 += ts2 - ts1; sa2 += ts3 - ts2; sa3 += ts4 - ts3;
+        sa5 += tsa - ts0; sa6 += tsb - tsa; sa7 += tsc - tsb;
+#endif
+    }
+#ifdef FINO_ATTN_STAMP
+    if (blockIdx.x == 40 && lane == 0 && VAR == 0) {
+        fino_attn_dbg[wave * 8 + 0] = sa0; fino_attn_dbg[wave * 8 + 1] = sa1; fino_attn_dbg[wave * 8 + 2] = sa2;
+        fino_attn_dbg[wave * 8 + 3] = sa3; fino_attn_dbg[wave * 8 + 4] = (unsigned long long)nt;
+        fino_attn_dbg[wave * 8 + 5] = sa5; fino_attn_dbg[wave * 8 + 6] = sa6; fino_attn_dbg[wave * 8 + 7] = sa7;
+    }
+#endif
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef QK_TILE
+#undef PP_LOAD
+#undef PP_WRITE
+#undef LDS_PTR
+#undef MASK_RAGGED
+#undef MAX8
+#undef MAX_FINISH1
+
+    // ---------------- epilogue: normalise, store O[q][d] ----------------
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (part >= 0) {
+        // partial: raw accumulators in thread order (coalesced), m and l per thread; attn_combine_kernel finishes
+        float* w = p.ws + (int64_t)part * partial_floats<D>();
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[(dt * 16 + j) * (kWaves * 64) + tid] = o[dt][j];
+        w[kDT * 16 * (kWaves * 64) + tid] = m_run;
+        w[kDT * 16 * (kWaves * 64) + kWaves * 64 + tid] = l_run;
+        continue;
+    }
+    const float inv = 1.0f / l_run;
+    if (qrow < p.lq) {
+        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
+                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+            }
+        }
+    }
+  }   // piece
+}
+
 // Merge the key-range partials of each tail block: m = max m_s, O = sum O_s 2^(m_s-m), l likewise; store bf16.
 template <typename T, int D>
 __global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnParams p) {
@@ -521,9 +910,15 @@ template <typename T, int D, int VAR>
 int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
     static bool attr_set = false;
+    static bool pingpong = true;
     if (!attr_set) {
+        const char* ev = getenv("FINO_ATTN_PP");          // A/B knob: 0 selects the one-barrier loop
+        pingpong = !(ev && ev[0] == '0') && kWaves == 8;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pp_kernel<T, D, VAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             fino_set_error("fino_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return FINO_ERR_LAUNCH;
@@ -543,7 +938,10 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     }
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
-    attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
+    if (pingpong)
+        attn_pp_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
+    else
+        attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     if (sp.rem_x > 0) {
         attn_combine_kernel<T, D><<<dim3((unsigned)(8 * sp.rem_x)), kWaves * 64, 0, st>>>(p);

@@ -27,7 +27,7 @@ for b, lq, lk in [(2, 12320, 12320), (1, 12320, 12320), (1, 3080, 12320), (2, 30
     kv = torch.randn(b, lk, 2 * D, device="cuda").bfloat16()
     o = torch.empty_like(q)
     res = []
-    for split in (False, True, False, True):
+    for split in (False, True, False, True):  # noqa
         ops.SPLIT_ATTENTION_TAIL = split
         t = timeit(lambda: ops.attention(q, kv[:, :, :D], kv[:, :, D:], H, out=o))
         res.append(4.0 * b * lq * lk * D / t / 1e12)
