@@ -201,6 +201,10 @@ def main():
                 one_step(i)
         sync()
         elapsed = time.perf_counter() - t0
+    if world > 1:                                     # MAX over ranks, before rank 0 goes off to time the VAE
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
     # ---- once-per-clip stages (rank 0, outside the timed region): Wan VAE encode of the conditions + decode ----
     vae_times = None
     if rank == 0 and a.workload != "tiny" and not a.no_vae:
@@ -220,10 +224,6 @@ def main():
                 torch.cuda.synchronize(); t3 = time.perf_counter()
         vae_times = (t2 - t1, t3 - t2)
         del vae, vid
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
     assert torch.isfinite(st.lat).all(), "non-finite latents"
 
     if rank == 0:
