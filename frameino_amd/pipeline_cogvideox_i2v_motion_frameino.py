@@ -67,6 +67,7 @@ class CogVideoXPipelineOutput(SimpleNamespace):
 
 class CogVideoXImageToVideoPipeline:
     _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+    extend_rope_by_first_frame = True             # :834-839 (the ID frame reuses the first frame's RoPE rows)
 
     def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None):
         self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
@@ -90,9 +91,10 @@ class CogVideoXImageToVideoPipeline:
         gw = width // (self.vae_scale_factor_spatial * c.patch_size)
         crops = get_resize_crop_region_for_grid((gh, gw), c.sample_width // c.patch_size, c.sample_height // c.patch_size)
         cos, sin = get_3d_rotary_pos_embed(c.attention_head_dim, crops, (gh, gw), num_frames)
-        n1 = cos.shape[0] // num_frames
-        cos = torch.cat([cos, cos[:n1]], dim=0)
-        sin = torch.cat([sin, sin[:n1]], dim=0)
+        if self.extend_rope_by_first_frame:
+            n1 = cos.shape[0] // num_frames
+            cos = torch.cat([cos, cos[:n1]], dim=0)
+            sin = torch.cat([sin, sin[:n1]], dim=0)
         return cos.to(device), sin.to(device)
 
     @torch.no_grad()

@@ -215,6 +215,13 @@ class WanImageToVideoPipeline:
     def prepare_latents(self, image, traj_tensor, ID_tensor, batch_size, num_channels_latents=16, height=480,
                         width=832, num_frames=81, dtype=None, device=None, generator=None, latents=None,
                         last_image=None):
+        """reference :400-553 (Wan2.2 / expand_timesteps branch)"""
+        return self._prepare_conditions(image, traj_tensor, ID_tensor, batch_size, num_channels_latents, height, width,
+                                        num_frames, dtype, device, generator, latents, last_image)
+
+    def _prepare_conditions(self, image, traj_tensor, ID_tensor, batch_size, num_channels_latents=16, height=480,
+                            width=832, num_frames=81, dtype=None, device=None, generator=None, latents=None,
+                            last_image=None):
         if last_image is not None:
             raise NotImplementedError("last_image is a Wan2.1 FLF2V feature, outside the FrameINO path")
         nlf = (num_frames - 1) // self.vae_scale_factor_temporal + 1
@@ -402,7 +409,7 @@ class WanImageToVideoPipeline:
             negative_prompt_embeds = negative_prompt_embeds.to(device=device, dtype=tdt)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         image = self.video_processor.preprocess(image, height=height, width=width).to(device, dtype=torch.float32)
-        latents, condition, traj_latents, id_cond, mask = self.prepare_latents(
+        latents, condition, traj_latents, id_cond, mask = self._prepare_conditions(
             image, traj_tensor, ID_tensor, batch_size * num_videos_per_prompt, self.vae.config.z_dim, height, width,
             num_frames, torch.float32, device, generator, latents, last_image)
         latents = self.denoise(latents, condition, traj_latents, id_cond, mask, prompt_embeds, negative_prompt_embeds,

@@ -29,11 +29,12 @@ def cog_denoise_loop(sd, cfg, latents, image_latents, traj_latents, id_latent, p
     lat = latents.clone()
     for t in ts.tolist():
         x = torch.cat([lat] * 2)
-        lid = torch.cat([id_latent] * 2)
-        pad = torch.zeros_like(lid)
-        x = torch.cat([x, lid], dim=1)                                             # :868
-        img = torch.cat([torch.cat([image_latents] * 2), pad], dim=1)
-        trj = torch.cat([torch.cat([traj_latents] * 2), pad], dim=1)
+        img, trj = torch.cat([image_latents] * 2), torch.cat([traj_latents] * 2)
+        if id_latent is not None:                                                  # stage 1 (no ID frame): skip
+            lid = torch.cat([id_latent] * 2)
+            pad = torch.zeros_like(lid)
+            x = torch.cat([x, lid], dim=1)                                         # :868
+            img, trj = torch.cat([img, pad], dim=1), torch.cat([trj, pad], dim=1)
         x = torch.cat([x, img, trj], dim=2)                                        # :880
         pred = cog_forward(sd, cfg, x, prompt, torch.full((2,), float(t)), rotary).float()[:, :nlf]
         g = guidance

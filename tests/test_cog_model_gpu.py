@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _model(golden):
+def _model(golden, name="cog_dit_tiny"):
     from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
-    cfg, sd, a = golden("cog_dit_tiny")
+    cfg, sd, a = golden(name)
     cfg = _cog_cfg(cfg)
     m = CogVideoXTransformer3DModel(**cfg).to(DEV)
     m.load_reference_state_dict(sd, dtype=torch.bfloat16)
@@ -40,6 +40,15 @@ def test_cog_forward_vs_reference_golden(golden, tag):
     r32, rb, rr = rel_rms(out, ref), rel_rms(out, refb), rel_rms(refb, ref)
     print(f"[{tag}] hip-vs-fp32 {r32:.4f}  hip-vs-bf16-oracle {rb:.4f}  bf16-oracle-vs-fp32 {rr:.4f}")
     assert r32 < 4e-2 and rb < 3e-2
+
+
+@pytest.mark.parametrize("tag", ["def", "rsz"])
+def test_cog_stage1_forward_vs_reference_golden(golden, tag):
+    """use_FrameIn=False (stage-1 motion model, pipeline_cogvideox_i2v_motion.py): plain joint PE, RoPE not extended."""
+    m, cfg, sd, a = _model(golden, "cog_dit_s1_tiny")
+    out = _run(m, a, tag)
+    r32 = rel_rms(out, a[f"y_{tag}"])
+    assert out.shape == a[f"y_{tag}"].shape and r32 < 4e-2, r32
 
 
 def test_fused_projections_and_custom_processor(golden):
@@ -87,3 +96,29 @@ def test_cog_denoise_loop_and_rope_prep_vs_golden(golden):
                            d("negative_embeds"), float(a["guidance"]), int(a["steps"]), use_dynamic_cfg=dyn)
         r = rel_rms(out, a[key])
         assert out.shape == a[key].shape and r < 6e-2, (key, r)
+
+
+def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):
+    """Stage-1 pipeline (pipelines/pipeline_cogvideox_i2v_motion.py): no ID frame, RoPE of exactly F frames, on the
+    use_FrameIn=False weights recorded from the reference; against the oracle loop (itself pinned by cog_loop_tiny)."""
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.pipeline_cogvideox_i2v_motion import CogVideoXImageToVideoPipeline
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    from oracle.cog_pipeline import cog_denoise_loop
+    cfg, sd, a = golden("cog_dit_s1_tiny")
+    cfg = _cog_cfg(cfg)
+    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDDIMScheduler())
+    cos, sin = pipe._prepare_rotary_positional_embeddings(64, 64, 3, "cpu")
+    torch.testing.assert_close(cos, a["cos_def"], atol=1e-6, rtol=1e-6)          # not extended
+    g = torch.Generator().manual_seed(7)
+    nlf, C, hh, ww = 3, 2, 8, 8
+    lat = torch.randn(1, nlf, C, hh, ww, generator=g)
+    img = torch.cat([torch.randn(1, 1, C, hh, ww, generator=g), torch.zeros(1, nlf - 1, C, hh, ww)], dim=1)
+    trj = torch.randn(1, nlf, C, hh, ww, generator=g)
+    pe, ne = torch.randn(1, 8, 16, generator=g), torch.randn(1, 8, 16, generator=g)
+    out = pipe.denoise(lat.to(DEV), img.to(DEV), trj.to(DEV), pe.to(DEV), ne.to(DEV), 6.0, 4)
+    ref = cog_denoise_loop(sd, cfg, lat, img, trj, None, pe, ne, (a["cos_def"], a["sin_def"]), 6.0, 4)
+    r = rel_rms(out, ref)
+    assert out.shape == ref.shape and r < 6e-2, r

@@ -132,6 +132,17 @@ def test_cog_forward_frame_in_default_and_resized_resolution(golden):
     torch.testing.assert_close(a["y_def_fused"], a["y_def"], atol=1e-5, rtol=1e-5)
 
 
+def test_cog_forward_stage1_no_frame_in(golden):
+    """Stage-1 motion model (use_FrameIn=False, pipelines/pipeline_cogvideox_i2v_motion.py; BASELINE config 1 class)."""
+    from oracle import cog_dit as C
+    cfg, sd, a = golden("cog_dit_s1_tiny")
+    cfg = _cog_cfg(cfg)
+    assert cfg["use_FrameIn"] is False
+    for tag in ("def", "rsz"):
+        out = C.cog_forward(sd, cfg, a[f"x_{tag}"], a[f"txt_{tag}"], a[f"ts_{tag}"], (a[f"cos_{tag}"], a[f"sin_{tag}"]))
+        torch.testing.assert_close(out, a[f"y_{tag}"], atol=5e-5, rtol=5e-5)
+
+
 def test_cog_denoise_loop_restatement(golden):
     from oracle.cog_pipeline import cog_denoise_loop, ddim_tables
     cfg, sd, a = golden("cog_loop_tiny")

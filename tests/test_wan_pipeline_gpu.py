@@ -141,3 +141,28 @@ def test_unipc_hip_graph_replay_equals_eager(golden):
     pipe.use_hip_graph = True
     graphed = _run(pipe, a)
     assert torch.equal(eager, graphed)
+
+
+def test_stage1_pipeline_no_id_frame_vs_oracle_loop(golden):
+    """pipelines/pipeline_wan_i2v_motion.py (stage 1): same loop without the identity frame; 4-tensor prepare_latents
+    and an `ID_tensor`-free `__call__` signature."""
+    import inspect
+    from frameino_amd.pipeline_wan_i2v_motion import WanImageToVideoPipeline as Stage1
+    from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from oracle.schedulers import FlowMatchEulerOracle
+    from oracle.wan_pipeline import wan_denoise_loop
+    pipe, a = _pipe(golden)
+    s1 = Stage1(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=pipe.transformer,
+                expand_timesteps=True)
+    assert "ID_tensor" not in inspect.signature(s1.__call__).parameters
+    assert "ID_tensor" not in inspect.signature(s1.prepare_latents).parameters
+    d = lambda k: a[k].to(DEV)                    # noqa: E731
+    nf = a["latents0"].shape[2]
+    traj = a["traj_latents"][:, :, :nf]           # no zero padding for an ID frame
+    out = s1.denoise(d("latents0"), d("condition"), traj.to(DEV), None, d("mask"), d("prompt_embeds"),
+                     d("negative_embeds"), float(a["guidance"]), 3)
+    cfg, sd, _ = golden("wan_pipe_tiny")
+    dit_sd = {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}
+    ref = wan_denoise_loop(dit_sd, cfg, FlowMatchEulerOracle(shift=5.0), a["latents0"], a["condition"], traj, None,
+                           a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), 3)
+    assert rel_rms(out, ref) < 5e-2

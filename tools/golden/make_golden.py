@@ -252,6 +252,32 @@ def gen_cog_dit():
     save("cog_dit_tiny", cfg=COG_TINY, sd=sd, **arrays)
 
 
+def gen_cog_dit_s1():
+    """Stage-1 CogVideoX motion model (pipelines/pipeline_cogvideox_i2v_motion.py: `use_FrameIn=False`, no ID frame,
+    RoPE not extended) -- BASELINE config 1's shape class -- at the default and a resized resolution."""
+    from architecture.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from architecture.embeddings import get_3d_rotary_pos_embed
+    cfg = dict(COG_TINY, use_FrameIn=False)
+    torch.manual_seed(0)
+    m = CogVideoXTransformer3DModel(**cfg).eval()
+    randomize_(m, 51, std=0.15)
+    with torch.no_grad():
+        m.patch_embed.pos_embedding.copy_(torch.randn(m.patch_embed.pos_embedding.shape,
+                                                      generator=torch.Generator().manual_seed(52)) * 0.3)
+    g = torch.Generator().manual_seed(53)
+    arrays = {}
+    for tag, (hh, ww) in (("def", (8, 8)), ("rsz", (8, 12))):
+        x = torch.randn(2, 3, 6, hh, ww, generator=g)
+        txt = torch.randn(2, 8, 16, generator=g)
+        ts = torch.tensor([401.0, 401.0])
+        cos, sin = get_3d_rotary_pos_embed(64, ((0, 0), (hh // 2, ww // 2)), (hh // 2, ww // 2), 3)
+        y = m(hidden_states=x, encoder_hidden_states=txt, timestep=ts, image_rotary_emb=(cos, sin),
+              return_dict=False)[0]
+        arrays.update({f"x_{tag}": x, f"txt_{tag}": txt, f"ts_{tag}": ts, f"cos_{tag}": cos, f"sin_{tag}": sin,
+                       f"y_{tag}": y})
+    save("cog_dit_s1_tiny", cfg=cfg, sd=dict(m.state_dict()), **arrays)
+
+
 def gen_cog_loop():
     """G10 (Cog): the denoise loop of pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944 re-created around
     the REFERENCE transformer (latents passed explicitly; the third-party CogVideoX VAE is not available offline, so
@@ -307,7 +333,7 @@ def gen_cog_loop():
 
 
 GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae, "cog_dit": gen_cog_dit,
-        "cog_loop": gen_cog_loop}
+        "cog_dit_s1": gen_cog_dit_s1, "cog_loop": gen_cog_loop}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
