@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wan2.2-5b-49f-704x1280", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--cfg-streams", action="store_true", help="CFG branches on two concurrent streams (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the once-per-clip VAE encode/decode timing")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
@@ -145,6 +146,7 @@ def main():
         from frameino_amd.parallel import shard_pipeline
         shard_pipeline(pipe, rank, world)
     pipe.use_hip_graph = a.graph
+    pipe.cfg_streams = a.cfg_streams
 
     g = torch.Generator().manual_seed(1234)           # CPU generator, then copy
     lat = torch.randn(1, C, fg, lh, lw, generator=g).to(dev)

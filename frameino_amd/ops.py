@@ -163,9 +163,10 @@ def _attention_workspace(b, heads, lq, lk, dh, device):
     need = _lib.lib().fino_attn_workspace_bytes(b, heads, lq, lk, dh)
     if need <= 0:
         return None, 0
-    ws = _attn_ws.get(device.index)
+    key = (device.index, torch.cuda.current_stream().cuda_stream)       # concurrent streams must not share partials
+    ws = _attn_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
-        ws = _attn_ws[device.index] = torch.empty(need // 4, dtype=torch.float32, device=device)
+        ws = _attn_ws[key] = torch.empty(need // 4, dtype=torch.float32, device=device)
     return ws, need
 
 

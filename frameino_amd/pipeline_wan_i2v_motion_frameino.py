@@ -89,6 +89,8 @@ class WanImageToVideoPipeline:
         self.video_processor = VideoProcessor(vae_scale_factor=self.vae_scale_factor_spatial)
         self.use_hip_graph = False
         self.batch_cfg = True            # run cond+uncond as one batch-2 forward when not CFG-parallel
+        self.cfg_streams = False         # ... or as two B=1 forwards on two concurrent streams (takes precedence)
+        self._streams = None
         self._interrupt = False
         self._graph = None
 
@@ -270,6 +272,22 @@ class WanImageToVideoPipeline:
             # CFG branches on two rank groups; one exchange of noise_pred per step (frameino_amd/parallel.py)
             mine = fwd("cond", st.pe) if plan.cfg_idx == 0 else fwd("uncond", st.ne)
             pc, pu = plan.exchange_cfg(mine)
+        elif st.cfg and self.cfg_streams and getattr(tr, "parallel", None) is None:
+            # the two CFG branches as two concurrent kernel streams: each branch's launches are 2.3-10.7 "rounds" of
+            # workgroups over the 256 CUs, and the CUs that one branch's last partial round leaves idle take the
+            # other branch's workgroups (same for the synchronized epilogue bursts)
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            main = torch.cuda.current_stream()
+            s1, s2 = self._streams
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                pc = fwd("cond", st.pe)
+            with torch.cuda.stream(s2):
+                pu = fwd("uncond", st.ne)
+            main.wait_stream(s1)
+            main.wait_stream(s2)
         elif st.cfg and self.batch_cfg and st.pe_ne is not None and getattr(tr, "parallel", None) is None:
             # both CFG branches as ONE batch-2 forward (rows of the same GEMMs: identical per-row arithmetic, twice
             # the tiles per launch, weights streamed once).  The reference makes two calls (:862-882).

@@ -205,7 +205,8 @@ class WanTransformer3DModel(nn.Module):
         return pk
 
     def _workspace(self, L, dtype, device):
-        key = (L, dtype, str(device))
+        # one workspace per (shape, cache_context name): the two CFG branches may run concurrently on two streams
+        key = (L, dtype, str(device), self._ctx_name)
         ws = self._ws.get(key)
         if ws is None:
             d, f = self.inner_dim, self.config.ffn_dim
@@ -213,7 +214,8 @@ class WanTransformer3DModel(nn.Module):
             ws = SimpleNamespace(x=mk(L, d), n=mk(L, d), qkv=mk(L, 3 * d), att=mk(L, d), q2=mk(L, d), ff=mk(L, f),
                                  a=mk(L, self.config.in_channels * math.prod(self.config.patch_size)),
                                  po=mk(L, self.config.out_channels * math.prod(self.config.patch_size)))
-            self._ws = {key: ws}
+            self._ws = {k: v for k, v in self._ws.items() if k[:3] == key[:3]}      # drop other shapes, keep branches
+            self._ws[key] = ws
         return ws
 
     def _rope(self, ppf, pph, ppw, device):
