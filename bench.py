@@ -251,11 +251,11 @@ def main():
         ks = timer.summary().get("attn_self") if not a.graph else None
         heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
         if ks:
-            traffic, traffic_src = profiled_traffic("attn_fwd_kernel<BF16, 128, 0>")
+            traffic, traffic_src = profiled_traffic("attn_pp_kernel<BF16, 128, 0>")
             # algorithmic FLOPs of the timed launches (4.Lq.Lk.H.Dh per batch element) / their summed duration
             total_fl = timer.flops["attn_self"]
             ach = total_fl / (ks["total_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<BF16,128,0> (3D self-attention)",
+            out["roofline"] = {"bound": "mfma", "kernel": "attn_pp_kernel<BF16,128,0> (3D self-attention)",
                                "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "launches": ks["launches"], "avg_us": ks["avg_us"],
