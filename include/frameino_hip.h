@@ -200,6 +200,19 @@ int fino_vae_unpatchify_clamp(const void* y, float* out, int t, int h, int w, in
 int fino_vae_patchify(const float* x, void* y, int t, int h, int w, int c_pad, int channels, int patch, int dtype,
                       void* stream);
 
+/* ---- condition builders in front of the path ---------------------------------------------------------
+ * Trajectory video of data_loader/video_dataset_motion.py:120-206 (`prepare_traj_tensor`, app.py:616-620).
+ * fino_traj_paint: canvas fp32 [frames, 3, H, W] = 255, then for every frame its points, in order, paint the square
+ *   [y-r, y+r) x [x-r, x+r) clipped to the canvas with their colour (:146-160; points outside the canvas skipped).
+ *   points int32 [n, 4] = (x, y, r | g<<8 | b<<16, 0) sorted by frame; frame_offsets int32 [frames+1] (CSR).
+ * fino_traj_blur_quantize: separable `taps`-tap blur with BORDER_REFLECT_101 (the 45x45 isotropic Gaussian of :29 is
+ *   the outer product of its normalised 1-D factor; cv2.filter2D :172 is third-party and absent offline), truncation
+ *   to uint8 (numpy astype :172) and x/255*2-1 (:39-42).  canvas/scratch/out fp32 [planes, H, W]. */
+int fino_traj_paint(const int32_t* points, const int32_t* frame_offsets, float* canvas, int frames, int height, int width,
+                    int radius, void* stream);
+int fino_traj_blur_quantize(const float* canvas, float* scratch, float* out, const float* taps_dev, int taps, int planes,
+                            int height, int width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

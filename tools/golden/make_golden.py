@@ -278,6 +278,18 @@ def gen_cog_dit_s1():
     save("cog_dit_s1_tiny", cfg=cfg, sd=dict(m.state_dict()), **arrays)
 
 
+def gen_traj_kernel():
+    """The blur kernel of the trajectory-video builder (data_loader/video_dataset_motion.py:29) from the reference's own
+    function (utils/optical_flow_utils.py:197-219).  The builder itself imports cv2 (absent offline) and cannot run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ofu", "/root/reference/utils/optical_flow_utils.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    k = m.bivariate_Gaussian(45, 3, 3, 0, grid=None, isotropic=True)
+    np.savez_compressed(os.path.join(OUT, "traj_kernel.npz"), kernel=k)
+    print("wrote traj_kernel.npz", k.shape, k.dtype)
+
+
 def gen_cog_loop():
     """G10 (Cog): the denoise loop of pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944 re-created around
     the REFERENCE transformer (latents passed explicitly; the third-party CogVideoX VAE is not available offline, so
@@ -333,7 +345,7 @@ def gen_cog_loop():
 
 
 GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae, "cog_dit": gen_cog_dit,
-        "cog_dit_s1": gen_cog_dit_s1, "cog_loop": gen_cog_loop}
+        "cog_dit_s1": gen_cog_dit_s1, "cog_loop": gen_cog_loop, "traj_kernel": gen_traj_kernel}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
