@@ -166,3 +166,15 @@ def test_stage1_pipeline_no_id_frame_vs_oracle_loop(golden):
     ref = wan_denoise_loop(dit_sd, cfg, FlowMatchEulerOracle(shift=5.0), a["latents0"], a["condition"], traj, None,
                            a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), 3)
     assert rel_rms(out, ref) < 5e-2
+
+
+def test_example_script_smoke():
+    """examples/run_wan_frameino.py --smoke: condition builder -> VAE encodes -> UniPC loop -> VAE decode, tiny shapes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_wan_frameino.py"), "--smoke"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "clip (5 frames 64x96" in r.stdout
