@@ -9,9 +9,12 @@
 //   * O^T = V^T.P^T: the S^T accumulator registers, packed to bf16, ARE the B operand of the second product
 //     (k-order permuted: element j of half h is key 16s + 8(j>>2) + 4h + (j&3)); V^T comes from LDS through
 //     ds_read_b64_tr_b16 in the same permuted order -- no cross-lane movement of P, no LDS round trip for P.
-//   * K/V tiles of 64 keys are register-staged (global_load_dwordx4 issued before the tile's math, ds_write_b128
-//     after it) into a double-buffered, XOR-swizzled LDS image that is conflict-free for both the row reads (K)
-//     and the transposed reads (V); one barrier per tile.
+//   * K/V tiles of 64 keys are register-staged (buffer/global_load_dwordx4, then ds_write_b128) into a double-buffered,
+//     XOR-swizzled LDS image that is conflict-free for both the row reads (K) and the transposed reads (V).
+//   * Two main loops: attn_pp_kernel (default) -- PING-PONG: the two waves of a SIMD alternate a softmax phase and a
+//     32-MFMA matrix phase, one phase apart, two barriers per tile -- and attn_fwd_kernel, the earlier one-barrier
+//     loop in which every wave interleaves S(t+1) MFMAs with the exp of S(t) (FINO_ATTN_PP=0, kept for A/B).
+//   * Tail split: the key tiles of an XCD's last, partial round of blocks are dealt to all its CUs (fino_attn_fwd_ws).
 //   * q/k/v are read in place from the fused-QKV GEMM output ([L, 3*H*Dh], strides passed in), o is written
 //     token-major [L, H*Dh]: no transposes anywhere.
 //   * blockIdx -> (head, q-block) is XCD-aware: all q-blocks of a head share blockIdx%8, i.e. one XCD's L2 holds
@@ -30,10 +33,7 @@ extern "C" int fino_attn_debug_read(unsigned long long* out) {
 #define ASTAMP(V_)
 #endif
 
-#ifndef FINO_ATTN_WAVES
-#define FINO_ATTN_WAVES 8
-#endif
-#define FINO_ATTN_WAVES_DEFAULT FINO_ATTN_WAVES
+#define FINO_ATTN_WAVES 8      // waves per workgroup (4 waves x 2 workgroups per CU measured slower: 853 vs 935 TFLOP/s)
 
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float d;
@@ -66,7 +66,7 @@ struct AttnParams {
 
 // floats per partial: O^T accumulators in thread order + per-thread m and l
 template <int D>
-constexpr int64_t partial_floats() { return (int64_t)(D / 32) * 16 * (FINO_ATTN_WAVES_DEFAULT * 64) + 2 * (FINO_ATTN_WAVES_DEFAULT * 64); }
+constexpr int64_t partial_floats() { return (int64_t)(D / 32) * 16 * (FINO_ATTN_WAVES * 64) + 2 * (FINO_ATTN_WAVES * 64); }
 
 constexpr int kQRowsPerWave = 32;
 constexpr int kWaves = FINO_ATTN_WAVES;   // waves (32 query rows each) per workgroup
@@ -166,27 +166,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     int st_off[kLoadsPerThread];
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; ++i) st_off[i] = lds_off<D>(st_row[i], st_ch[i]);
-#ifdef FINO_ATTN_DMA
-    // LDS-DMA staging: wave-instruction wi = wave + 8*i writes 1 KiB (lane-linear) = 1024/rowbytes tile rows; the
-    // XOR swizzle goes on the per-lane SOURCE chunk (same involution as the reads).
-    constexpr int kRowsPerInstr = 1024 / (D * 2);
-    int dma_row[kLoadsPerThread], dma_ch[kLoadsPerThread];
-#pragma unroll
-    for (int i = 0; i < kLoadsPerThread; ++i) {
-        const int wi = wave + kWaves * i;
-        dma_row[i] = wi * kRowsPerInstr + lane / kChunksPerRow;
-        const int cphys = lane % kChunksPerRow;
-        dma_ch[i] = (lds_off<D>(dma_row[i], cphys) - dma_row[i] * D * 2) >> 4;   // logical chunk stored at cphys
-    }
-#define DMA_TILE(BASE_PTR_, ROW_STRIDE_, T_, SLOT_)                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                              \
-        int row_ = (T_) * kKV + dma_row[i_];                                                                      \
-        row_ = row_ < lk ? row_ : lk - 1;                                                                     \
-        __builtin_amdgcn_global_load_lds(                                                                         \
-            (const FINO_GLB void*)((BASE_PTR_) + (int64_t)row_ * (ROW_STRIDE_) + dma_ch[i_] * 8),                 \
-            (FINO_LDS void*)(smem + (SLOT_) * kTileBytes + (wave + kWaves * i_) * 1024), 16, 0, 0);               \
-    }
-#endif
 #define STAGE_LOAD(T_)                                                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
         int row_ = (T_) * kKV + st_row[i_];                                                           \
@@ -233,17 +212,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     // while the VALU does the softmax of S(t); then O += V(t)^T.P(t).  LDS: K[2] ring + V[2] ring; K(t+2) and
     // V(t+1) travel global -> registers during the iteration and are written to LDS at its end; 1 barrier / tile.
     const int nt = (lk + kKV - 1) / kKV;
-#ifdef FINO_ATTN_DMA
-    DMA_TILE(kp, p.k_rs, 0, 0)
-    DMA_TILE(vp, p.v_rs, 0, 2)
-    if (nt > 1) { DMA_TILE(kp, p.k_rs, 1, 1) }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (false) {
-#else
     STAGE_LOAD(0)
     STAGE_WRITE(0)
     if (nt > 1) {
-#endif
         // K(1) only
 #pragma unroll
         for (int i = 0; i < kLoadsPerThread; ++i) {
@@ -257,10 +228,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
 
     f32x16_t sc0, sc1;   // S(t)
     QK_TILE(0, sc0, sc1)
-#ifdef FINO_ATTN_PRIO
-    // static priority for the later-dispatched half (waves 4-7 lose VALU arbitration to their SIMD partners otherwise)
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // row max of a tile (query on the lane; partner half-wave holds the other 32 keys) -> MX_
 #define ROW_MAX(S0_, S1_, MX_)                                                                               \
@@ -300,11 +267,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
         const int cur = t & 1;                                                                               \
         ASTAMP(ts0)                                                                                          \
         /* global -> registers: K(t+2), V(t+1) (clamped rows; dead data is never written to LDS) */          \
-        if (HAS_NEXT_ && kDma) {                                                                             \
-            DMA_TILE_OR_NOTHING(kp, p.k_rs, t + 2, cur)                                                      \
-            DMA_TILE_OR_NOTHING(vp, p.v_rs, t + 1, 2 + (cur ^ 1))                                            \
-        }                                                                                                    \
-        if (HAS_NEXT_ && !kDma) {                                                                            \
+        if (HAS_NEXT_) {                                                                            \
             _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i) {                                    \
                 int rk = (t + 2) * kKV + st_row[i];                                                          \
                 int rv = (t + 1) * kKV + st_row[i];                                                          \
@@ -362,15 +325,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
             ROW_MAX(sn0, sn1, mxn)                                                                           \
             ASTAMP(ts2)                                                                                      \
             /* registers -> LDS: K(t+2) into the K slot S(t) came from, V(t+1) into the other V slot */      \
-            if (!kDma && t + 2 < nt) {                                                                       \
+            if (t + 2 < nt) {                                                                       \
                 _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
                     *reinterpret_cast<u32x4_t*>(smem + cur * kTileBytes + st_off[i]) = kreg[i];              \
             }                                                                                                \
-            if (!kDma) {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
-                    *reinterpret_cast<u32x4_t*>(smem + (2 + (cur ^ 1)) * kTileBytes + st_off[i]) = vreg[i];  \
-            }                                                                                                \
-            if (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+            _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                      \
+                *reinterpret_cast<u32x4_t*>(smem + (2 + (cur ^ 1)) * kTileBytes + st_off[i]) = vreg[i];      \
             sc0 = sn0;                                                                                       \
             sc1 = sn1;                                                                                       \
             MAYBE_RESCALE(mxn)                                                                               \
@@ -382,13 +342,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     }
 
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
-#ifdef FINO_ATTN_DMA
-    constexpr bool kDma = true;
-#define DMA_TILE_OR_NOTHING(A_, B_, C_, D_) DMA_TILE(A_, B_, C_, D_)
-#else
-    constexpr bool kDma = false;
-#define DMA_TILE_OR_NOTHING(A_, B_, C_, D_)
-#endif
 #ifdef FINO_ATTN_STAMP
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
 #define ASTAMP_ACC { sa0 += ts1 - ts0; sa1 += ts2 - ts1; sa2 += ts3 - ts2; sa3 += ts4 - ts3; }
