@@ -397,11 +397,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 // Phases are separated by s_barrier, so the matrix pipe of each SIMD always has exactly one wave feeding it and the
 // age-based arbitration between co-resident waves (the older wave starving the younger, then idling at the barrier:
 // 2840 cycles per K-tile measured on the one-barrier loop against 2048 of MFMA) has nothing to arbitrate.
-//   phase 2t   : G0 LOAD(t)  + DMA {A rows 0-127, W} of tile t+1     | G1 COMPUTE(t-1) (+ WC pieces of W(t+1))
+//   phase 2t   : G0 LOAD(t)  + DMA {A rows 0-127, W} of tile t+1     | G1 COMPUTE(t-1)
 //   phase 2t+1 : G0 COMPUTE(t)                                        | G1 LOAD(t) + DMA {A rows 128-255} of tile t+1
 // LDS: two 64-KiB stages.  Stage (t+1)%2 held tile t-1: its A half of a group is dead after that group's LOAD(t-1),
 // its W after G1's LOAD(t-1) (phase 2t-1), so every DMA above starts in a free region and has >= one whole phase to land.
-template <typename T, int EPI, int WC>
+// (Moving 2 or 4 of G0's eight W pieces per wave into G1's COMPUTE phase was measured: no difference.)
+template <typename T, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::vec8 vec8;
@@ -501,16 +502,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
             for (int q = 0; q < 4; ++q) PP_DMA_A(cur ^ 1, t + 1, q)
             if (wm == 0) {
 #pragma unroll
-                for (int q = 0; q < 8 - WC; ++q) PP_DMA_W(cur ^ 1, t + 1, q)
+                for (int q = 0; q < 8; ++q) PP_DMA_W(cur ^ 1, t + 1, q)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (WC > 0 && wm == 1) {
-            // my W pieces of tile t+1 (issued in COMPUTE(t-1)) are older than the 4 A pieces just issued
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PSTAMP(t1)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -520,7 +516,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (WC > 0 && wm == 1 && t + 2 < nk && (kk * 8 + i) < WC) PP_DMA_W(cur, t + 2, 8 - WC + kk * 8 + i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
@@ -528,11 +523,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (WC > 0 && wm == 1) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC) : "memory");     // my A pieces of tile t+1; W(t+2) stays in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my pieces of tile t+1, issued one phase ago
         PSTAMP(t3)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -572,14 +563,11 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
-#ifndef FINO_GEMM_PP_WC
-#define FINO_GEMM_PP_WC 0
-#endif
 template <typename T, int EPI>
 int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, FINO_GEMM_PP_WC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         if (e != hipSuccess) {
             fino_set_error("fino_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -587,7 +575,7 @@ int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    gemm_pp_kernel<T, EPI, FINO_GEMM_PP_WC><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    gemm_pp_kernel<T, EPI><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
