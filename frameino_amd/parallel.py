@@ -46,7 +46,12 @@ class TokenShard:
 
     def _all_gather(self, key, t, async_op):
         out = self._get(key, (self.ways * t.shape[0],) + tuple(t.shape[1:]), t.dtype, t.device)
-        if dist.get_backend(self.group) == "gloo":           # CPU tests
+        if dist.get_backend(self.group) == "gloo":           # tests: CPU tensors, or device tensors staged via host
+            if t.is_cuda:
+                parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.ways)]
+                dist.all_gather(parts, t.cpu().contiguous(), group=self.group)
+                out.copy_(torch.cat(parts).to(t.device))
+                return out, None
             parts = list(out.chunk(self.ways))
             dist.all_gather(parts, t.contiguous(), group=self.group)
             return out, None
@@ -79,7 +84,12 @@ class ParallelPlan:
         if self._buf is None or self._buf.shape[1:] != mine.shape or self._buf.dtype != mine.dtype:
             self._buf = torch.empty((2,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
         if dist.get_backend(self.cfg_group) == "gloo":
-            dist.all_gather([self._buf[0], self._buf[1]], mine.contiguous(), group=self.cfg_group)
+            if mine.is_cuda:                                 # tests on one GPU: stage through host memory
+                parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(2)]
+                dist.all_gather(parts, mine.cpu().contiguous(), group=self.cfg_group)
+                self._buf.copy_(torch.stack(parts).to(mine.device))
+            else:
+                dist.all_gather([self._buf[0], self._buf[1]], mine.contiguous(), group=self.cfg_group)
         else:
             dist.all_gather_into_tensor(self._buf, mine.contiguous(), group=self.cfg_group)
         return self._buf[0], self._buf[1]
