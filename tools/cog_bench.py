@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Second backbone at BASELINE config 5's shape, in bf16 (the fp8 path is not built): CogVideoX-5B FrameINO,
+49 frames 480x720 -> model input [2, 14, 48, 60, 90] (CFG-batched, one ID frame), L = 226 + 18900 joint tokens,
+42 layers, 48 heads x 64.  Random-init weights on the device, synthetic latents; one step = the B=2 forward + guidance +
+v-prediction DDIM update (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944).  GPU box only."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+COG5B = dict(num_attention_heads=48, attention_head_dim=64, in_channels=48, out_channels=16, flip_sin_to_cos=True,
+             freq_shift=0, time_embed_dim=512, text_embed_dim=4096, num_layers=42, sample_width=90, sample_height=60,
+             sample_frames=49, patch_size=2, temporal_compression_ratio=4, max_text_seq_length=226,
+             norm_elementwise_affine=True, norm_eps=1e-5, use_rotary_positional_embeddings=True,
+             use_learned_positional_embeddings=True, use_FrameIn=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=None)
+    a = ap.parse_args()
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    cfg = dict(COG5B)
+    if a.layers:
+        cfg["num_layers"] = a.layers
+    dev = torch.device("cuda")
+    with torch.device("meta"):
+        m = CogVideoXTransformer3DModel(**cfg)
+    m = m.to_empty(device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            t = 0.02 * torch.randn(p.shape, generator=g, device=dev)
+            if name.endswith("norm.weight") or "norm_q.weight" in name or "norm_k.weight" in name:
+                t = 1.0 + t
+            p.data = t.bfloat16()
+        for name, b in m.named_buffers():
+            b.data = (0.02 * torch.randn(b.shape, generator=g, device=dev)).to(b.dtype)
+    m = m.eval()
+    pipe = CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())
+    F, C, h, w = 13, 16, 60, 90
+    lat = torch.randn(1, F, C, h, w, device=dev, generator=g)
+    img = torch.cat([torch.randn(1, 1, C, h, w, device=dev, generator=g), torch.zeros(1, F - 1, C, h, w, device=dev)], 1)
+    trj = torch.randn(1, F, C, h, w, device=dev, generator=g)
+    idl = torch.randn(1, 1, C, h, w, device=dev, generator=g)
+    pe = torch.randn(1, 226, 4096, device=dev, generator=g)
+    ne = torch.randn(1, 226, 4096, device=dev, generator=g)
+    total = a.warmup + a.steps
+    seen = []
+
+    def cb(p, i, t, kw):
+        torch.cuda.synchronize()
+        seen.append(time.perf_counter())
+        return {}
+
+    pipe.denoise(lat, img, trj, idl, pe, ne, 6.0, total, callback_on_step_end=cb)
+    dt = (seen[-1] - seen[a.warmup - 1]) / a.steps if a.warmup else (seen[-1] - seen[0]) / (a.steps - 1)
+    L, d, nl = 226 + 14 * 30 * 45, 3072, cfg["num_layers"]
+    flops = 2 * nl * (8 * L * d * d + 4 * L * L * d + 16 * L * d * d)          # B=2: proj + SDPA + FFN (4x)
+    print(f"CogVideoX-5B FrameINO 49f 480x720 bf16: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
+          f"{flops / dt / 1e12:.0f} TFLOP/s model ({nl} layers, L={L})")
+
+
+if __name__ == "__main__":
+    main()
