@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--workload", default="wan2.2-5b-49f-704x1280", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--cfg-streams", action="store_true", help="CFG branches on two concurrent streams (A/B)")
+    ap.add_argument("--plan", choices=["auto", "split", "interleave"], default="auto",
+                    help="N>1: cfg x token split, both CFG branches interleaved on token shards, or probe both (>= 4 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the once-per-clip VAE encode/decode timing")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
@@ -118,11 +120,16 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    backend = os.environ.get("FINO_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 flow on fewer GPUs than ranks
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from frameino_amd import _lib, ops
     _lib.load()                                   # no fallback: fail here if the HIP library is missing
@@ -142,9 +149,15 @@ def main():
     model = build_model(cfg, dev)
     pipe = WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=model,
                                    expand_timesteps=True)
+    plans = {}
     if world > 1:
-        from frameino_amd.parallel import shard_pipeline
-        shard_pipeline(pipe, rank, world)
+        from frameino_amd.parallel import make_plan, shard_pipeline
+        # every rank creates every communicator, in the same order
+        if a.plan in ("auto", "split"):
+            plans["split"] = make_plan(rank, world, True, "split")
+        if a.plan == "interleave" or (a.plan == "auto" and world >= 4):
+            plans["interleave"] = make_plan(rank, world, mode="interleave")
+        shard_pipeline(pipe, rank, world, plan=next(iter(plans.values())))
     pipe.use_hip_graph = a.graph
     pipe.cfg_streams = a.cfg_streams
 
@@ -188,6 +201,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if len(plans) > 1:
+        # probe: one warm + two timed steps per plan on this node, MAX over ranks, keep the faster plan.  (With one
+        # CFG branch per rank nothing can overlap the K|V all-gather; with both branches per rank it can hide, at
+        # the price of smaller GEMMs -- which wins depends on the node's xGMI, so it is measured, not assumed.)
+        snap = st.lat.clone()
+        best = None
+        with torch.no_grad():
+            for name, plan in plans.items():
+                shard_pipeline(pipe, rank, world, plan=plan)
+                st.t_rows[1:2].copy_(ts[0:1])
+                st.dt.copy_(dts[0:1])
+                pipe._step(st)
+                sync()
+                t0 = time.perf_counter()
+                pipe._step(st)
+                pipe._step(st)
+                sync()
+                tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                if rank == 0:
+                    print(f"[bench] plan {plan.desc}: {tt.item() / 2 * 1e3:.1f} ms/step (probe)", file=sys.stderr, flush=True)
+                if best is None or tt.item() < best[0]:
+                    best = (tt.item(), plan)
+                st.lat.copy_(snap)
+        shard_pipeline(pipe, rank, world, plan=best[1])
     with torch.no_grad():
         for i in range(a.warmup):
             if a.graph and i == 0:

@@ -181,7 +181,7 @@ def attention(q, k, v, heads, out=None, scale=None):
     if out is None:
         out = torch.empty((b, lq, hd), dtype=q.dtype, device=q.device)
     scale = dh ** -0.5 if scale is None else scale
-    ev = _timed("attn_self" if lq == lk else "attn_cross")
+    ev = _timed("attn_self" if lk > 1024 else "attn_cross")      # same rule as the kernel symbols (VAR 0 / 1)
     ws, ws_bytes = _attention_workspace(b, heads, lq, lk, dh, q.device) if SPLIT_ATTENTION_TAIL else (None, 0)
     _lib.check(_lib.lib().fino_attn_fwd_ws(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh,
                                           q.stride(0), q.stride(1), dh, k.stride(0), k.stride(1), dh,
@@ -190,7 +190,7 @@ def attention(q, k, v, heads, out=None, scale=None):
     if ev is not None:
         ev.record()
         kt_ = KernelTimer.active
-        nm = "attn_self" if lq == lk else "attn_cross"
+        nm = "attn_self" if lk > 1024 else "attn_cross"
         kt_.flops[nm] = kt_.flops.get(nm, 0.0) + 4.0 * b * lq * lk * hd      # 4.Lq.Lk.(H.Dh) per batch element
     return out
 

@@ -11,8 +11,15 @@ The reference has no multi-GPU inference path; this is new des
 * **CFG branches** -- the cond and uncond forwards of a step are independent; with an even number of ranks they run on
   two rank groups that exchange `noise_pred` once per step (no per-layer traffic).
 
-`shard_pipeline(pipe, rank, world)` picks cfg x token = 2 x (world/2) for even `world`, else 1 x world.  Latents and
-the sampler state are replicated (2.2 M floats); every rank performs the same CFG+Euler update.
+* **interleaved branches** (`mode="interleave"`) -- every rank holds BOTH CFG branches on a 1/world token shard and
+  advances them alternately, block by block, on two HIP streams with two communicators: the branches are the only
+  independent work of a denoising step, so this is what lets one branch's K|V all-gather fly under the other branch's
+  GEMMs and attention instead of standing in front of its own (with one branch per rank nothing can overlap it: the
+  gather is ~1.1 ms per layer on one xGMI link pair at 4 GPUs against ~2.8 ms of compute).
+
+`shard_pipeline(pipe, rank, world)` picks cfg x token = 2 x (world/2) for even `world`, else 1 x world; `mode=` selects
+the interleaved plan (bench.py probes both on the node and keeps the faster).  Latents and the sampler state are
+replicated (2.2 M floats); every rank performs the same CFG+Euler update.
 """
 import torch
 import torch.distributed as dist
@@ -67,16 +74,21 @@ class TokenShard:
 
 
 class ParallelPlan:
-    def __init__(self, rank, world, cfg_ways, token_ways, token_group, cfg_group):
+    def __init__(self, rank, world, cfg_ways, token_ways, token_group, cfg_group, token_group_b=None):
         self.rank, self.world = rank, world
         self.cfg_ways, self.token_ways = cfg_ways, token_ways
         self.cfg_idx, self.tok_rank = rank // token_ways, rank % token_ways
         self.token_group, self.cfg_group = token_group, cfg_group
         self.shard = TokenShard(self.tok_rank, token_ways, token_group)
+        # interleaved plan: a second shard object (own buffers, own communicator) for the second CFG branch
+        self.interleave = token_group_b is not None
+        self.shards = (self.shard, TokenShard(self.tok_rank, token_ways, token_group_b)) if self.interleave else None
         self._buf = None
 
     @property
     def desc(self):
+        if self.interleave:
+            return f"token{self.token_ways}x2branches-interleaved"
         return f"cfg{self.cfg_ways}xtoken{self.token_ways}"
 
     def exchange_cfg(self, mine):
@@ -95,7 +107,13 @@ class ParallelPlan:
         return self._buf[0], self._buf[1]
 
 
-def make_plan(rank, world, cfg_parallel=True):
+def make_plan(rank, world, cfg_parallel=True, mode="split"):
+    if mode == "interleave":
+        if world < 2:
+            raise ValueError("the interleaved plan needs at least 2 ranks")
+        ga = dist.new_group(list(range(world)))      # one communicator per branch: their collectives are independent
+        gb = dist.new_group(list(range(world)))
+        return ParallelPlan(rank, world, 1, world, ga, None, token_group_b=gb)
     cfg_ways = 2 if (cfg_parallel and world % 2 == 0) else 1
     token_ways = world // cfg_ways
     token_group = cfg_group = None
@@ -113,8 +131,8 @@ def make_plan(rank, world, cfg_parallel=True):
     return ParallelPlan(rank, world, cfg_ways, token_ways, token_group, cfg_group)
 
 
-def shard_pipeline(pipe, rank, world, cfg_parallel=True):
-    plan = make_plan(rank, world, cfg_parallel)
+def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None):
+    plan = plan or make_plan(rank, world, cfg_parallel, mode)
     pipe.parallel = plan
     pipe.parallel_desc = plan.desc
     pipe.token_shards = plan.token_ways

@@ -66,6 +66,11 @@ class VideoProcessor:
         raise ValueError(f"unsupported output_type {output_type}")
 
 
+import contextlib as _contextlib
+
+_null_ctx = _contextlib.nullcontext
+
+
 class WanPipelineOutput(SimpleNamespace):
     pass
 
@@ -268,7 +273,36 @@ class WanImageToVideoPipeline:
                           attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0][0]
 
         plan = getattr(self, "parallel", None)
-        if plan is not None and plan.cfg_ways == 2 and st.cfg:
+        if plan is not None and plan.interleave and st.cfg:
+            # both branches on this rank's token shard, advanced alternately block by block on two streams: the K|V
+            # all-gather of one branch overlaps the other branch's compute (frameino_amd/parallel.py)
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream()) if x.is_cuda else (None, None)
+            main = torch.cuda.current_stream() if x.is_cuda else None
+            gens, outs = [], [None, None]
+            for name, emb, shard in (("cond", st.pe, plan.shards[0]), ("uncond", st.ne, plan.shards[1])):
+                gens.append((name, tr.forward_steps(hidden_states=x, timestep=None, encoder_hidden_states=emb,
+                                                     return_dict=False, attention_kwargs=st.attention_kwargs,
+                                                     timestep_rows=rows, shard=shard)))
+            for s_ in self._streams:
+                if s_ is not None:
+                    s_.wait_stream(main)
+            alive = [True, True]
+            while any(alive):
+                for i, (name, g) in enumerate(gens):
+                    if not alive[i]:
+                        continue
+                    ctx_stream = torch.cuda.stream(self._streams[i]) if self._streams[i] is not None else _null_ctx()
+                    with ctx_stream, tr.cache_context(name):
+                        try:
+                            next(g)
+                        except StopIteration as done:
+                            outs[i], alive[i] = done.value[0][0], False
+            for s_ in self._streams:
+                if s_ is not None:
+                    main.wait_stream(s_)
+            pc, pu = outs
+        elif plan is not None and plan.cfg_ways == 2 and st.cfg:
             # CFG branches on two rank groups; one exchange of noise_pred per step (frameino_amd/parallel.py)
             mine = fwd("cond", st.pe) if plan.cfg_idx == 0 else fwd("uncond", st.ne)
             pc, pu = plan.exchange_cfg(mine)

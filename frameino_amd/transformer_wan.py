@@ -279,6 +279,21 @@ class WanTransformer3DModel(nn.Module):
                 return_dict=True, attention_kwargs=None, timestep_rows=None):
         """`timestep_rows=(values [R], selector int32 [L])` is the de-duplicated form of a per-token timestep; when a
         2-D `timestep` is given instead it is de-duplicated here (torch.unique: host sync, eager only)."""
+        gen = self.forward_steps(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image,
+                                 return_dict, attention_kwargs, timestep_rows)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+
+    def forward_steps(self, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None,
+                      return_dict=True, attention_kwargs=None, timestep_rows=None, shard=None):
+        """The forward as a generator that yields after the embedding stage and after every block, so that a caller
+        can interleave two independent forwards (the CFG branches) kernel-stream by kernel-stream
+        (frameino_amd/parallel.py: one branch's K|V all-gather then flies under the other branch's compute).  Every
+        piece of per-call state (workspace, text K/V, shard) is bound at the first `next()`; `shard` overrides
+        `self.parallel` for this call.  Returns (StopIteration.value) what `forward` returns."""
         if encoder_hidden_states_image is not None:
             raise NotImplementedError("encoder_hidden_states_image: Wan2.1 branch, outside the TI2V-5B path")
         if attention_kwargs is not None:
@@ -297,7 +312,8 @@ class WanTransformer3DModel(nn.Module):
         cos1, sin1 = self._rope(ppf, pph, ppw, dev)
 
         # ---- token shard of this rank (frameino_amd/parallel.py); single GPU: the whole sequence ----
-        sh = self.parallel if (self.parallel is not None and self.parallel.ways > 1) else None
+        sh = shard if shard is not None else self.parallel
+        sh = sh if (sh is not None and sh.ways > 1) else None
         if sh is not None:
             if b != 1:
                 raise NotImplementedError("token-sharded execution runs one sample per call")
@@ -349,6 +365,7 @@ class WanTransformer3DModel(nn.Module):
             a_rows = torch.cat([o.patchify(hidden_states[i], cfg.patch_size) for i in range(b)])
         x = o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=ws.x[:nr])
         nrm, att, q2, ff = ws.n[:nr], ws.att[:nr], ws.q2[:nr], ws.ff[:nr]
+        yield
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
@@ -403,6 +420,7 @@ class WanTransformer3DModel(nn.Module):
             o.gemm(nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
             o.gemm(ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x, gate=m[:, 5],
                    sel=sel, out=x)
+            yield
 
         # ---- output head (:519-543) ----
         o.adaln_modulate(x, head[:, 0], head[:, 1], sel, cfg.eps, out=nrm)

@@ -31,7 +31,7 @@ def _run(pipe, a):
                         a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), int(a["steps"]))
 
 
-def _worker(rank, world, port, cfg_parallel, q):
+def _worker(rank, world, port, cfg_parallel, q, mode="split"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, cfg_parallel, q):
         from frameino_amd.parallel import shard_pipeline
         cfg, sd, a = load_golden("wan_pipe_tiny")
         pipe = _build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")})
-        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel)
+        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode)
         out = _run(pipe, a)
         q.put((rank, plan.desc, out))
     finally:
@@ -52,7 +52,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("cfg_parallel,desc", [(True, "cfg2xtoken1"), (False, "cfg1xtoken2")])
+@pytest.mark.parametrize("cfg_parallel,desc", [(True, "cfg2xtoken1"), (False, "cfg1xtoken2"),
+                                               ("interleave", "token2x2branches-interleaved")])
 def test_two_rank_plans_match_single_process(cfg_parallel, desc):
     cfg, sd, a = load_golden("wan_pipe_tiny")
     single = _run(_build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}), a)
@@ -62,7 +63,8 @@ def test_two_rank_plans_match_single_process(cfg_parallel, desc):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_parallel, q)) for r in range(2)]
+    mode = "interleave" if cfg_parallel == "interleave" else "split"
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_parallel is True, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=300) for _ in range(2)]

@@ -31,13 +31,13 @@ def _run(pipe, a, dev):
                         d("prompt_embeds"), d("negative_embeds"), float(a["guidance"]), int(a["steps"]))
 
 
-def _worker(rank, world, port, cfg_parallel, q):
+def _worker(rank, world, port, cfg_parallel, q, mode="split"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from frameino_amd.parallel import shard_pipeline
         pipe, a = _pipe("cuda:0")
-        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel)
+        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode)
         out = _run(pipe, a, "cuda:0")
         q.put((rank, plan.desc, out.cpu()))
     finally:
@@ -50,7 +50,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("cfg_parallel,desc", [(True, "cfg2xtoken1"), (False, "cfg1xtoken2")])
+@pytest.mark.parametrize("cfg_parallel,desc", [(True, "cfg2xtoken1"), (False, "cfg1xtoken2"),
+                                               ("interleave", "token2x2branches-interleaved")])
 def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc):
     pipe, a = _pipe("cuda:0")
     pipe.batch_cfg = False                                     # two batch-1 forwards, as each rank group runs them
@@ -60,7 +61,8 @@ def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_parallel, q)) for r in range(2)]
+    mode = "interleave" if cfg_parallel == "interleave" else "split"
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_parallel is True, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=600) for _ in range(2)]
