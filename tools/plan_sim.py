@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Compute-side cost of the multi-GPU plans on ONE GPU: the per-rank work of an N-GPU run with the collectives replaced
+by local copies (a fake TokenShard), full Wan2.2-5B size.  split(N): one CFG branch, 1/(N/2) of the tokens;
+interleave(N): both branches, 1/N of the tokens each, advanced alternately on two streams.  Add the K|V all-gather
+time of the node by hand -- this measures what the GPU has to do, not the wire."""
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import build_model  # noqa: E402
+from frameino_amd.parallel import TokenShard  # noqa: E402
+
+
+class FakeShard(TokenShard):
+    """rank 0 of `ways`; the all-gather copies the local block into its slot (the other slots keep old data)."""
+
+    def _all_gather(self, key, t, async_op):
+        out = self._get(key, (self.ways * t.shape[0],) + tuple(t.shape[1:]), t.dtype, t.device)
+        out[:t.shape[0]].copy_(t)
+        return out, None
+
+
+def main():
+    from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
+    from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from oracle.wan_dit import WAN22_5B_CFG
+    dev = torch.device("cuda")
+    cfg = dict(WAN22_5B_CFG)
+    model = build_model(cfg, dev)
+    pipe = WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=model,
+                                   expand_timesteps=True)
+    g = torch.Generator().manual_seed(1234)
+    C, fg, lh, lw = 48, 13, 44, 80
+    lat = torch.randn(1, C, fg, lh, lw, generator=g).to(dev)
+    cond = torch.randn(1, C, 1, lh, lw, generator=g).to(dev)
+    traj = torch.randn(1, C, fg + 1, lh, lw, generator=g).to(dev)
+    idl = torch.randn(1, C, 1, lh, lw, generator=g).to(dev)
+    mask = torch.ones(1, 1, fg, lh, lw, device=dev)
+    mask[:, :, 0] = 0
+    pe = torch.randn(1, 512, cfg["text_dim"], generator=g).to(dev).bfloat16()
+    ne = torch.randn(1, 512, cfg["text_dim"], generator=g).to(dev).bfloat16()
+    pipe.scheduler.set_timesteps(8, device=dev)
+    st = pipe.make_state(lat, cond, traj, idl, mask, pe, ne, 5.0)
+    st.t_rows[1:2] = 700.0
+    st.dt[0] = -0.01
+
+    def timed(n=2):
+        with torch.no_grad():
+            pipe._step(st)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pipe._step(st)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    print(f"N=1 (batch-2 forward): {timed():.1f} ms/step")
+    for ways in (1, 2, 4):          # split plans: one branch per rank, token_ways = N/2
+        n_gpus = 2 * ways
+        sh = FakeShard(0, ways)
+        pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
+                                        exchange_cfg=lambda mine: (mine, mine))
+        model.parallel = sh if ways > 1 else None
+        print(f"split      N={n_gpus}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+    for ways in (2, 4, 8):          # interleaved plans: both branches per rank, token_ways = N
+        pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
+                                        shards=(FakeShard(0, ways), FakeShard(0, ways)))
+        model.parallel = pipe.parallel.shards[0]
+        print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+
+
+if __name__ == "__main__":
+    main()
