@@ -133,7 +133,7 @@ def main():
 
     from frameino_amd import _lib, ops
     _lib.load()                                   # no fallback: fail here if the HIP library is missing
-    from oracle.wan_dit import WAN22_5B_CFG       # config constants only (the oracle is not on the measured path)
+    from frameino_amd.configs import WAN22_5B_CFG
     from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
     from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
 
@@ -249,10 +249,8 @@ def main():
     vae_times = None
     if rank == 0 and a.workload != "tiny" and not a.no_vae:
         from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
-        vae = AutoencoderKLWan(base_dim=160, decoder_base_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
-                               temperal_downsample=[False, True, True], is_residual=True, in_channels=12,
-                               out_channels=12, patch_size=2, scale_factor_temporal=4,
-                               scale_factor_spatial=16).random_init_(seed=2, device=dev)
+        from frameino_amd.configs import WAN22_VAE_CFG
+        vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=2, device=dev)
         vid = torch.rand(1, 3, 1 + 4 * (fg - 1), lh * 16, lw * 16, device=dev) * 2 - 1
         with torch.no_grad():
             for rep in range(2):                          # first pass warms the kernels

@@ -85,12 +85,9 @@ def main():
                                    out_channels=12, patch_size=2, scale_factor_temporal=4, scale_factor_spatial=16,
                                    latents_mean=[0.0] * 16, latents_std=[1.0] * 16).random_init_(seed=2, device=dev)
         else:
-            from oracle.wan_dit import WAN22_5B_CFG          # configuration constants only
+            from frameino_amd.configs import WAN22_5B_CFG, WAN22_VAE_CFG
             cfg = dict(WAN22_5B_CFG)
-            vae = AutoencoderKLWan(base_dim=160, decoder_base_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4],
-                                   num_res_blocks=2, temperal_downsample=[False, True, True], is_residual=True,
-                                   in_channels=12, out_channels=12, patch_size=2, scale_factor_temporal=4,
-                                   scale_factor_spatial=16).random_init_(seed=2, device=dev)
+            vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=2, device=dev)
         transformer = build_model(cfg, dev)
         text_dim = cfg["text_dim"]
 

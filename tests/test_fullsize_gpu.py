@@ -87,7 +87,7 @@ def test_gemm_full_size_sampled_rows(n, k, epi):
 def wan5b():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import build_model
-    from oracle.wan_dit import WAN22_5B_CFG           # configuration constants only
+    from frameino_amd.configs import WAN22_5B_CFG
     cfg = dict(WAN22_5B_CFG, num_layers=4)            # 4 of the 30 identical layers: same shapes, 1/7 of the time
     return build_model(cfg, torch.device(DEV)), cfg
 
@@ -129,9 +129,8 @@ def test_vae_decode_full_size_is_causal_in_time():
     """Decoding the first k latent frames alone gives the first 1 + 4(k-1) video frames of the full decode (what
     the reference's frame-by-frame feat_cache streaming relies on, autoencoder_kl_wan.py:1198-1227) -- at 704x1280."""
     from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
-    vae = AutoencoderKLWan(base_dim=160, decoder_base_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
-                           temperal_downsample=[False, True, True], is_residual=True, in_channels=12, out_channels=12,
-                           patch_size=2, scale_factor_temporal=4, scale_factor_spatial=16).random_init_(seed=2, device=DEV)
+    from frameino_amd.configs import WAN22_VAE_CFG
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=2, device=DEV)
     z = torch.randn(1, 48, 5, 44, 80, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
     with torch.no_grad():
         full = vae.decode(z, return_dict=False)[0]

@@ -155,3 +155,9 @@ def test_cog_denoise_loop_restatement(golden):
                                a["prompt_embeds"], a["negative_embeds"], (a["cos"], a["sin"]), float(a["guidance"]),
                                int(a["steps"]), dynamic_cfg=dyn)
         torch.testing.assert_close(out, a[key], atol=1e-4, rtol=1e-4)
+
+
+def test_product_and_oracle_configs_agree():
+    from frameino_amd.configs import WAN22_5B_CFG as product
+    from oracle.wan_dit import WAN22_5B_CFG as oracle_cfg
+    assert product == oracle_cfg

@@ -11,11 +11,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-COG5B = dict(num_attention_heads=48, attention_head_dim=64, in_channels=48, out_channels=16, flip_sin_to_cos=True,
-             freq_shift=0, time_embed_dim=512, text_embed_dim=4096, num_layers=42, sample_width=90, sample_height=60,
-             sample_frames=49, patch_size=2, temporal_compression_ratio=4, max_text_seq_length=226,
-             norm_elementwise_affine=True, norm_eps=1e-5, use_rotary_positional_embeddings=True,
-             use_learned_positional_embeddings=True, use_FrameIn=True)
+from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG as COG5B  # noqa: E402
 
 
 def main():

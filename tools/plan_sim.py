@@ -27,7 +27,7 @@ class FakeShard(TokenShard):
 def main():
     from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
     from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
-    from oracle.wan_dit import WAN22_5B_CFG
+    from frameino_amd.configs import WAN22_5B_CFG
     dev = torch.device("cuda")
     cfg = dict(WAN22_5B_CFG)
     model = build_model(cfg, dev)
