@@ -6,9 +6,10 @@ What is built: the CFG-batched denoise loop (:848-944) -
 kernels, ID-frame drop (:901-902), (dynamic) guidance (:906-911), v-prediction DDIM update (:916) in one kernel --
 plus `_prepare_rotary_positional_embeddings` (:540-584) with the FrameIn extension (:834-839).
 
-What is NOT here: the CogVideoX VAE.  The reference takes it from diffusers (`AutoencoderKLCogVideoX`, third-party,
-no source in the reference tree, not installable offline), so `__call__` needs a user-supplied `vae` object with the
-diffusers interface for the condition encodes / final decode; `denoise()` works on latents alone.
+What is NOT here: the CogVideoX VAE and the T5 text encoder.  The reference takes them from diffusers / transformers
+(`AutoencoderKLCogVideoX`: third-party, no source in the reference tree, not installable offline), so `__call__`
+(:604-957: condition encodes, loop, decode, post-processing) runs around a user-supplied `vae` object with the
+diffusers interface and pre-computed prompt embeddings; `denoise()` works on latents alone.
 """
 import math
 from types import SimpleNamespace
@@ -145,9 +146,111 @@ class CogVideoXImageToVideoPipeline:
                     lat.copy_(out["latents"][0])
         return lat[None]
 
+    # ---- condition encodes / decode around a user-supplied VAE (diffusers interface) ----
+    def _need_vae(self):
+        if self.vae is None:
+            raise NotImplementedError(
+                "CogVideoXImageToVideoPipeline.__call__ needs a `vae` with the diffusers AutoencoderKLCogVideoX "
+                "interface (.encode(x).latent_dist.sample(generator), .decode(z).sample, .config.scaling_factor, "
+                ".config.invert_scale_latents, .dtype): that model is third-party and not part of the reference tree. "
+                "`denoise()` works on latents alone.")
+
+    def prepare_latents(self, image, batch_size=1, num_channels_latents=16, num_frames=13, height=60, width=90,
+                        dtype=None, device=None, generator=None, latents=None):
+        """reference :350-423 (patch_size_t None).  image [B, C, H, W] in [-1, 1]."""
+        self._need_vae()
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
+                             f"the generators.")
+        nlf = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        lh, lw = height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial
+        image = image.unsqueeze(2)                                                   # [B, C, 1, H, W]
+        gens = generator if isinstance(generator, list) else [generator] * image.shape[0]
+        image_latents = torch.cat([self.vae.encode(img.unsqueeze(0)).latent_dist.sample(g)
+                                   for img, g in zip(image, gens)], dim=0).to(dtype).permute(0, 2, 1, 3, 4)
+        if not getattr(self.vae.config, "invert_scale_latents", False):
+            image_latents = self.vae_scaling_factor_image * image_latents
+        else:
+            image_latents = 1 / self.vae_scaling_factor_image * image_latents
+        pad = torch.zeros((batch_size, nlf - 1, num_channels_latents, lh, lw), device=device, dtype=dtype)
+        image_latents = torch.cat([image_latents, pad], dim=1)
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else device
+            latents = torch.randn((batch_size, nlf, num_channels_latents, lh, lw), generator=generator
+                                  if isinstance(generator, torch.Generator) else None, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma, image_latents
+
+    def decode_latents(self, latents):
+        """reference :426-431"""
+        self._need_vae()
+        latents = latents.permute(0, 2, 1, 3, 4)
+        return self.vae.decode(1 / self.vae_scaling_factor_image * latents).sample
+
     @torch.no_grad()
-    def __call__(self, *args, **kwargs):
-        raise NotImplementedError(
-            "CogVideoXImageToVideoPipeline.__call__ needs diffusers' AutoencoderKLCogVideoX (third-party, not part of "
-            "the reference tree) for the condition encodes and the final decode; use .denoise() with latents, or wrap "
-            "it with your VAE: see DESIGN.md section 7.")
+    def __call__(self, image, traj_tensor=None, ID_tensor=None, prompt=None, negative_prompt=None, height=None,
+                 width=None, num_frames=49, num_inference_steps=50, timesteps=None, guidance_scale=6,
+                 use_dynamic_cfg=False, add_ID_reference_augment_noise=True, num_videos_per_prompt=1, eta=0.0,
+                 generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type="pil",
+                 return_dict=True, attention_kwargs=None, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=["latents"], max_sequence_length=226):
+        """reference :604-957 with pre-computed prompt embeddings (the T5 encoder is third-party; pass
+        `prompt_embeds` / `negative_prompt_embeds` [1, 226, 4096]) and one video per call."""
+        self._need_vae()
+        if timesteps is not None or eta != 0.0:
+            raise NotImplementedError("custom timesteps / eta: the built sampler is the v-prediction DDIM step (eta 0)")
+        if prompt_embeds is None:
+            raise NotImplementedError("text encoding (T5, third-party) is outside the path: pass prompt_embeds")
+        c = self.transformer.config
+        height = height or c.sample_height * self.vae_scale_factor_spatial
+        width = width or c.sample_width * self.vae_scale_factor_spatial
+        dev = prompt_embeds.device
+        dt = self.transformer.dtype
+        self._interrupt = False
+        if isinstance(image, torch.Tensor):
+            img = image if image.ndim == 4 else image[None]
+            img = img if img.min() < 0 else 2.0 * img - 1.0
+        else:
+            import numpy as np
+            import PIL.Image
+            arr = np.asarray(image.resize((width, height), resample=PIL.Image.LANCZOS)).astype("float32") / 255.0
+            img = 2.0 * torch.from_numpy(arr.transpose(2, 0, 1).copy())[None] - 1.0
+        img = img.to(dev, dtype=dt)
+        n_lat = c.out_channels          # 16 for CogVideoX-5B (hard-coded at :797)
+        latents, image_latents = self.prepare_latents(img, 1, n_lat, num_frames, height, width, dt, dev, generator, latents)
+        latents = latents / self.scheduler.init_noise_sigma          # denoise() applies it (:421)
+        vdt = getattr(self.vae, "dtype", dt)
+        traj = traj_tensor.to(dev, dtype=vdt)[None].permute(0, 2, 1, 3, 4)                        # :809-811
+        traj_latents = self.vae.encode(traj).latent_dist.sample() * self.vae.config.scaling_factor
+        traj_latents = traj_latents.permute(0, 2, 1, 3, 4).contiguous().float().to(dt)            # [1, F, C, h, w]
+        id_latent = None
+        if ID_tensor is not None:                                                                  # :820-826, train_code :515-546
+            idt = ID_tensor.unsqueeze(0).unsqueeze(2).to(dev, dtype=vdt)                           # [1, C, 1, H, W]
+            if add_ID_reference_augment_noise:
+                sigma = torch.exp(torch.normal(mean=-3.0, std=0.5, size=(1,), device=dev)).to(idt.dtype)
+                idt = idt + torch.randn_like(idt) * sigma[:, None, None, None, None]
+            idl = self.vae.encode(idt).latent_dist.sample() * self.vae.config.scaling_factor
+            id_latent = idl.squeeze(2).contiguous().float().unsqueeze(1).to(dt)                    # [1, 1, C, h, w]
+        gscale = guidance_scale if negative_prompt_embeds is not None else 1.0
+        out = self.denoise(latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_prompt_embeds,
+                           gscale, num_inference_steps, use_dynamic_cfg, None, attention_kwargs, callback_on_step_end)
+        if output_type == "latent":
+            video = out
+        else:
+            frames = self.decode_latents(out)                                                      # [1, C, F, H, W]
+            v = (frames.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)                      # [1, F, C, H, W]
+            if output_type == "pt":
+                video = v
+            elif output_type == "np":
+                video = v.permute(0, 1, 3, 4, 2).cpu().numpy()
+            elif output_type == "pil":
+                import PIL.Image
+                arr = (v.permute(0, 1, 3, 4, 2).cpu().numpy() * 255).round().astype("uint8")
+                video = [[PIL.Image.fromarray(f) for f in vid] for vid in arr]
+            else:
+                raise ValueError(f"unsupported output_type {output_type}")
+        if not return_dict:
+            return (video,)
+        return CogVideoXPipelineOutput(frames=video)

@@ -122,3 +122,79 @@ def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):
     ref = cog_denoise_loop(sd, cfg, lat, img, trj, None, pe, ne, (a["cos_def"], a["sin_def"]), 6.0, 4)
     r = rel_rms(out, ref)
     assert out.shape == ref.shape and r < 6e-2, r
+
+
+class _FakeDist:
+    def __init__(self, z):
+        self.z = z
+
+    def sample(self, generator=None):
+        return self.z
+
+    def mode(self):
+        return self.z
+
+
+class _FakeCogVAE(torch.nn.Module):
+    """Stand-in with the diffusers AutoencoderKLCogVideoX interface (8x spatial, 4x temporal, 16 latent channels): the
+    real one is third-party and absent, so `__call__` is tested for its plumbing, not for the VAE's arithmetic."""
+
+    def __init__(self, c_lat=2):
+        super().__init__()
+        g = torch.Generator().manual_seed(9)
+        self.register_buffer("proj", torch.randn(c_lat, 3, generator=g) * 0.5)
+        self.config = __import__("types").SimpleNamespace(scaling_factor=0.7, invert_scale_latents=False)
+
+    @property
+    def dtype(self):
+        return self.proj.dtype
+
+    def encode(self, x):                                           # [B, 3, F, H, W] -> [B, C, (F-1)/4+1, H/8, W/8]
+        x = torch.nn.functional.avg_pool3d(x.float(), (1, 8, 8))
+        x = torch.cat([x[:, :, :1], torch.nn.functional.avg_pool3d(x[:, :, 1:], (4, 1, 1))], dim=2) \
+            if x.shape[2] > 1 else x
+        return __import__("types").SimpleNamespace(latent_dist=_FakeDist(torch.einsum("oc,bcfhw->bofhw", self.proj.float(), x)))
+
+    def decode(self, z):                                           # -> [B, 3, 1+4(F-1), 8H, 8W]
+        y = torch.einsum("oc,bofhw->bcfhw", self.proj.float(), z.float())
+        y = torch.cat([y[:, :, :1], y[:, :, 1:].repeat_interleave(4, dim=2)], dim=2)
+        return __import__("types").SimpleNamespace(sample=torch.nn.functional.interpolate(y, scale_factor=(1, 8, 8)))
+
+
+def test_cog_full_call_plumbing_with_a_stand_in_vae(golden):
+    """`__call__` (:604-957): condition encodes (first frame, trajectory video, ID frame), scaling factors, layout
+    permutes, the loop, decode + post-processing -- equal to `denoise()` fed with hand-made conditions."""
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    cfg, sd, a = golden("cog_loop_tiny")
+    cfg = _cog_cfg(cfg)
+    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    vae = _FakeCogVAE(c_lat=2).to(DEV)
+    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDDIMScheduler(), vae=vae)
+    g = torch.Generator().manual_seed(11)
+    H = W = 64
+    frames = 9                                                      # 3 latent frames
+    image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    traj = torch.rand(frames, 3, H, W, generator=g) * 2 - 1
+    ident = torch.rand(3, H, W, generator=g) * 2 - 1
+    lat0 = torch.randn(1, 3, 2, 8, 8, generator=g)
+    pe, ne = a["prompt_embeds"].to(DEV).bfloat16(), a["negative_embeds"].to(DEV).bfloat16()
+    kw = dict(image=image.to(DEV), traj_tensor=traj.to(DEV), ID_tensor=ident.to(DEV), height=H, width=W,
+              num_frames=frames, num_inference_steps=3, guidance_scale=6.0, add_ID_reference_augment_noise=False,
+              latents=lat0.to(DEV), prompt_embeds=pe, negative_prompt_embeds=ne)
+    out_lat = pipe(output_type="latent", **kw).frames
+    # the same conditions by hand
+    dt = torch.bfloat16
+    img_lat = 0.7 * vae.encode(image.to(DEV).to(dt).unsqueeze(2)).latent_dist.sample().to(dt).permute(0, 2, 1, 3, 4)   # :389-392
+    img_lat = torch.cat([img_lat, torch.zeros(1, 2, 2, 8, 8, device=DEV, dtype=dt)], dim=1)
+    trj_lat = (vae.encode(traj.to(DEV)[None].permute(0, 2, 1, 3, 4)).latent_dist.sample() * 0.7) \
+        .permute(0, 2, 1, 3, 4).contiguous().float().to(dt)
+    id_lat = (vae.encode(ident.to(DEV)[None, :, None]).latent_dist.sample() * 0.7).squeeze(2).float().unsqueeze(1).to(dt)
+    ref = pipe.denoise(lat0.to(DEV), img_lat, trj_lat, id_lat, pe, ne, 6.0, 3)
+    assert torch.equal(out_lat, ref)
+    vid = pipe(output_type="np", **kw).frames
+    assert vid.shape == (1, frames, H, W, 3) and vid.min() >= 0.0 and vid.max() <= 1.0
+    with pytest.raises(NotImplementedError):
+        CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())(image=image)
