@@ -34,6 +34,9 @@ SIGNATURES = {
     "fino_attn_fwd_ws": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 12 +
                         [c_float, c_int, c_void_p, c_i64, c_void_p],
     "fino_attn_workspace_bytes": [c_int, c_int, c_i64, c_i64, c_int],
+    "fino_mxfp8_scale_bytes": [c_i64, c_i64],
+    "fino_quantize_mxfp8": [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p],
+    "fino_gemm_mxfp8": [c_void_p] * 6 + [c_i64] * 4 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_traj_paint": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fino_traj_blur_quantize": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
@@ -52,7 +55,7 @@ SIGNATURES = {
     "fino_vae_unpatchify_clamp": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     "fino_vae_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
 }
-_RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64}
+_RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64, "fino_mxfp8_scale_bytes": c_i64}
 
 
 def declared_symbols(header_path=HEADER_PATH):

@@ -28,115 +28,6 @@ extern "C" int fino_gemm_debug_read(unsigned long long* out) {
 
 namespace {
 
-// ---- tile id -> (tm, tn): contiguous id range per XCD, 4-tile-high groups inside (operand reuse in that XCD's L2) ----
-__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    constexpr int GROUP_M = 4;
-    const int group = id / (GROUP_M * p.tiles_n);
-    const int first_m = group * GROUP_M;
-    const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
-    const int in_group = id - group * GROUP_M * p.tiles_n;
-    tm = first_m + in_group % gsz;
-    tn = in_group / gsz;
-}
-
-// Shared by both main-loop variants.  Every wave must be past its last LDS operand read (barrier) before the call.
-template <typename T, int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[8][4], const GemmParams& p, char* smem, int64_t m0,
-                                              int64_t n0, int tid, int lane, int wm, int wn) {
-    // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
-    // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*128 + i*16 + (lane&15)
-    constexpr bool kHasRes =
-        EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED;
-    constexpr int kIters = (BM * BN / 8) / kThreads;      // 16 row-chunks of 16 bytes per thread
-    // The residual tile is this epilogue's only long-latency input and depends on nothing computed here: all 16 loads
-    // per thread go out FIRST and fly under the accumulator conversion + LDS staging (every CU reaches its epilogue
-    // at about the same time, so these reads are an HBM burst: 4 in flight per thread measured ~24 us per round of
-    // tiles at N = 3072, against ~7 us for the store-only epilogue).
-    constexpr bool kGated = EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED;
-    uint4 rres[kHasRes ? kIters : 1];
-    int rsel[kGated ? kIters : 1];
-    if (kHasRes) {
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int idx = it * kThreads + tid;
-            int64_t gm = m0 + (idx >> 5), gn = n0 + (idx & 31) * 8;
-            gm = gm < p.m ? gm : p.m - 1;
-            gn = gn < p.n ? gn : p.n - 8;
-            rres[it] = *reinterpret_cast<const uint4*>(p.r + gm * p.ldr + gn);
-            if (kGated) rsel[it] = p.sel ? p.sel[gm] : 0;
-        }
-    }
-    float bv[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int64_t gn = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + e;
-            if (gn >= p.n) gn = p.n - 1;
-            bv[j][e] = p.bias ? T::to_f32(p.bias[gn]) : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wm * 128 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = acc[i][j][e] + bv[j][e];
-                if (EPI == FINO_EPI_GELU_TANH) y[e] = gelu_tanh_f32(round_to<T>(y[e]));
-            }
-            const uint32_t w0 = (uint32_t)T::from_f32(y[0]) | ((uint32_t)T::from_f32(y[1]) << 16);
-            const uint32_t w1 = (uint32_t)T::from_f32(y[2]) | ((uint32_t)T::from_f32(y[3]) << 16);
-            const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
-            *reinterpret_cast<uint2*>(smem + row * kCsStride + col * 2) = make_uint2(w0, w1);
-        }
-    }
-    __syncthreads();
-    int gsel = -1;
-    float gg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int it = 0; it < kIters; ++it) {
-        const int idx = it * kThreads + tid;
-        const int row = idx >> 5;
-        const int ch = idx & 31;
-        const int64_t gm = m0 + row, gn = n0 + ch * 8;
-        if (gm >= p.m || gn >= p.n) continue;
-        uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
-        if (kHasRes) {
-            float y[8], rv[8], o[8];
-            unpack8<T>(yv, y);
-            unpack8<T>(rres[it], rv);
-            if (kGated) {
-                // a thread keeps one 8-column chunk for all its rows, and the gate row changes with the timestep row
-                // of the token (2 distinct rows in FrameINO): reload the 8 fp32 gates only when the selector changes
-                // (was: 2 x float4 per row -- 256 KB of L1/L2 reads per tile, more than the residual itself)
-                if (rsel[it] != gsel) {
-                    gsel = rsel[it];
-                    const float* g = p.gate + (int64_t)gsel * p.mod_stride + gn;
-                    const float4 g0 = *reinterpret_cast<const float4*>(g);
-                    const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
-                    gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w;
-                    gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    o[e] = rv[e] + (EPI == FINO_EPI_GATED_RESIDUAL_STAGED ? round_to<T>(y[e] * gg[e]) : y[e] * gg[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
-            }
-            yv = pack8<T>(o);
-        }
-        *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
-    }
-}
-
 template <typename T, int EPI, bool GENERIC, bool CONV>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -218,6 +218,47 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     return out
 
 
+def quantize_mxfp8(x, out=None):
+    """x [rows, cols] bf16|fp16 (cols % 128 == 0) -> (q uint8 [rows, cols], scales uint8 [...]) in the layout
+    fino_gemm_mxfp8 consumes (OCP e4m3 elements, one e8m0 scale per 32 K-elements)."""
+    x2, rows, cols, ldx = _rows2d(x)
+    nbytes = _lib.lib().fino_mxfp8_scale_bytes(rows, cols)
+    if nbytes <= 0:
+        raise ValueError(f"quantize_mxfp8: cols={cols} must be a positive multiple of 128")
+    if out is None:
+        q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+        s = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+    else:
+        q, s = out
+    _lib.check(_lib.lib().fino_quantize_mxfp8(_p(x2), _p(q), _p(s), rows, cols, ldx, _dt(x), _stream()),
+               "fino_quantize_mxfp8")
+    return q, s
+
+
+def gemm_mxfp8(aq, a_scales, wq, w_scales, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None,
+               out_dtype=torch.bfloat16):
+    """C = epilogue(dequant(aq).dequant(wq)^T + bias): aq [M, K], wq [N, K] uint8 (e4m3) + their MX scales."""
+    m, k = aq.shape
+    n = wq.shape[0]
+    assert wq.shape[1] == k and aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and aq.is_contiguous() \
+        and wq.is_contiguous()
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=aq.device)
+    o2, _, _, ldc = _rows2d(out)
+    r2, ldr = (None, 0)
+    if residual is not None:
+        r2, _, _, ldr = _rows2d(residual)
+    ms = gate.stride(0) if (gate is not None and gate.dim() == 2) else 0
+    ev = _timed("gemm")
+    _lib.check(_lib.lib().fino_gemm_mxfp8(_p(aq), _p(a_scales), _p(wq), _p(w_scales), _p(bias), _p(o2), m, n, k, ldc,
+                                         epilogue, _p(r2), ldr, _p(gate), ms, _p(sel), _dt(out), _stream()),
+               "fino_gemm_mxfp8")
+    if ev is not None:
+        ev.record()
+        KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
+    return out
+
+
 def skinny_linear(x, w, b=None, silu_input=False):
     """fp32 y = W.(silu?)(x) + b for M <= 16 rows; w fp32 or bf16/fp16."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and w.is_contiguous()

@@ -200,6 +200,22 @@ int fino_vae_unpatchify_clamp(const void* y, float* out, int t, int h, int w, in
 int fino_vae_patchify(const float* x, void* y, int t, int h, int w, int c_pad, int channels, int patch, int dtype,
                       void* stream);
 
+/* ---- MXFP8 linear layers (BASELINE config 5: "fp8 MFMA path"; no reference counterpart) -------------
+ * OCP e4m3 elements with one e8m0 scale per 32 consecutive K-elements (MX), fp32 accumulate
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the bf16 MFMA rate), same fused epilogues and output types as fino_gemm.
+ * fino_quantize_mxfp8: x [rows, cols] bf16|fp16 (row stride ldx, cols % 128 == 0) -> q [rows, cols] bytes and
+ *   `scales`, fino_mxfp8_scale_bytes(rows, cols) bytes laid out [cols/128][ceil(rows/256)][1024], inside a KiB
+ *   [K-block (4)][row & 15][row >> 4] (what one 256-row tile needs for one 128-wide K-tile, contiguous).
+ *   Scale of a block = 2^e with amax / 2^e in [224, 448].  Quantise weights once, activations per call.
+ * fino_gemm_mxfp8: C[M, N] = epilogue(dequant(Aq) . dequant(Wq)^T + bias); Aq [M, K], Wq [N, K] bytes; K % 128 == 0;
+ *   bias / residual / C in out_dtype, epilogue arguments as fino_gemm. */
+int64_t fino_mxfp8_scale_bytes(int64_t rows, int64_t cols);
+int fino_quantize_mxfp8(const void* x, void* q, void* scales, int64_t rows, int64_t cols, int64_t ldx, int dtype,
+                        void* stream);
+int fino_gemm_mxfp8(const void* aq, const void* a_scales, const void* wq, const void* w_scales, const void* bias,
+                    void* c, int64_t m, int64_t n, int64_t k, int64_t ldc, int epilogue, const void* r, int64_t ldr,
+                    const float* gate, int64_t mod_stride, const int32_t* sel, int out_dtype, void* stream);
+
 /* ---- condition builders in front of the path ---------------------------------------------------------
  * Trajectory video of data_loader/video_dataset_motion.py:120-206 (`prepare_traj_tensor`, app.py:616-620).
  * fino_traj_paint: canvas fp32 [frames, 3, H, W] = 255, then for every frame its points, in order, paint the square

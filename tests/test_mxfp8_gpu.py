@@ -1,0 +1,64 @@
+"""MXFP8 linear path (BASELINE config 5): quantiser against a torch restatement of the MX rule, the scaled-MFMA GEMM
+against fp32 matmul on the DEQUANTISED operands (exact up to fp32 summation order), and the end-to-end error of
+quantise + GEMM against the bf16 GEMM it replaces."""
+import pytest
+import torch
+
+from tests.parity import rel_rms
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dequant(q, scales, rows, cols):
+    """inverse of the layout fino_quantize_mxfp8 writes: -> fp32 [rows, cols]"""
+    rp = (rows + 255) // 256 * 256
+    s = scales.view(cols // 128, rp // 256, 4, 16, 16).cpu()          # [kt][rt][g][row&15][row>>4]
+    e = s.permute(1, 4, 3, 0, 2).reshape(rp, cols // 32)[:rows]       # [row][kt*4+g]  (row = (row>>4)*16 + (row&15))
+    val = q.cpu().view(torch.float8_e4m3fn).float()
+    return val * torch.exp2(e.float() - 127).repeat_interleave(32, dim=1)
+
+
+@pytest.mark.parametrize("rows,cols", [(300, 256), (77, 1024), (512, 3072)])
+def test_quantize_matches_mx_rule(rows, cols):
+    from frameino_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(rows, cols, generator=g) * torch.exp2(torch.randint(-6, 6, (rows, 1), generator=g).float())).bfloat16()
+    x[0, :32] = 0                                                     # an all-zero block
+    q, s = ops.quantize_mxfp8(x.to(DEV))
+    xd = dequant(q, s, rows, cols)
+    xf = x.float()
+    blk = xf.view(rows, cols // 32, 32)
+    amax = blk.abs().amax(-1, keepdim=True)
+    # every block's amax is scaled into (224, 448]: nothing saturates; e4m3's half-ulp there is 16, so the error
+    # of any element is at most amax * 16 / 224
+    err = (xd.view(rows, cols // 32, 32) - blk).abs()
+    assert (err <= amax / 14 + 1e-30).all()
+    assert (xd[0, :32] == 0).all()
+    assert rel_rms(xd, xf) < 0.04
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(256, 256, 128, 0), (300, 520, 384, 0), (1000, 768, 1024, 1), (513, 256, 2048, 3),
+                                       (2048, 3072, 3072, 2)])
+def test_gemm_mxfp8_vs_dequantised_fp32(m, n, k, epi):
+    from frameino_amd import ops
+    from tests.test_kernels_gpu import gemm_ref
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(m, k, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().to(DEV)
+    bias = torch.randn(n, generator=g).bfloat16().to(DEV)
+    res = torch.randn(m, n, generator=g).bfloat16().to(DEV) if epi >= 2 else None
+    gate = torch.randn(2, n, generator=g).to(DEV) if epi == 3 else None
+    sel = (torch.arange(m) % 2).to(torch.int32).to(DEV) if epi == 3 else None
+    aq, sa = ops.quantize_mxfp8(a)
+    wq, sw = ops.quantize_mxfp8(w)
+    out = ops.gemm_mxfp8(aq, sa, wq, sw, bias, epi, res, gate, sel)
+    ad = dequant(aq, sa, m, k).to(DEV)
+    wd = dequant(wq, sw, n, k).to(DEV)
+    ref = gemm_ref(ad, wd, bias, epi, res, gate, sel)                 # fp32 matmul of exactly what the MFMA multiplies
+    assert rel_rms(out, ref.float()) < 2.0 ** -7                      # bf16 output rounding only
+    # and against the bf16 GEMM it replaces: MX quantisation noise (two e4m3 operands)
+    full = ops.gemm(a, w, bias, epi, res, gate, sel)
+    r = rel_rms(out, full.float())
+    print(f"[{m}x{n}x{k} epi {epi}] mxfp8 vs bf16 GEMM rel-RMS {r:.4f}")
+    assert r < 0.06
