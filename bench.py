@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--cfg-streams", action="store_true", help="CFG branches on two concurrent streams (A/B)")
     ap.add_argument("--plan", choices=["auto", "split", "interleave"], default="auto",
                     help="N>1: cfg x token split, both CFG branches interleaved on token shards, or probe both (>= 4 GPUs)")
+    ap.add_argument("--mxfp8", action="store_true",
+                    help="NOT the headline: large linears on the MXFP8 path (BASELINE config 5 style), attention in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the once-per-clip VAE encode/decode timing")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
@@ -147,6 +149,8 @@ def main():
     C = cfg["out_channels"]
     L = (fg + nid) * (lh // 2) * (lw // 2)
     model = build_model(cfg, dev)
+    if a.mxfp8:
+        model.enable_mxfp8_linears()
     pipe = WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=model,
                                    expand_timesteps=True)
     plans = {}
@@ -271,7 +275,9 @@ def main():
             "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if not a.mxfp8 else "mxfp8 linears (e4m3 + e8m0/32) + bf16 attention -- not the headline",
+            "data": "synthetic",
             "config": {"workload": a.workload, "tokens": L, "layers": cfg["num_layers"], "guidance": 5.0,
                        "id_frames": nid, "hip_graph": bool(a.graph),
                        "parallelism": getattr(pipe, "parallel_desc", "single"),

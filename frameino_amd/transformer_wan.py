@@ -139,6 +139,7 @@ class WanTransformer3DModel(nn.Module):
         self._ctx_name = None
         self.ops = ops            # kernel front end (tests of the sharding logic inject a CPU stand-in)
         self.parallel = None      # frameino_amd.parallel.TokenShard or None
+        self._fp8 = {}            # (layer, linear) -> (e4m3 weight bytes, MX scales); see enable_mxfp8_linears
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -203,6 +204,34 @@ class WanTransformer3DModel(nn.Module):
                                type(b.attn2.processor) is MI355WanAttnProcessor for b in self.blocks)
         self._packed = pk
         return pk
+
+    # ------------------------------------------------------------------ MXFP8 linears (optional; BASELINE config 5)
+    def enable_mxfp8_linears(self, enabled=True):
+        """Run the six large linears of every block (QKV, attention out, cross-attention q / out, FFN up / down) on the
+        MXFP8 path (`fino_quantize_mxfp8` + `fino_gemm_mxfp8`: OCP e4m3 with one e8m0 scale per 32 K-elements, fp32
+        accumulate): weights are quantised once here, activations per call.  Attention, norms, modulation, embeddings
+        and the output head stay in the model dtype.  There is no reference counterpart: the result is
+        compared with this model's own bf16 forward (tests/test_mxfp8_gpu.py)."""
+        self._fp8 = {}
+        if not enabled:
+            return self
+        pk = self._packed or self._pack()
+        o = self.ops
+        for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
+            for key, w in (("qkv", e.wqkv), ("out", blk.attn1.to_out[0].weight), ("q2", blk.attn2.to_q.weight),
+                           ("out2", blk.attn2.to_out[0].weight), ("ff1", blk.ffn.net[0].proj.weight),
+                           ("ff2", blk.ffn.net[2].weight)):
+                self._fp8[(li, key)] = o.quantize_mxfp8(w.detach().contiguous())
+        return self
+
+    def _lin(self, li, key, x, w, b, epi=0, **kw):
+        """one of a block's large linears: MXFP8 when enabled (and K is a multiple of 128), else the model-dtype GEMM"""
+        wq = self._fp8.get((li, key)) if self._fp8 else None
+        o = self.ops
+        if wq is None:
+            return o.gemm(x, w, b, epi, **kw)
+        xq, xs = o.quantize_mxfp8(x)
+        return o.gemm_mxfp8(xq, xs, wq[0], wq[1], b, epi, **kw)
 
     def _workspace(self, L, dtype, device):
         # one workspace per (shape, cache_context name): the two CFG branches may run concurrently on two streams
@@ -379,7 +408,7 @@ class WanTransformer3DModel(nn.Module):
                 o.gated_residual(x, a.reshape(nr, d), m[:, 2], sel, out=x)
             elif sh is None:
                 qkv = ws.qkv[:nr]
-                o.gemm(nrm, e.wqkv, e.bqkv, out=qkv)
+                self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
                 o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
                 o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                 q3 = qkv.view(b, n, 3 * d)
@@ -397,8 +426,8 @@ class WanTransformer3DModel(nn.Module):
                 kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
                 o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
             if pk.default_procs:
-                o.gemm(att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
-                       residual=x, gate=m[:, 2], sel=sel, out=x)
+                self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
+                          residual=x, gate=m[:, 2], sel=sel, out=x)
             # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange
             n2 = blk.norm2
             if n2 is not None:
@@ -406,20 +435,21 @@ class WanTransformer3DModel(nn.Module):
             else:
                 nrm.copy_(x)
             if pk.default_procs:
-                o.gemm(nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=q2)
+                self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=q2)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)
                 o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
-                o.gemm(att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=x, out=x)
+                self._lin(li, "out2", att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
+                          residual=x, out=x)
             else:
                 a = blk.attn2(nrm.view(b, n, d), encoder_hidden_states=text.txt.view(b, lt, d),
                               **(attention_kwargs or {}))
                 o.gated_residual(x, a.reshape(nr, d), out=x)
             # 3. feed-forward (:344-348)
             o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
-            o.gemm(nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
-            o.gemm(ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x, gate=m[:, 5],
-                   sel=sel, out=x)
+            self._lin(li, "ff1", nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
+            self._lin(li, "ff2", ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
+                      gate=m[:, 5], sel=sel, out=x)
             yield
 
         # ---- output head (:519-543) ----

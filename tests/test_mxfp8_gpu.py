@@ -62,3 +62,27 @@ def test_gemm_mxfp8_vs_dequantised_fp32(m, n, k, epi):
     r = rel_rms(out, full.float())
     print(f"[{m}x{n}x{k} epi {epi}] mxfp8 vs bf16 GEMM rel-RMS {r:.4f}")
     assert r < 0.06
+
+
+def test_wan_model_with_mxfp8_linears_vs_own_bf16():
+    """`enable_mxfp8_linears()`: the same forward with the six large linears per block on the MXFP8 path; compared with
+    this model's own bf16 forward (there is no reference fp8 path)."""
+    from oracle import wan_dit as W
+    from tests.parity import hip_wan_model
+    cfg = dict(W.WAN22_5B_CFG, num_attention_heads=4, attention_head_dim=128, in_channels=16, out_channels=8,
+               text_dim=256, ffn_dim=1024, num_layers=3)
+    sd = W.wan_random_state_dict(cfg, seed=7, dtype=torch.float32, std=0.04)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 16, 5, 16, 20, generator=g).to(DEV).bfloat16()
+    txt = torch.randn(1, 77, 256, generator=g).to(DEV).bfloat16()
+    ts = torch.full((1, 5 * 8 * 10), 811.0)
+    ts[0, :80] = 0.0
+    m = hip_wan_model(cfg, sd, DEV)
+    ref = m(x, ts.to(DEV), txt, return_dict=False)[0]
+    m.enable_mxfp8_linears()
+    out = m(x, ts.to(DEV), txt, return_dict=False)[0]
+    m.enable_mxfp8_linears(False)
+    back = m(x, ts.to(DEV), txt, return_dict=False)[0]
+    r = rel_rms(out, ref.float())
+    print(f"mxfp8-linears forward vs own bf16 forward: rel-RMS {r:.4f}")
+    assert 1e-4 < r < 0.1 and torch.equal(back, ref)
