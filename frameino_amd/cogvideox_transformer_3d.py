@@ -171,6 +171,29 @@ class CogVideoXTransformer3DModel(nn.Module):
         return self
 
     # ---- packing ----
+    # ------------------------------------------------------------------ MXFP8 linears (BASELINE config 5)
+    def enable_mxfp8_linears(self, enabled=True):
+        """QKV, attention out, FFN up and FFN down of every block on the MXFP8 path (OCP e4m3 + one e8m0 scale per 32
+        K-elements, fp32 accumulate; `fino_quantize_mxfp8` / `fino_gemm_mxfp8`); weights are quantised once here.
+        Attention, norms, embeddings and the output head stay in the model dtype.  No reference counterpart (SURVEY
+        F11): compared with this model's own bf16 forward."""
+        self._fp8 = {}
+        if not enabled:
+            return self
+        pk = self._packed or self._pack()
+        for li, (blk, e) in enumerate(zip(self.transformer_blocks, pk.layers)):
+            for key, w in (("qkv", e.wqkv), ("out", blk.attn1.to_out[0].weight), ("ff1", blk.ff.net[0].proj.weight),
+                           ("ff2", blk.ff.net[2].weight)):
+                self._fp8[(li, key)] = ops.quantize_mxfp8(w.detach().contiguous())
+        return self
+
+    def _lin(self, li, key, x, w, b, epi=0, **kw):
+        wq = self._fp8.get((li, key)) if getattr(self, "_fp8", None) else None
+        if wq is None:
+            return ops.gemm(x, w, b, epi, **kw)
+        xq, xs = ops.quantize_mxfp8(x)
+        return ops.gemm_mxfp8(xq, xs, wq[0], wq[1], b, epi, **kw)
+
     def _pack(self):
         pk = SimpleNamespace(layers=[])
         f32 = lambda t: None if t is None else t.detach().float().contiguous()     # noqa: E731
@@ -281,13 +304,13 @@ class CogVideoXTransformer3DModel(nn.Module):
             t1, t2 = tables[2 * li], tables[2 * li + 1]                              # [2B, 3, D]
             n = ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
             if pk.default_procs:
-                qkv = ops.gemm(n, e.wqkv, e.bqkv).view(b, L, 3 * d)
+                qkv = self._lin(li, "qkv", n, e.wqkv, e.bqkv).view(b, L, 3 * d)
                 nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
                 ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt)
                 ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
                 att = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads)
-                ops.gemm(att.view(b * L, d), blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
-                         ops.EPI_GATED_RESIDUAL_STAGED, residual=x2, gate=t1[:, 2], sel=sel, out=x2)
+                self._lin(li, "out", att.view(b * L, d), blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
+                          ops.EPI_GATED_RESIDUAL_STAGED, residual=x2, gate=t1[:, 2], sel=sel, out=x2)
             else:
                 n3 = n.view(b, L, d)
                 ah, ae = blk.attn1(hidden_states=n3[:, lt:], encoder_hidden_states=n3[:, :lt],
@@ -295,9 +318,9 @@ class CogVideoXTransformer3DModel(nn.Module):
                 y = torch.cat([ae, ah], dim=1).reshape(b * L, d)
                 ops.gated_residual(x2, y, t1[:, 2], sel, out=x2, staged=True)
             n = ops.layernorm_zero(x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
-            ff = ops.gemm(n, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
-            ops.gemm(ff, blk.ff.net[2].weight, blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED, residual=x2,
-                     gate=t2[:, 2], sel=sel, out=x2)
+            ff = self._lin(li, "ff1", n, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
+            self._lin(li, "ff2", ff, blk.ff.net[2].weight, blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED,
+                      residual=x2, gate=t2[:, 2], sel=sel, out=x2)
 
         # 4. final norms + projection (:531-542) on the video rows
         outs = []

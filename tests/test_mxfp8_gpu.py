@@ -86,3 +86,22 @@ def test_wan_model_with_mxfp8_linears_vs_own_bf16():
     r = rel_rms(out, ref.float())
     print(f"mxfp8-linears forward vs own bf16 forward: rel-RMS {r:.4f}")
     assert 1e-4 < r < 0.1 and torch.equal(back, ref)
+
+
+def test_cog_model_with_mxfp8_linears_vs_own_bf16(golden):
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from tests.test_oracle_golden import _cog_cfg
+    cfg, sd, a = golden("cog_dit_tiny")
+    cfg = _cog_cfg(cfg)
+    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    m = m.eval()
+    run = lambda: m(hidden_states=a["x_def"].to(DEV).bfloat16(), encoder_hidden_states=a["txt_def"].to(DEV).bfloat16(),   # noqa: E731
+                    timestep=a["ts_def"].to(DEV), image_rotary_emb=(a["cos_def"].to(DEV), a["sin_def"].to(DEV)),
+                    return_dict=False)[0]
+    ref = run()
+    m.enable_mxfp8_linears()
+    out = run()
+    r = rel_rms(out, ref.float())
+    print(f"cog mxfp8-linears forward vs own bf16 forward: rel-RMS {r:.4f}")
+    assert r < 0.12

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--mxfp8", action="store_true", help="QKV / out / FFN linears on the MXFP8 path (config 5)")
     a = ap.parse_args()
     from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
@@ -40,6 +41,8 @@ def main():
         for name, b in m.named_buffers():
             b.data = (0.02 * torch.randn(b.shape, generator=g, device=dev)).to(b.dtype)
     m = m.eval()
+    if a.mxfp8:
+        m.enable_mxfp8_linears()
     pipe = CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())
     F, C, h, w = 13, 16, 60, 90
     lat = torch.randn(1, F, C, h, w, device=dev, generator=g)
@@ -60,7 +63,7 @@ def main():
     dt = (seen[-1] - seen[a.warmup - 1]) / a.steps if a.warmup else (seen[-1] - seen[0]) / (a.steps - 1)
     L, d, nl = 226 + 14 * 30 * 45, 3072, cfg["num_layers"]
     flops = 2 * nl * (8 * L * d * d + 4 * L * L * d + 16 * L * d * d)          # B=2: proj + SDPA + FFN (4x)
-    print(f"CogVideoX-5B FrameINO 49f 480x720 bf16: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
+    print(f"CogVideoX-5B FrameINO 49f 480x720 {'mxfp8 linears + bf16 attention' if a.mxfp8 else 'bf16'}: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
           f"{flops / dt / 1e12:.0f} TFLOP/s model ({nl} layers, L={L})")
 
 
