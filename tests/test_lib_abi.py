@@ -37,6 +37,27 @@ def test_version_and_error_channel(lib):
     assert rc == -1
 
 
+def test_argument_validation_of_the_later_entry_points(lib):
+    f1 = ctypes.c_float(1.0)
+    # workspace must be 16-byte aligned
+    rc = lib.fino_attn_fwd_ws(16, 16, 16, 16, 1, 1, 8, 8, 128, *([8] * 12), f1, 0, 24, 1024, 0)
+    assert rc == -1 and b"workspace" in lib.fino_last_error()
+    assert lib.fino_attn_workspace_bytes(1, 24, 12320, 12320, 96) == 0        # unsupported head_dim: nothing to split
+    assert lib.fino_attn_workspace_bytes(2, 24, 12320, 12320, 128) > 0        # the bench shape has a partial last round
+    # MXFP8: K (= cols) must be a multiple of 128
+    assert lib.fino_mxfp8_scale_bytes(256, 100) == 0 and lib.fino_mxfp8_scale_bytes(300, 256) == 2 * 2 * 1024
+    rc = lib.fino_quantize_mxfp8(16, 16, 16, 4, 100, 104, 0, 0)
+    assert rc == -1 and b"multiple of 128" in lib.fino_last_error()
+    rc = lib.fino_gemm_mxfp8(16, 16, 16, 16, 0, 16, 8, 8, 64, 8, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -1 and b"multiple of 128" in lib.fino_last_error()
+    # UniPC step: null history buffers
+    rc = lib.fino_cfg_unipc_step(16, 0, 16, 0, 16, 16, 4, 3, 4, 8, 8, 16, 0, 0)
+    assert rc == -1 and b"null" in lib.fino_last_error()
+    # trajectory builder: even tap count
+    rc = lib.fino_traj_blur_quantize(16, 16, 16, 16, 44, 3, 8, 8, 0)
+    assert rc == -1 and b"odd" in lib.fino_last_error()
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from frameino_amd import ops
