@@ -198,3 +198,37 @@ def test_cog_full_call_plumbing_with_a_stand_in_vae(golden):
     assert vid.shape == (1, frames, H, W, 3) and vid.min() >= 0.0 and vid.max() <= 1.0
     with pytest.raises(NotImplementedError):
         CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())(image=image)
+
+
+def test_baseline_config1_shape_full_width_two_layers_vs_oracle():
+    """BASELINE config 1's shape class: the STAGE-1 CogVideoX-5B model (`use_FrameIn=False`) on 13 frames
+    256x256 -> hidden_states [2, 4, 48, 32, 32], text [2, 226, 4096], L = 226 + 1024, resized learned PE -- at the real
+    widths (D = 3072, 48 heads x 64, FFN 12288) with 2 of the 42 identical layers, against the oracle in fp32."""
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG
+    from frameino_amd.pipeline_cogvideox_i2v_motion import CogVideoXImageToVideoPipeline
+    from oracle import cog_dit as C
+    cfg = dict(COGVIDEOX_5B_FRAMEINO_CFG, use_FrameIn=False, num_layers=2)
+    torch.manual_seed(0)
+    m = CogVideoXTransformer3DModel(**cfg)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.02 if p.ndim > 1 else 0.1) +
+                    (1.0 if name.endswith("norm.weight") or "norm_q.weight" in name or "norm_k.weight" in name else 0.0))
+        m.patch_embed.pos_embedding.copy_(torch.randn(m.patch_embed.pos_embedding.shape, generator=g) * 0.1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 4, 48, 32, 32, generator=g)
+    txt = torch.randn(2, 226, 4096, generator=g)
+    ts = torch.tensor([601.0, 601.0])
+    pipe = CogVideoXImageToVideoPipeline(transformer=m, scheduler=None)
+    cos, sin = pipe._prepare_rotary_positional_embeddings(256, 256, 4, "cpu")
+    assert cos.shape == (4 * 16 * 16, 64)
+    ref = C.cog_forward(sd, cfg, x, txt, ts, (cos, sin))
+    hm = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    hm.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    out = hm.eval()(hidden_states=x.to(DEV).bfloat16(), encoder_hidden_states=txt.to(DEV).bfloat16(), timestep=ts.to(DEV),
+                    image_rotary_emb=(cos.to(DEV), sin.to(DEV)), return_dict=False)[0]
+    r = rel_rms(out, ref)
+    print(f"config-1 shape, full width, 2 layers: hip bf16 vs oracle fp32 rel-RMS {r:.4f}")
+    assert out.shape == ref.shape == (2, 4, 16, 32, 32) and r < 4e-2
