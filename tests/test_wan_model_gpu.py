@@ -109,3 +109,24 @@ def test_fp16_model_vs_reference_golden_and_oracle(golden):
         r32, rh = rel_rms(out, a[y]), rel_rms(out, refh)
         print(f"[{ts}] fp16 hip-vs-fp32 {r32:.5f}  hip-vs-fp16-oracle {rh:.5f}")
         assert r32 < 5e-3 and rh < 2.5e-3, (ts, r32, rh)
+
+
+def test_full_width_two_layers_vs_oracle():
+    """The real Wan2.2-5B widths (D = 3072, 24 heads x 128, FFN 14336, text 4096, 96 -> 48 channels) with 2 of the 30
+    identical layers, per-token timesteps {0, t} as the FrameINO pipeline builds them, against the oracle in fp32 and in
+    bf16 (same rounding points)."""
+    cfg = dict(W.WAN22_5B_CFG, num_layers=2)
+    sd = W.wan_random_state_dict(cfg, seed=11, dtype=torch.float32, std=0.02)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 96, 4, 16, 32, generator=g)
+    txt = torch.randn(1, 64, 4096, generator=g)
+    L = 4 * 8 * 16
+    ts = torch.full((1, L), 655.0)
+    ts[0, :128] = 0.0
+    ref32 = W.wan_forward(sd, cfg, x, ts, txt)
+    refb = W.wan_forward(bf16_state_dict(sd), cfg, x.bfloat16(), ts, txt.bfloat16()).float()
+    m = hip_wan_model(cfg, sd, DEV)
+    out = m(x.to(DEV).bfloat16(), ts.to(DEV), txt.to(DEV).bfloat16(), return_dict=False)[0]
+    r32, rb = rel_rms(out, ref32), rel_rms(out, refb)
+    print(f"full width, 2 layers: hip-vs-fp32 {r32:.4f}  hip-vs-bf16-oracle {rb:.4f}")
+    assert out.shape == (1, 48, 4, 16, 32) and r32 < 3e-2 and rb < 1.5e-2
