@@ -119,3 +119,28 @@ def test_pipeline_conditions_and_video_of_the_recorded_reference_run(golden):
     video = vae.decode(a["out_latents"].to(DEV) / inv_std + mean, return_dict=False)[0]
     got = (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
     assert psnr(got, a["out_video"], peak=1.0) > 35.0
+
+
+def test_full_width_vae_vs_oracle_small_video():
+    """The real Wan2.2 VAE widths (base 160 / decoder 256, z = 48, 2x2 patchify, residual blocks) with seeded random
+    weights on a small video (9 frames 64x96 -> 3 latent frames 4x6 and back), against the oracle in fp32: the wide
+    channel counts (up to 1024) and every conv geometry at their real K, which the tiny golden cannot reach."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    from oracle import wan_vae as V
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=5, device=DEV)
+    sd = {k: v.float().cpu() for k, v in vae._sd.items()}
+    cfg = dict(WAN22_VAE_CFG)
+    g = torch.Generator().manual_seed(6)
+    vid = torch.rand(1, 3, 9, 64, 96, generator=g) * 2 - 1
+    ref_z = V.wan_vae_encode(sd, cfg, vid)                       # moments [1, 96, 3, 4, 6]
+    post = vae.encode(vid.to(DEV)).latent_dist
+    assert post.parameters.shape == ref_z.shape
+    r_enc = rel_rms(post.parameters, ref_z)
+    z = torch.randn(1, 48, 3, 4, 6, generator=g)
+    ref_v = V.wan_vae_decode(sd, cfg, z)
+    out = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert out.shape == ref_v.shape == (1, 3, 9, 64, 96)
+    p = psnr(out, ref_v)
+    print(f"full-width VAE: encode rel-RMS {r_enc:.4f}, decode PSNR {p:.1f} dB")
+    assert r_enc < 3e-2 and p > 35.0
