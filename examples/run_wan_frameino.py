@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--prompt", default="A corgi runs into the frame from the left.")
     ap.add_argument("--scheduler", choices=["euler", "unipc"], default="unipc")
     ap.add_argument("--smoke", action="store_true", help="tiny random model + tiny VAE, 64x96, 5 frames")
+    ap.add_argument("--repeat", type=int, default=1, help="generate the clip this many times (the first call is cold)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
 
@@ -106,15 +107,20 @@ def main():
     else:
         kw = dict(prompt=a.prompt, negative_prompt="")
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    frames = pipe(image=canvas, traj_tensor=traj, ID_tensor=id_tensor, height=a.height, width=a.width,
-                  num_frames=a.frames, num_inference_steps=a.steps, guidance_scale=a.guidance,
-                  generator=torch.Generator().manual_seed(1234), **kw).frames[0]
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    assert frames.shape == (a.frames, a.height, a.width, 3) and np.isfinite(frames).all()
-    print(f"conditions {t1 - t0:.2f} s, clip ({a.frames} frames {a.height}x{a.width}, {a.steps} steps, "
-          f"{a.scheduler}) {t2 - t1:.2f} s, frames in [{frames.min():.3f}, {frames.max():.3f}]")
+    tc = time.perf_counter()
+    for rep in range(a.repeat):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        frames = pipe(image=canvas, traj_tensor=traj, ID_tensor=id_tensor, height=a.height, width=a.width,
+                      num_frames=a.frames, num_inference_steps=a.steps, guidance_scale=a.guidance,
+                      generator=torch.Generator().manual_seed(1234), **kw).frames[0]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert frames.shape == (a.frames, a.height, a.width, 3) and np.isfinite(frames).all()
+        cond_s = f"conditions {tc - t0:.2f} s, " if rep == 0 else ""
+        print(f"{cond_s}clip ({a.frames} frames {a.height}x{a.width}, {a.steps} steps, "
+              f"{a.scheduler}) {t2 - t1:.2f} s{' (cold)' if rep == 0 and a.repeat > 1 else ''}, "
+              f"frames in [{frames.min():.3f}, {frames.max():.3f}]")
     if a.out:
         np.save(a.out, frames)
 
