@@ -135,6 +135,10 @@ def sdpa_ref(q, k, v, heads):
     (1, 24, 128, 513, 512),    # all heads -> exercises the XCD mapping
     (2, 5, 64, 700, 700),      # CogVideoX head size, batch 2, ragged
     (1, 1, 64, 31, 1),         # single key
+    (1, 2, 128, 1, 64),        # one query, exactly one full key tile
+    (1, 2, 128, 257, 65),      # two tiles, one key in the second; query block boundary + 1
+    (2, 3, 64, 256, 128),      # exactly two tiles, exactly one query block
+    (1, 9, 128, 40, 193),      # odd head count, three tiles + 1 key
 ])
 def test_attention_vs_fp32_sdpa(ops, dtype, b, heads, dh, lq, lk):
     q = rnd(b, lq, heads * dh, dtype=dtype, seed=11)
