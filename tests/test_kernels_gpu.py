@@ -236,6 +236,8 @@ def gemm_ref(a, w, bias, epi, residual=None, gate=None, sel=None):
     (257, 192, 384),     # N < tile (proj_out / patch-embed shapes)
     (72, 48, 48),        # generic path: K not a multiple of 64 (tiny test models)
     (5, 3072, 64),       # tiny M
+    (256, 264, 128),     # exactly one row tile, ragged N (multiple of 8), two K-tiles
+    (513, 256, 192),     # three K-tiles (odd count through the ping-pong phases), M = 2 tiles + 1 row
 ])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_epilogues(ops, dtype, m, n, k, epi):
