@@ -37,6 +37,7 @@ SIGNATURES = {
     "fino_mxfp8_scale_bytes": [c_i64, c_i64],
     "fino_quantize_mxfp8": [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p],
     "fino_gemm_mxfp8": [c_void_p] * 6 + [c_i64] * 4 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
+    "fino_gemm_mxfp8_q": [c_void_p] * 7 + [c_i64] * 3 + [c_int, c_int, c_void_p],
     "fino_traj_paint": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fino_traj_blur_quantize": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],

@@ -318,9 +318,16 @@ class CogVideoXTransformer3DModel(nn.Module):
                 y = torch.cat([ae, ah], dim=1).reshape(b * L, d)
                 ops.gated_residual(x2, y, t1[:, 2], sel, out=x2, staged=True)
             n = ops.layernorm_zero(x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
-            ff = self._lin(li, "ff1", n, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
-            self._lin(li, "ff2", ff, blk.ff.net[2].weight, blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED,
-                      residual=x2, gate=t2[:, 2], sel=sel, out=x2)
+            fp8 = getattr(self, "_fp8", None) or {}
+            w1q, w2q = fp8.get((li, "ff1")), fp8.get((li, "ff2"))
+            if w1q is not None and w2q is not None:
+                hq = ops.gemm_mxfp8_q(*ops.quantize_mxfp8(n), w1q[0], w1q[1], blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
+                ops.gemm_mxfp8(hq[0], hq[1], w2q[0], w2q[1], blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED,
+                               residual=x2, gate=t2[:, 2], sel=sel, out=x2)
+            else:
+                ff = self._lin(li, "ff1", n, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
+                self._lin(li, "ff2", ff, blk.ff.net[2].weight, blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED,
+                          residual=x2, gate=t2[:, 2], sel=sel, out=x2)
 
         # 4. final norms + projection (:531-542) on the video rows
         outs = []

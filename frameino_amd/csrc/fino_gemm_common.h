@@ -26,7 +26,41 @@ struct GemmParams {
     int to, ho, wo, ti, hi, wi;      // output / input extents
     int kt, kh, kw, st, sh, sw, pt, ph, pw, up, cin_chunks;
     const uint16_t* zero_page;       // >= 128 B of zeros: source of out-of-range taps (LDS-DMA cannot zero-fill)
+    // MXFP8 output (QOUT epilogues of the fp8 kernel): e4m3 bytes [m, n] + scales in the fino_quantize_mxfp8 layout
+    uint8_t* cq;
+    uint8_t* cs;
+    int64_t cs_rows_pad;
 };
+
+// ---- MXFP8 quantisation of 8 consecutive values held by one lane; 4 adjacent lanes form the 32-element block ----
+// e = exponent with amax / 2^e in (224, 448]; returns the 8 e4m3 bytes (lo, hi words) and e through `e_out`.
+__device__ __forceinline__ uint2 mx_quant8(const float (&v)[8], int& e_out) {
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    int e = -127;
+    if (amax > 0.f) {
+        int ex;
+        (void)frexpf(amax * (1.0f / 448.0f), &ex);      // amax/448 = f * 2^ex, f in [0.5, 1)
+        e = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+    }
+    const float inv = __builtin_amdgcn_ldexpf(1.0f, -e);
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, w1, true);
+    e_out = e;
+    return make_uint2((uint32_t)w0, (uint32_t)w1);
+}
+
+// index of the e8m0 scale of (row, 32-column block starting at col) in the [cols/128][rows_pad/256][1024] layout
+__device__ __forceinline__ int64_t mx_scale_index(int64_t row, int64_t col, int64_t rows_pad) {
+    const int rr = (int)(row & 255);
+    return ((col >> 7) * (rows_pad >> 8) + (row >> 8)) * 1024 + ((col >> 5) & 3) * 256 + (rr & 15) * 16 + (rr >> 4);
+}
 
 __device__ __forceinline__ float gelu_tanh_f32(float x) {
     // 0.5*x*(1+tanh(u)) == x*sigmoid(2u),  u = sqrt(2/pi)*(x + 0.044715 x^3)
@@ -58,7 +92,7 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
 }
 
 // Shared by both main-loop variants.  Every wave must be past its last LDS operand read (barrier) before the call.
-template <typename T, int EPI>
+template <typename T, int EPI, bool QOUT = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[8][4], const GemmParams& p, char* smem, int64_t m0,
                                               int64_t n0, int tid, int lane, int wm, int wn) {
     // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
@@ -147,7 +181,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[8][4], const GemmPa
             }
             yv = pack8<T>(o);
         }
-        *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
+        if constexpr (QOUT) {
+            // the T-rounded result quantised in place of a separate pass: same bytes as fino_quantize_mxfp8 on C
+            float y[8];
+            unpack8<T>(yv, y);
+            int e;
+            const uint2 qv = mx_quant8(y, e);
+            *reinterpret_cast<uint2*>(p.cq + gm * p.n + gn) = qv;
+            if ((ch & 3) == 0) p.cs[mx_scale_index(gm, gn, p.cs_rows_pad)] = (uint8_t)(e + 127);
+        } else {
+            *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
+        }
     }
 }
 

@@ -45,37 +45,17 @@ __global__ __launch_bounds__(256) void mxfp8_quantize_kernel(const uint16_t* __r
         const int64_t c = (i - row * chunks) * 8;
         float v[8];
         unpack8<T>(*reinterpret_cast<const uint4*>(x + row * ldx + c), v);
-        float amax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-        int e = -127;
-        if (amax > 0.f) {
-            int ex;
-            (void)frexpf(amax * (1.0f / 448.0f), &ex);      // amax/448 = f * 2^ex, f in [0.5, 1)
-            e = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
-        }
-        const float inv = __builtin_amdgcn_ldexpf(1.0f, -e);
-        int w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, w1, true);
-        *reinterpret_cast<uint2*>(q + row * cols + c) = make_uint2((uint32_t)w0, (uint32_t)w1);
+        int e;
+        const uint2 qv = mx_quant8(v, e);
+        *reinterpret_cast<uint2*>(q + row * cols + c) = qv;
         // scales of one (K-tile of 128, 256-row tile): 1 KiB ordered [K-block g][row & 15][row >> 4], so that the
         // 8 (A) / 4 (W) fragment scales a GEMM lane needs are one ds_read_b64 / ds_read_b32
-        if ((c & 31) == 0) {
-            const int64_t rt = row >> 8;
-            const int rr = (int)(row & 255);
-            scales[((c >> 7) * (rows_pad >> 8) + rt) * 1024 + ((c >> 5) & 3) * 256 + (rr & 15) * 16 + (rr >> 4)] =
-                (uint8_t)(e + 127);
-        }
+        if ((c & 31) == 0) scales[mx_scale_index(row, c, rows_pad)] = (uint8_t)(e + 127);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- GEMM
-template <typename T, int EPI>
+template <typename T, int EPI, bool QOUT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_mxfp8_kernel(const Fp8Params fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmParams& p = fp.g;
@@ -227,14 +207,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_mxfp8_kernel(const Fp8Params
 #undef F8_DMA_A
 #undef F8_DMA_W
 #undef F8_DMA_S
-    gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
+    gemm_epilogue<T, EPI, QOUT>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool QOUT = false>
 int launch_mxfp8(const Fp8Params& fp, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel<T, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel<T, EPI, QOUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmemF8);
         if (e != hipSuccess) {
             fino_set_error("fino_gemm_mxfp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -242,7 +222,7 @@ int launch_mxfp8(const Fp8Params& fp, hipStream_t st) {
         }
         attr_set = true;
     }
-    gemm_mxfp8_kernel<T, EPI><<<dim3((unsigned)(fp.g.tiles_m * fp.g.tiles_n)), kThreads, kSmemF8, st>>>(fp);
+    gemm_mxfp8_kernel<T, EPI, QOUT><<<dim3((unsigned)(fp.g.tiles_m * fp.g.tiles_n)), kThreads, kSmemF8, st>>>(fp);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -286,6 +266,43 @@ extern "C" int fino_quantize_mxfp8(const void* x, void* q, void* scales, int64_t
                                                                    rows, cols, ldx, rows_pad);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
+}
+
+static int mxfp8_fill(Fp8Params& fp, const void* aq, const void* a_scales, const void* wq, const void* w_scales,
+                      const void* bias, int64_t m, int64_t n, int64_t k) {
+    GemmParams& p = fp.g;
+    p.a = (const uint16_t*)aq; p.w = (const uint16_t*)wq; p.bias = (const uint16_t*)bias;
+    p.m = m; p.n = n; p.k = k; p.lda = k; p.ldw = k;
+    p.tiles_m = (int)((m + BM - 1) / BM);
+    p.tiles_n = (int)((n + BN - 1) / BN);
+    fp.sa = (const uint8_t*)a_scales; fp.sw = (const uint8_t*)w_scales;
+    fp.m_pad = (m + 255) / 256 * 256; fp.n_pad = (n + 255) / 256 * 256;
+    return FINO_OK;
+}
+
+extern "C" int fino_gemm_mxfp8_q(const void* aq, const void* a_scales, const void* wq, const void* w_scales,
+                                 const void* bias, void* cq, void* c_scales, int64_t m, int64_t n, int64_t k,
+                                 int epilogue, int bias_dtype, void* stream) {
+    FINO_CHECK(bias_dtype == FINO_BF16 || bias_dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm_mxfp8_q: dtype %d", bias_dtype);
+    FINO_CHECK(aq && a_scales && wq && w_scales && cq && c_scales, FINO_ERR_ARG, "fino_gemm_mxfp8_q: null pointer");
+    FINO_CHECK(m >= 0 && n > 0 && k > 0 && k % 128 == 0 && n % 128 == 0, FINO_ERR_ARG,
+               "fino_gemm_mxfp8_q: K=%lld and N=%lld must be multiples of 128", (long long)k, (long long)n);
+    FINO_CHECK(epilogue == FINO_EPI_NONE || epilogue == FINO_EPI_GELU_TANH, FINO_ERR_ARG,
+               "fino_gemm_mxfp8_q: epilogue %d (NONE or GELU_TANH)", epilogue);
+    FINO_CHECK(fino_aligned16(aq) && fino_aligned16(wq) && fino_aligned16(a_scales) && fino_aligned16(w_scales) &&
+                   ((uintptr_t)cq & 7) == 0,
+               FINO_ERR_ARG, "fino_gemm_mxfp8_q: alignment");
+    FINO_CHECK(m * k < (1ll << 31) && n * k < (1ll << 31), FINO_ERR_UNSUPPORTED, "fino_gemm_mxfp8_q: operand > 2 GiB");
+    if (m == 0) return FINO_OK;
+    Fp8Params fp = {};
+    mxfp8_fill(fp, aq, a_scales, wq, w_scales, bias, m, n, k);
+    fp.g.cq = (uint8_t*)cq; fp.g.cs = (uint8_t*)c_scales; fp.g.cs_rows_pad = fp.m_pad;
+    hipStream_t st = (hipStream_t)stream;
+    if (bias_dtype == FINO_BF16)
+        return epilogue == FINO_EPI_NONE ? launch_mxfp8<BF16, FINO_EPI_NONE, true>(fp, st)
+                                         : launch_mxfp8<BF16, FINO_EPI_GELU_TANH, true>(fp, st);
+    return epilogue == FINO_EPI_NONE ? launch_mxfp8<F16, FINO_EPI_NONE, true>(fp, st)
+                                     : launch_mxfp8<F16, FINO_EPI_GELU_TANH, true>(fp, st);
 }
 
 extern "C" int fino_gemm_mxfp8(const void* aq, const void* a_scales, const void* wq, const void* w_scales,

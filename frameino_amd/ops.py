@@ -259,6 +259,25 @@ def gemm_mxfp8(aq, a_scales, wq, w_scales, bias=None, epilogue=EPI_NONE, residua
     return out
 
 
+def gemm_mxfp8_q(aq, a_scales, wq, w_scales, bias, epilogue=EPI_NONE, out=None):
+    """MXFP8 GEMM whose result leaves quantised: -> (q uint8 [M, N], scales) ready to be the next MXFP8 GEMM's A."""
+    m, k = aq.shape
+    n = wq.shape[0]
+    assert bias is not None and wq.shape[1] == k
+    if out is None:
+        q = torch.empty((m, n), dtype=torch.uint8, device=aq.device)
+        s = torch.zeros(_lib.lib().fino_mxfp8_scale_bytes(m, n), dtype=torch.uint8, device=aq.device)
+    else:
+        q, s = out
+    ev = _timed("gemm")
+    _lib.check(_lib.lib().fino_gemm_mxfp8_q(_p(aq), _p(a_scales), _p(wq), _p(w_scales), _p(bias), _p(q), _p(s), m, n, k,
+                                           epilogue, _dt(bias), _stream()), "fino_gemm_mxfp8_q")
+    if ev is not None:
+        ev.record()
+        KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
+    return q, s
+
+
 def skinny_linear(x, w, b=None, silu_input=False):
     """fp32 y = W.(silu?)(x) + b for M <= 16 rows; w fp32 or bf16/fp16."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and w.is_contiguous()

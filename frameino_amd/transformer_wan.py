@@ -447,9 +447,16 @@ class WanTransformer3DModel(nn.Module):
                 o.gated_residual(x, a.reshape(nr, d), out=x)
             # 3. feed-forward (:344-348)
             o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
-            self._lin(li, "ff1", nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
-            self._lin(li, "ff2", ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
-                      gate=m[:, 5], sel=sel, out=x)
+            w1q, w2q = self._fp8.get((li, "ff1")), self._fp8.get((li, "ff2"))
+            if w1q is not None and w2q is not None:
+                # MXFP8: the GELU epilogue emits the hidden activations already quantised (no bf16 round trip)
+                hq = o.gemm_mxfp8_q(*o.quantize_mxfp8(nrm), w1q[0], w1q[1], blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH)
+                o.gemm_mxfp8(hq[0], hq[1], w2q[0], w2q[1], blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
+                             gate=m[:, 5], sel=sel, out=x)
+            else:
+                self._lin(li, "ff1", nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
+                self._lin(li, "ff2", ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
+                          gate=m[:, 5], sel=sel, out=x)
             yield
 
         # ---- output head (:519-543) ----

@@ -215,6 +215,12 @@ int fino_quantize_mxfp8(const void* x, void* q, void* scales, int64_t rows, int6
 int fino_gemm_mxfp8(const void* aq, const void* a_scales, const void* wq, const void* w_scales, const void* bias,
                     void* c, int64_t m, int64_t n, int64_t k, int64_t ldc, int epilogue, const void* r, int64_t ldr,
                     const float* gate, int64_t mod_stride, const int32_t* sel, int out_dtype, void* stream);
+/* Same product with the result QUANTISED in the epilogue (epilogue NONE or GELU_TANH): cq [M, N] e4m3 bytes + c_scales
+ * in the fino_quantize_mxfp8 layout, byte-identical to fino_quantize_mxfp8 applied to the bias_dtype-rounded C.  Feeds
+ * the next MXFP8 GEMM (FFN up -> FFN down) without the bf16 round trip through HBM.  N % 128 == 0. */
+int fino_gemm_mxfp8_q(const void* aq, const void* a_scales, const void* wq, const void* w_scales, const void* bias,
+                      void* cq, void* c_scales, int64_t m, int64_t n, int64_t k, int epilogue, int bias_dtype,
+                      void* stream);
 
 /* ---- condition builders in front of the path ---------------------------------------------------------
  * Trajectory video of data_loader/video_dataset_motion.py:120-206 (`prepare_traj_tensor`, app.py:616-620).

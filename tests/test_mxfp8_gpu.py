@@ -105,3 +105,22 @@ def test_cog_model_with_mxfp8_linears_vs_own_bf16(golden):
     r = rel_rms(out, ref.float())
     print(f"cog mxfp8-linears forward vs own bf16 forward: rel-RMS {r:.4f}")
     assert r < 0.12
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(300, 512, 256, 0), (1000, 1024, 384, 1)])
+def test_quantised_output_epilogue_equals_two_passes(m, n, k, epi):
+    """fino_gemm_mxfp8_q == fino_quantize_mxfp8(fino_gemm_mxfp8(...)), byte for byte."""
+    from frameino_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(m, k, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().to(DEV)
+    bias = torch.randn(n, generator=g).bfloat16().to(DEV)
+    aq, sa = ops.quantize_mxfp8(a)
+    wq, sw = ops.quantize_mxfp8(w)
+    q1, s1 = ops.gemm_mxfp8_q(aq, sa, wq, sw, bias, epi)
+    q2, s2 = ops.quantize_mxfp8(ops.gemm_mxfp8(aq, sa, wq, sw, bias, epi))
+    assert torch.equal(q1, q2)
+    rp = (m + 255) // 256 * 256
+    v1 = s1.view(n // 128, rp // 256, 4, 16, 16).permute(1, 4, 3, 0, 2).reshape(rp, n // 32)[:m]
+    v2 = s2.view(n // 128, rp // 256, 4, 16, 16).permute(1, 4, 3, 0, 2).reshape(rp, n // 32)[:m]
+    assert torch.equal(v1, v2)
