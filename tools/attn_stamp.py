@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 os.environ["FINO_LIB_PATH"] = os.path.join(ROOT, "frameino_amd/lib/libframeino_stamp.so")
 import torch
 from frameino_amd import ops
-L, D, H = 12320, 3072, 24
+L, D, H = (int(x) for x in (sys.argv[1:4] + ["12320", "3072", "24"][len(sys.argv) - 1:]))
+print(f"L={L} D={D} heads={H} head_dim={D // H}")
 qkv = torch.randn(1, L, 3 * D, device="cuda").bfloat16()
 for _ in range(3): ops.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H)
 torch.cuda.synchronize()
