@@ -178,3 +178,23 @@ def test_example_script_smoke():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "clip (5 frames 64x96" in r.stdout
+
+
+@pytest.mark.parametrize("sched", ["euler", "unipc"])
+def test_no_cfg_path_vs_oracle_loop(golden, sched):
+    """guidance_scale <= 1 (or no negative prompt): one forward per step (:862-882 skips the uncond call)."""
+    from frameino_amd.schedulers import UniPCMultistepScheduler
+    from oracle.schedulers import FlowMatchEulerOracle, UniPCOracle
+    from oracle.wan_pipeline import wan_denoise_loop
+    pipe, a = _pipe(golden)
+    if sched == "unipc":
+        pipe.scheduler = UniPCMultistepScheduler(flow_shift=5.0)
+    d = lambda k: a[k].to(DEV)                    # noqa: E731
+    out = pipe.denoise(d("latents0"), d("condition"), d("traj_latents"), d("id_latent"), d("mask"),
+                       d("prompt_embeds"), None, 1.0, 4)
+    cfg, sd, _ = golden("wan_pipe_tiny")
+    dit_sd = {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}
+    orc = UniPCOracle(flow_shift=5.0) if sched == "unipc" else FlowMatchEulerOracle(shift=5.0)
+    ref = wan_denoise_loop(dit_sd, cfg, orc, a["latents0"], a["condition"], a["traj_latents"], a["id_latent"],
+                           a["mask"], a["prompt_embeds"], None, 1.0, 4)
+    assert rel_rms(out, ref) < 5e-2
