@@ -76,6 +76,26 @@ def test_two_rank_plans_match_single_process(cfg_parallel, desc):
         torch.testing.assert_close(out, single, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("mode,desc", [("split", "cfg2xtoken2"), ("interleave", "token4x2branches-interleaved")])
+def test_four_rank_plans_match_single_process(mode, desc):
+    """BASELINE config 3's structure (4 ranks): cfg x token = 2 x 2, and both branches interleaved on 4 token shards."""
+    cfg, sd, a = load_golden("wan_pipe_tiny")
+    single = _run(_build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}), a)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, True, q, mode)) for r in range(4)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, d, out in outs:
+        assert d == desc
+        torch.testing.assert_close(out, single, atol=1e-5, rtol=1e-5)
+
+
 def test_token_shard_rows_cover_sequence_with_padding():
     from frameino_amd.parallel import TokenShard
     for L, ways in ((12320, 8), (12320, 4), (25088, 8), (101, 4), (72, 2)):
