@@ -226,6 +226,9 @@ def gemm_ref(a, w, bias, epi, residual=None, gate=None, sel=None):
     elif epi == 3:
         g = gate[sel.long()] if sel is not None else gate
         y = (residual.float() + y.float() * g).to(a.dtype)
+    elif epi == 4:                                   # staged: the gated product is rounded to T first (CogVideoX)
+        g = gate[sel.long()] if sel is not None else gate
+        y = (residual.float() + (y.float() * g).to(a.dtype).float()).to(a.dtype)
     return y
 
 
