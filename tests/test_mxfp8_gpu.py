@@ -124,3 +124,29 @@ def test_quantised_output_epilogue_equals_two_passes(m, n, k, epi):
     v1 = s1.view(n // 128, rp // 256, 4, 16, 16).permute(1, 4, 3, 0, 2).reshape(rp, n // 32)[:m]
     v2 = s2.view(n // 128, rp // 256, 4, 16, 16).permute(1, 4, 3, 0, 2).reshape(rp, n // 32)[:m]
     assert torch.equal(v1, v2)
+
+
+def _mx_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    return [(rng.choice([rng.randint(1, 700), 256 * rng.randint(1, 5), 256 * rng.randint(1, 5) + 3]),
+             8 * rng.randint(1, 200), 128 * rng.randint(1, 20), rng.randint(0, 4)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _mx_cases(16, 99), ids=lambda c: "m%d_n%d_k%d_e%d" % c)
+def test_gemm_mxfp8_random_shapes(case):
+    from frameino_amd import ops
+    from tests.test_kernels_gpu import gemm_ref
+    m, n, k, epi = case
+    g = torch.Generator(device=DEV).manual_seed(sum(case))
+    a = torch.randn(m, k, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(n, k, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(n, device=DEV, generator=g).bfloat16()
+    res = torch.randn(m, n, device=DEV, generator=g).bfloat16() if epi >= 2 else None
+    gate = torch.randn(2, n, device=DEV, generator=g) if epi >= 3 else None
+    sel = torch.randint(0, 2, (m,), device=DEV, generator=g).to(torch.int32) if epi >= 3 else None
+    aq, sa = ops.quantize_mxfp8(a)
+    wq, sw = ops.quantize_mxfp8(w)
+    out = ops.gemm_mxfp8(aq, sa, wq, sw, bias, epi, res, gate, sel)
+    ref = gemm_ref(dequant(aq, sa, m, k).to(DEV), dequant(wq, sw, n, k).to(DEV), bias, epi, res, gate, sel)
+    assert rel_rms(out, ref.float()) < 2.0 ** -7
