@@ -211,6 +211,7 @@ def main():
         # the price of smaller GEMMs -- which wins depends on the node's xGMI, so it is measured, not assumed.)
         snap = st.lat.clone()
         best = None
+        probe_ms = {}
         with torch.no_grad():
             for name, plan in plans.items():
                 shard_pipeline(pipe, rank, world, plan=plan)
@@ -224,12 +225,14 @@ def main():
                 sync()
                 tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                probe_ms[plan.desc] = tt.item() / 2 * 1e3
                 if rank == 0:
                     print(f"[bench] plan {plan.desc}: {tt.item() / 2 * 1e3:.1f} ms/step (probe)", file=sys.stderr, flush=True)
                 if best is None or tt.item() < best[0]:
                     best = (tt.item(), plan)
                 st.lat.copy_(snap)
         shard_pipeline(pipe, rank, world, plan=best[1])
+        pipe.plan_probe_ms = probe_ms
     with torch.no_grad():
         for i in range(a.warmup):
             if a.graph and i == 0:
@@ -284,6 +287,8 @@ def main():
                        "sec_per_50_step_clip_denoise_only": 50 * ms_step / 1e3,
                        "model_tflops_per_s": flops_step / (ms_step * 1e-3) / 1e12},
         }
+        if getattr(pipe, "plan_probe_ms", None):
+            out["config"]["plan_probe_ms_per_step"] = pipe.plan_probe_ms
         if vae_times is not None:
             enc_s, dec_s = vae_times
             out["config"].update({"vae_encode_conditions_s": enc_s, "vae_decode_s": dec_s,
