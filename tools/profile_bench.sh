@@ -20,7 +20,7 @@ for d in ("fetch", "write", "sq"):
     for f in glob.glob(f"gpurun_out/{tag}_{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "attn_" in k or "gemm_" in k:
+            if "(anonymous namespace)::" in k and "at::native" not in k:   # every kernel of libframeino_hip.so
                 pm[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out["pmc_avg_per_dispatch"] = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"dispatches": len(next(iter(d.values())))}
                                for k, d in pm.items()}
