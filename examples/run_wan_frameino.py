@@ -120,7 +120,8 @@ def main():
         cond_s = f"conditions {tc - t0:.2f} s, " if rep == 0 else ""
         print(f"{cond_s}clip ({a.frames} frames {a.height}x{a.width}, {a.steps} steps, "
               f"{a.scheduler}) {t2 - t1:.2f} s{' (cold)' if rep == 0 and a.repeat > 1 else ''}, "
-              f"frames in [{frames.min():.3f}, {frames.max():.3f}]")
+              f"frames in [{frames.min():.3f}, {frames.max():.3f}], peak device memory "
+              f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if a.out:
         np.save(a.out, frames)
 
