@@ -42,23 +42,8 @@ def wan_flops_per_forward(L, cfg, text_len=512):
 
 def build_model(cfg, device, seed=0):
     """Random-init Wan2.2-5B (no checkpoints offline): N(0, 0.02^2) weights generated on the device."""
-    from frameino_amd.transformer_wan import WanTransformer3DModel
-    torch.manual_seed(seed)
-    with torch.device("meta"):
-        m = WanTransformer3DModel(**cfg)
-    m = m.to_empty(device=device)
-    g = torch.Generator(device=device).manual_seed(seed)
-    keep = WanTransformer3DModel._keep_in_fp32_modules
-    with torch.no_grad():
-        for name, p in m.named_parameters():
-            if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm2.weight"):
-                t = 1.0 + 0.05 * torch.randn(p.shape, generator=g, device=device)
-            elif "scale_shift_table" in name:
-                t = torch.randn(p.shape, generator=g, device=device) / p.shape[-1] ** 0.5
-            else:
-                t = 0.02 * torch.randn(p.shape, generator=g, device=device)
-            p.data = t.to(torch.float32 if any(k in name for k in keep) else torch.bfloat16)
-    return m.eval()
+    from frameino_amd.random_init import random_wan_model
+    return random_wan_model(cfg, device, seed)
 
 
 def cpu_baseline(cfg, L, budget_s=25.0):
@@ -99,6 +84,41 @@ def cpu_baseline(cfg, L, budget_s=25.0):
                       f"layers x 2 forwards"}
 
 
+class Watchdog:
+    """Ends the process when a phase of the N>1 run stalls (a hung collective would otherwise lose the whole record).
+    `fallback` is a JSON line already measured: rank 0 prints it before leaving, so the driver still gets a valid
+    line.  Never re-exec: the process has touched the GPU; os._exit tears the context down."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.phase, self.deadline, self.fallback, self.ok = rank, "init", None, None, False
+        self._lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, phase, seconds, fallback=None, ok=False):
+        """ok: the result is already out, a stall in this phase (teardown) is not a failure"""
+        with self._lock:
+            self.phase, self.deadline, self.fallback, self.ok = phase, time.monotonic() + seconds, fallback, ok
+
+    def disarm(self):
+        with self._lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                if self.deadline is None or time.monotonic() < self.deadline:
+                    continue
+                phase, fb, ok = self.phase, self.fallback, self.ok
+            print(f"[bench] rank {self.rank}: phase '{phase}' stalled -- leaving"
+                  f"{' with the line already measured' if fb else ''}", file=sys.stderr, flush=True)
+            if fb is not None and self.rank == 0:
+                print(fb, flush=True)
+            os._exit(0 if (fb is not None or ok) else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,12 +128,18 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--cfg-streams", action="store_true", help="CFG branches on two concurrent streams (A/B)")
     ap.add_argument("--plan", choices=["auto", "split", "interleave"], default="auto",
-                    help="N>1: cfg x token split, both CFG branches interleaved on token shards, or probe both (>= 4 GPUs)")
+                    help="N>1: cfg x token split, both CFG branches interleaved on token shards, or (auto, >= 4 GPUs) "
+                         "measure split, then probe interleave under a watchdog and keep the faster")
     ap.add_argument("--mxfp8", action="store_true",
                     help="NOT the headline: large linears on the MXFP8 path (BASELINE config 5 style), attention in bf16")
+    ap.add_argument("--logit-scale", type=float, default=1.0,
+                    help="NOT the headline: scale of the attention-probe q (peaky logits make the rescale branch fire)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the once-per-clip VAE encode/decode timing")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary numbers (hipGraph replay, UniPC, config 4, config 5, attention probes)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
+    ap.add_argument("--stall-s", type=float, default=240.0, help="N>1: seconds a phase may take before the watchdog acts")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -127,11 +153,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    dog = Watchdog(rank) if world > 1 else None
     if world > 1:
+        dog.arm("init_process_group", a.stall_s)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        dog.disarm()
 
     from frameino_amd import _lib, ops
     _lib.load()                                   # no fallback: fail here if the HIP library is missing
@@ -156,48 +185,38 @@ def main():
     plans = {}
     if world > 1:
         from frameino_amd.parallel import make_plan, shard_pipeline
+        dog.arm("communicators", a.stall_s)
         # every rank creates every communicator, in the same order
         if a.plan in ("auto", "split"):
             plans["split"] = make_plan(rank, world, True, "split")
         if a.plan == "interleave" or (a.plan == "auto" and world >= 4):
             plans["interleave"] = make_plan(rank, world, mode="interleave")
         shard_pipeline(pipe, rank, world, plan=next(iter(plans.values())))
+        dog.disarm()
     pipe.use_hip_graph = a.graph
     pipe.cfg_streams = a.cfg_streams
 
-    g = torch.Generator().manual_seed(1234)           # CPU generator, then copy
-    lat = torch.randn(1, C, fg, lh, lw, generator=g).to(dev)
-    cond = torch.randn(1, C, 1, lh, lw, generator=g).to(dev)
-    traj = torch.randn(1, C, fg + nid, lh, lw, generator=g).to(dev)
-    traj[:, :, fg:] = 0
-    idl = torch.randn(1, C, nid, lh, lw, generator=g).to(dev)
-    mask = torch.ones(1, 1, fg, lh, lw, device=dev)
-    mask[:, :, 0] = 0
-    pe = torch.randn(1, 512, cfg["text_dim"], generator=g)
-    pe[:, 64:] = 0                                     # zero padding past the prompt length (:235-238)
-    ne = torch.randn(1, 512, cfg["text_dim"], generator=g)
-    ne[:, 8:] = 0
-    pe, ne = pe.to(dev).bfloat16(), ne.to(dev).bfloat16()
+    def make_inputs(fg_, lh_, lw_, text_dim):
+        g = torch.Generator().manual_seed(1234)           # CPU generator, then copy
+        lat = torch.randn(1, C, fg_, lh_, lw_, generator=g).to(dev)
+        cond = torch.randn(1, C, 1, lh_, lw_, generator=g).to(dev)
+        traj = torch.randn(1, C, fg_ + nid, lh_, lw_, generator=g).to(dev)
+        traj[:, :, fg_:] = 0
+        idl = torch.randn(1, C, nid, lh_, lw_, generator=g).to(dev)
+        mask = torch.ones(1, 1, fg_, lh_, lw_, device=dev)
+        mask[:, :, 0] = 0
+        pe = torch.randn(1, 512, text_dim, generator=g)
+        pe[:, 64:] = 0                                     # zero padding past the prompt length (:235-238)
+        ne = torch.randn(1, 512, text_dim, generator=g)
+        ne[:, 8:] = 0
+        return lat, cond, traj, idl, mask, pe.to(dev).bfloat16(), ne.to(dev).bfloat16()
 
+    lat, cond, traj, idl, mask, pe, ne = make_inputs(fg, lh, lw, cfg["text_dim"])
     total = a.warmup + a.steps
     pipe.scheduler.set_timesteps(max(total, 2), device=dev)
     st = pipe.make_state(lat, cond, traj, idl, mask, pe, ne, 5.0)
     ts, dts = pipe.scheduler.timesteps.to(dev).float(), pipe.scheduler.dts.to(dev)
-
-    graph = None
-
-    def one_step(i):
-        nonlocal graph
-        st.t_rows[1:2].copy_(ts[i:i + 1])
-        st.dt.copy_(dts[i:i + 1])
-        if a.graph:
-            if graph is None:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    pipe._step(st)
-            graph.replay()
-        else:
-            pipe._step(st)
+    lat0 = st.lat.clone()
 
     def sync():
         torch.cuda.synchronize()
@@ -205,56 +224,155 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if len(plans) > 1:
-        # probe: one warm + two timed steps per plan on this node, MAX over ranks, keep the faster plan.  (With one
-        # CFG branch per rank nothing can overlap the K|V all-gather; with both branches per rank it can hide, at
-        # the price of smaller GEMMs -- which wins depends on the node's xGMI, so it is measured, not assumed.)
-        snap = st.lat.clone()
-        best = None
-        probe_ms = {}
-        with torch.no_grad():
-            for name, plan in plans.items():
-                shard_pipeline(pipe, rank, world, plan=plan)
-                st.t_rows[1:2].copy_(ts[0:1])
-                st.dt.copy_(dts[0:1])
-                pipe._step(st)
-                sync()
-                t0 = time.perf_counter()
-                pipe._step(st)
-                pipe._step(st)
-                sync()
-                tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                probe_ms[plan.desc] = tt.item() / 2 * 1e3
-                if rank == 0:
-                    print(f"[bench] plan {plan.desc}: {tt.item() / 2 * 1e3:.1f} ms/step (probe)", file=sys.stderr, flush=True)
-                if best is None or tt.item() < best[0]:
-                    best = (tt.item(), plan)
-                st.lat.copy_(snap)
-        shard_pipeline(pipe, rank, world, plan=best[1])
-        pipe.plan_probe_ms = probe_ms
-    with torch.no_grad():
-        for i in range(a.warmup):
-            if a.graph and i == 0:
-                snap = st.lat.clone()
-                pipe._step(st)
-                st.lat.copy_(snap)
-            one_step(i)
-        sync()
-        timer = ops.KernelTimer({"attn_self"} if not a.graph else set())
-        t0 = time.perf_counter()
-        with timer:
-            for i in range(a.warmup, total):
-                one_step(i)
-        sync()
-        elapsed = time.perf_counter() - t0
-    if world > 1:                                     # MAX over ranks, before rank 0 goes off to time the VAE
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    # ---- once-per-clip stages (rank 0, outside the timed region): Wan VAE encode of the conditions + decode ----
+        return t.item()
+
+    def timed_run(warmup, steps, use_graph=False, timer_names=()):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize pairs; MAX over ranks."""
+        st.lat.copy_(lat0)
+        graph = None
+
+        def one_step(i):
+            nonlocal graph
+            i = min(i, ts.numel() - 1)
+            st.t_rows[1:2].copy_(ts[i:i + 1])
+            st.dt.copy_(dts[i:i + 1])
+            if use_graph:
+                if graph is None:
+                    snap = st.lat.clone()
+                    pipe._step(st)                       # eager pass fills every lazy cache before the capture
+                    st.lat.copy_(snap)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        pipe._step(st)
+                graph.replay()
+            else:
+                pipe._step(st)
+
+        with torch.no_grad():
+            for i in range(warmup):
+                one_step(i)
+            sync()
+            timer = ops.KernelTimer(set(timer_names))
+            t0 = time.perf_counter()
+            with timer:
+                for i in range(warmup, warmup + steps):
+                    one_step(i)
+            sync()
+            elapsed = time.perf_counter() - t0
+        return max_over_ranks(elapsed), timer
+
+    def kv_gather_us(plan):
+        """the K|V all-gather of one layer-call on this plan's communicator, alone on the wire (HIP events, rank 0)"""
+        sh = plan.shard
+        if sh.ways <= 1:
+            return None
+        _, n_, lpad = sh.rows(L)
+        buf = sh.kv_local(lpad, 2 * model.inner_dim, torch.bfloat16, dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(6):
+            if rep == 1:
+                torch.cuda.synchronize()
+                e0.record()
+            _, work = sh.all_gather_kv(buf)
+            if work is not None:
+                work.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5 * 1e3
+
+    base_cfg = {"workload": a.workload, "tokens": L, "layers": cfg["num_layers"], "guidance": 5.0, "id_frames": nid}
+
+    def result_line(elapsed, parallelism, extra_cfg, roofline=None, cpu=None, use_graph=False):
+        ms_step = elapsed / a.steps * 1e3
+        flops_step = 2 * wan_flops_per_forward(L, cfg)
+        out = {
+            "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
+            "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if not a.mxfp8 else "mxfp8 linears (e4m3 + e8m0/32) + bf16 attention -- not the headline",
+            "data": "synthetic",
+            "config": dict(base_cfg, hip_graph=bool(use_graph), parallelism=parallelism,
+                           sec_per_50_step_clip_denoise_only=50 * ms_step / 1e3,
+                           model_tflops_per_s=flops_step / (ms_step * 1e-3) / 1e12, **extra_cfg),
+        }
+        if a.layers:
+            out["config"]["INVALID_reduced_layers"] = a.layers
+        if roofline is not None:
+            out["roofline"] = roofline
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        return json.dumps(out)
+
+    # ================================================================ N > 1: strong scaling of the same clip
+    if world > 1:
+        names = list(plans)
+        first = plans[names[0]]
+        shard_pipeline(pipe, rank, world, plan=first)
+        dog.arm(f"timed run ({first.desc})", a.stall_s + 2.0 * total)
+        elapsed, _ = timed_run(a.warmup, a.steps)
+        assert torch.isfinite(st.lat).all(), "non-finite latents"
+        probe = {first.desc: elapsed / a.steps * 1e3}
+        gather_us = {first.desc: kv_gather_us(first)}
+
+        def line_for(el, plan):
+            return result_line(el, plan.desc, {"rccl_ranks": world, "backend": backend, "plan_probe_ms_per_step": probe,
+                                               "kv_allgather_us_per_layer_call": gather_us.get(plan.desc)})
+
+        best = (elapsed, first)
+        line = line_for(*best)
+        if len(names) > 1:
+            # The first plan's line exists; from here on a stall costs nothing: the watchdog prints that line and leaves.
+            second = plans[names[1]]
+            dog.arm(f"probe ({second.desc})", a.stall_s, fallback=line)
+            shard_pipeline(pipe, rank, world, plan=second)
+            el_p, _ = timed_run(1, 2)
+            probe[second.desc] = el_p / 2 * 1e3
+            gather_us[second.desc] = kv_gather_us(second)
+            if rank == 0:
+                print(f"[bench] {first.desc}: {probe[first.desc]:.1f} ms/step; {second.desc}: {probe[second.desc]:.1f} "
+                      f"ms/step (probe)", file=sys.stderr, flush=True)
+            if probe[second.desc] < 0.98 * probe[first.desc]:
+                dog.arm(f"timed run ({second.desc})", a.stall_s + 2.0 * total, fallback=line)
+                el2, _ = timed_run(a.warmup, a.steps)
+                if el2 < elapsed and bool(torch.isfinite(st.lat).all()):
+                    best = (el2, second)
+            line = line_for(*best)                                       # carries both plans' probe times
+        dog.disarm()
+        if rank == 0:
+            print(line, flush=True)
+        dog.arm("shutdown", 30.0, ok=True)           # the line is out: a hang in teardown is not a failed run
+        dist.destroy_process_group()
+        dog.disarm()
+        return
+
+    # ================================================================ N = 1: the headline + its evidence
+    elapsed, timer = timed_run(a.warmup, a.steps, use_graph=a.graph, timer_names=() if a.graph else ("attn_self",))
+    assert torch.isfinite(st.lat).all(), "non-finite latents"
+    ms_step = elapsed / a.steps * 1e3
+    extra = {}
+    heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
+
+    secondary = {}
+    if not a.no_secondary and a.workload == "wan2.2-5b-49f-704x1280" and not a.layers:
+        # (a) the same step replayed from a captured hipGraph (north_star: the sampler loop is graph-captured)
+        if not a.graph:
+            el_g, _ = timed_run(1, 5, use_graph=True)
+            extra["graph_ms_per_step"] = el_g / 5 * 1e3
+        # (b) UniPC (the scheduler the released Wan2.2 folder ships) instead of Euler: corrector+predictor+CFG kernel
+        extra["unipc_ms_per_step"] = unipc_ms_per_step(pipe, model, (lat, cond, traj, idl, mask, pe, ne), dev)
+        # (c) attention on peaky logits (q x 4: the deferred-rescale branch fires on most tiles) next to the N(0,1) case
+        secondary["attention_probe"] = attention_probe(ops, dev, L, heads, dh, a.logit_scale)
+        st.lat.copy_(lat0)
+
+    # ---- once-per-clip stages (outside the timed region): Wan VAE encode of the conditions + decode ----
     vae_times = None
-    if rank == 0 and a.workload != "tiny" and not a.no_vae:
+    if a.workload != "tiny" and not a.no_vae:
         from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
         from frameino_amd.configs import WAN22_VAE_CFG
         vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=2, device=dev)
@@ -268,51 +386,152 @@ def main():
                 vae.decode(st.lat[None], return_dict=False)
                 torch.cuda.synchronize(); t3 = time.perf_counter()
         vae_times = (t2 - t1, t3 - t2)
+        extra["peak_device_memory_gib"] = torch.cuda.max_memory_allocated() / 2 ** 30
         del vae, vid
-    assert torch.isfinite(st.lat).all(), "non-finite latents"
+        enc_s, dec_s = vae_times
+        extra.update({"vae_encode_conditions_s": enc_s, "vae_decode_s": dec_s,
+                      "sec_per_clip_50_steps": enc_s + 50 * ms_step / 1e3 + dec_s})
 
-    if rank == 0:
-        ms_step = elapsed / a.steps * 1e3
-        flops_step = 2 * wan_flops_per_forward(L, cfg)
-        out = {
-            "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
-            "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if not a.mxfp8 else "mxfp8 linears (e4m3 + e8m0/32) + bf16 attention -- not the headline",
-            "data": "synthetic",
-            "config": {"workload": a.workload, "tokens": L, "layers": cfg["num_layers"], "guidance": 5.0,
-                       "id_frames": nid, "hip_graph": bool(a.graph),
-                       "parallelism": getattr(pipe, "parallel_desc", "single"),
-                       "sec_per_50_step_clip_denoise_only": 50 * ms_step / 1e3,
-                       "model_tflops_per_s": flops_step / (ms_step * 1e-3) / 1e12},
-        }
-        if getattr(pipe, "plan_probe_ms", None):
-            out["config"]["plan_probe_ms_per_step"] = pipe.plan_probe_ms
-        if vae_times is not None:
-            enc_s, dec_s = vae_times
-            out["config"].update({"vae_encode_conditions_s": enc_s, "vae_decode_s": dec_s,
-                                  "sec_per_clip_50_steps": enc_s + 50 * ms_step / 1e3 + dec_s})
-        if a.layers:
-            out["config"]["INVALID_reduced_layers"] = a.layers
-        ks = timer.summary().get("attn_self") if not a.graph else None
-        heads, dh = cfg["num_attention_heads"], cfg["attention_head_dim"]
-        if ks:
-            traffic, traffic_src = profiled_traffic("attn_pp_kernel<BF16, 128, 0>")
-            # algorithmic FLOPs of the timed launches (4.Lq.Lk.H.Dh per batch element) / their summed duration
-            total_fl = timer.flops["attn_self"]
-            ach = total_fl / (ks["total_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "attn_pp_kernel<BF16,128,0> (3D self-attention)",
-                               "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                               "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                               "launches": ks["launches"], "avg_us": ks["avg_us"],
-                               "flops_per_launch": total_fl / ks["launches"],
-                               "batch_per_launch": 2 if (pipe.batch_cfg and world == 1) else 1}
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, L)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if not a.no_secondary and a.workload == "wan2.2-5b-49f-704x1280" and not a.layers and not a.mxfp8:
+        # (d) BASELINE config 4's per-GPU-independent part: the same model at 1024x1792 (L = 25088), whole on one GPU
+        secondary["config4_wan_1024x1792_L25088"] = config4_ms_per_step(pipe, make_inputs, cfg, dev)
+        # (e) BASELINE config 5: CogVideoX-5B FrameINO 49f 480x720, bf16 and MXFP8 linears
+        del pipe, st
+        model.reset_caches()
+        torch.cuda.empty_cache()
+        secondary.update(config5_ms_per_step(dev))
+    if secondary:
+        extra["secondary"] = secondary
+
+    roofline = None
+    ks = timer.summary().get("attn_self") if not a.graph else None
+    if ks:
+        traffic, traffic_src = profiled_traffic("attn_pp_kernel<BF16, 128, 0>")
+        # algorithmic FLOPs of the timed launches (4.Lq.Lk.H.Dh per batch element) / their summed duration
+        total_fl = timer.flops["attn_self"]
+        ach = total_fl / (ks["total_ms"] * 1e-3) / 1e12
+        batch = 2
+        alg_bytes = batch * 4 * L * heads * dh * 2           # Q, K, V read + O written, bf16
+        roofline = {"bound": "mfma", "kernel": "attn_pp_kernel<BF16,128,0> (3D self-attention)",
+                    "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "algorithmic_bytes": alg_bytes,
+                    "traffic_over_algorithmic": None if traffic is None else traffic / alg_bytes,
+                    "traffic_note": "K/V of one head (6.3 MB) exceed an XCD's 4 MiB L2 and are partly re-fetched; the "
+                                    "kernel is MFMA-bound (traffic / duration = 0.4 TB/s of 8)",
+                    "launches": ks["launches"], "avg_us": ks["avg_us"],
+                    "flops_per_launch": total_fl / ks["launches"], "batch_per_launch": batch}
+    cpu = None if a.no_cpu_baseline else cpu_baseline(cfg, L)
+    print(result_line(elapsed, "single", extra, roofline, cpu, use_graph=a.graph), flush=True)
+
+
+def unipc_ms_per_step(pipe_euler, model, inputs, dev, steps=3):
+    """The same step with the UniPC multistep update (corrector + predictor + CFG in one kernel, two extra fp32 history
+    buffers) instead of Euler -- what examples/run_wan_frameino.py runs with the released scheduler config."""
+    from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
+    from frameino_amd.schedulers import UniPCMultistepScheduler
+    pipe = WanImageToVideoPipeline(scheduler=UniPCMultistepScheduler(flow_shift=5.0), transformer=model,
+                                   expand_timesteps=True)
+    pipe.scheduler.set_timesteps(steps + 2, device=dev)
+    st = pipe.make_state(*inputs, 5.0)
+    coefs = pipe.scheduler.coefs.to(dev).clone()
+    coefs[:, 0] = 5.0
+    ts = pipe.scheduler.timesteps.to(dev).float()
+    with torch.no_grad():
+        for i in range(steps + 1):
+            if i == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            st.t_rows[1:2].copy_(ts[i:i + 1])
+            st.coef.copy_(coefs[i])
+            pipe._step(st)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def attention_probe(ops, dev, L, heads, dh, logit_scale):
+    """The dominant kernel alone at the bench shape (batch 2), on N(0,1) q/k (flat softmax rows: the deferred-rescale
+    branch almost never fires) and on peaky logits (q x 4, or --logit-scale: row maxima jump tile to tile)."""
+    d = heads * dh
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(7)
+    kv = torch.randn(2, L, 2 * d, device=dev, generator=g).bfloat16()
+    q0 = torch.randn(2, L, d, device=dev, generator=g)
+    for name, sc in (("q_x1", 1.0), ("q_x4_peaky", 4.0 if logit_scale == 1.0 else logit_scale)):
+        q = (q0 * sc).bfloat16()
+        o = torch.empty_like(q)
+        for _ in range(2):
+            ops.attention(q, kv[:, :, :d], kv[:, :, d:], heads, out=o)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.attention(q, kv[:, :, :d], kv[:, :, d:], heads, out=o)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 10 * 1e3
+        out[name] = {"avg_us": us, "tflops": 4.0 * 2 * L * L * d / (us * 1e-6) / 1e12, "logit_scale": sc}
+    return out
+
+
+def config4_ms_per_step(pipe, make_inputs, cfg, dev, steps=2):
+    """BASELINE config 4's clip (49 f 1024x1792 + ID frame, L = 25088) on ONE GPU: what each of the 8 ranks' shards add
+    up to before the wire.  1 warm + `steps` timed steps."""
+    fg, lh, lw = WORKLOADS["wan2.2-5b-49f-1024x1792"]
+    inputs = make_inputs(fg, lh, lw, cfg["text_dim"])
+    st = pipe.make_state(*inputs, 5.0)
+    ts, dts = pipe.scheduler.timesteps.to(dev).float(), pipe.scheduler.dts.to(dev)
+    with torch.no_grad():
+        for i in range(steps + 1):
+            if i == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            st.t_rows[1:2].copy_(ts[i:i + 1])
+            st.dt.copy_(dts[i:i + 1])
+            pipe._step(st)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    L = (fg + 1) * (lh // 2) * (lw // 2)
+    return {"ms_per_step": ms, "tokens": L, "steps": steps,
+            "model_tflops_per_s": 2 * wan_flops_per_forward(L, cfg) / (ms * 1e-3) / 1e12}
+
+
+def config5_ms_per_step(dev, steps=2):
+    """BASELINE config 5: CogVideoX-5B FrameINO, 49 f 480x720 -> model input [2, 14, 48, 60, 90], L = 226 + 18900, 42
+    layers, 48 heads x 64; one step = the B=2 forward + guidance + v-prediction DDIM update
+    (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944).  bf16, then MXFP8 linears (+ bf16 attention)."""
+    from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG as COG5B
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    from frameino_amd.random_init import random_cog_model
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    m = random_cog_model(dict(COG5B), dev)
+    pipe = CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())
+    g = torch.Generator(device=dev).manual_seed(1)
+    F_, C_, h, w = 13, 16, 60, 90
+    lat = torch.randn(1, F_, C_, h, w, device=dev, generator=g)
+    img = torch.cat([torch.randn(1, 1, C_, h, w, device=dev, generator=g), torch.zeros(1, F_ - 1, C_, h, w, device=dev)], 1)
+    trj = torch.randn(1, F_, C_, h, w, device=dev, generator=g)
+    idl = torch.randn(1, 1, C_, h, w, device=dev, generator=g)
+    pe = torch.randn(1, 226, 4096, device=dev, generator=g)
+    ne = torch.randn(1, 226, 4096, device=dev, generator=g)
+    L, d, nl = 226 + 14 * 30 * 45, 3072, COG5B["num_layers"]
+    flops = 2 * nl * (8 * L * d * d + 4 * L * L * d + 16 * L * d * d)          # B=2: proj + SDPA + FFN (4x)
+    out = {}
+    for key, fp8 in (("config5_cogvideox5b_480x720_bf16", False), ("config5_cogvideox5b_480x720_mxfp8_linears", True)):
+        if fp8:
+            m.enable_mxfp8_linears()
+        seen = []
+
+        def cb(p, i, t, kw):
+            torch.cuda.synchronize()
+            seen.append(time.perf_counter())
+            return {}
+
+        res = pipe.denoise(lat, img, trj, idl, pe, ne, 6.0, steps + 1, callback_on_step_end=cb)
+        assert torch.isfinite(res.float()).all()
+        ms = (seen[-1] - seen[0]) / steps * 1e3
+        out[key] = {"ms_per_step": ms, "denoise_steps_per_s": 1e3 / ms, "tokens": L, "steps": steps,
+                    "model_tflops_per_s": flops / (ms * 1e-3) / 1e12}
+    return out
 
 
 def profiled_traffic(kernel_substr):

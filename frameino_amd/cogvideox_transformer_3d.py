@@ -121,6 +121,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         self.proj_out = nn.Linear(inner, patch_size * patch_size * out_channels)
         self._packed = None
         self._pos_cache = {}
+        self._fp8 = {}
         self.original_attn_processors = None
 
     # ---- reference surface (:346-444) ----
@@ -166,9 +167,30 @@ class CogVideoXTransformer3DModel(nn.Module):
         with torch.no_grad():
             for k, t in list(self.named_parameters()) + list(self.named_buffers()):
                 t.data = sd[k].to(dtype or sd[k].dtype).to(t.device).contiguous()
-        self._packed = None
-        self._pos_cache.clear()
+        if self.reset_caches():
+            self.enable_mxfp8_linears()
         return self
+
+    def reset_caches(self):
+        """Drop everything derived from the parameters (packed / fused copies, MXFP8 weights, positional tables);
+        called whenever the parameters may have changed or moved."""
+        had_fp8 = bool(self._fp8)
+        self._packed = None
+        self._fp8 = {}
+        self._pos_cache.clear()
+        return had_fp8
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .half()
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_pos_cache") and self.reset_caches():
+            self.enable_mxfp8_linears()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if self.reset_caches():
+            self.enable_mxfp8_linears()
+        return out
 
     # ---- packing ----
     # ------------------------------------------------------------------ MXFP8 linears (BASELINE config 5)
@@ -188,11 +210,15 @@ class CogVideoXTransformer3DModel(nn.Module):
         return self
 
     def _lin(self, li, key, x, w, b, epi=0, **kw):
-        wq = self._fp8.get((li, key)) if getattr(self, "_fp8", None) else None
+        wq = self._fp8.get((li, key)) if self._fp8 else None
         if wq is None:
             return ops.gemm(x, w, b, epi, **kw)
         xq, xs = ops.quantize_mxfp8(x)
         return ops.gemm_mxfp8(xq, xs, wq[0], wq[1], b, epi, **kw)
+
+    def _default_processors(self):
+        return all(type(b.attn1.processor) in (MI355CogVideoXAttnProcessor, MI355FusedCogVideoXAttnProcessor)
+                   for b in self.transformer_blocks)
 
     def _pack(self):
         pk = SimpleNamespace(layers=[])
@@ -214,8 +240,6 @@ class CogVideoXTransformer3DModel(nn.Module):
         pk.w_patch = self.patch_embed.proj.weight.detach().reshape(self.inner_dim, -1).contiguous()
         pk.nfw, pk.nfb = f32(self.norm_final.weight), f32(self.norm_final.bias)
         pk.now, pk.nob = f32(self.norm_out.norm.weight), f32(self.norm_out.norm.bias)
-        pk.default_procs = all(type(b.attn1.processor) in (MI355CogVideoXAttnProcessor, MI355FusedCogVideoXAttnProcessor)
-                               for b in self.transformer_blocks)
         self._packed = pk
         return pk
 
@@ -256,6 +280,7 @@ class CogVideoXTransformer3DModel(nn.Module):
             attention_kwargs = dict(attention_kwargs)
             attention_kwargs.pop("scale", None)
         pk = self._packed or self._pack()
+        default_procs = self._default_processors()
         c = self.config
         b, nf, ch, hh, ww = hidden_states.shape
         d, heads, dh, ps = self.inner_dim, c.num_attention_heads, c.attention_head_dim, c.patch_size
@@ -303,7 +328,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         for li, (blk, e) in enumerate(zip(self.transformer_blocks, pk.layers)):
             t1, t2 = tables[2 * li], tables[2 * li + 1]                              # [2B, 3, D]
             n = ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
-            if pk.default_procs:
+            if default_procs:
                 qkv = self._lin(li, "qkv", n, e.wqkv, e.bqkv).view(b, L, 3 * d)
                 nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
                 ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt)
@@ -318,7 +343,7 @@ class CogVideoXTransformer3DModel(nn.Module):
                 y = torch.cat([ae, ah], dim=1).reshape(b * L, d)
                 ops.gated_residual(x2, y, t1[:, 2], sel, out=x2, staged=True)
             n = ops.layernorm_zero(x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
-            fp8 = getattr(self, "_fp8", None) or {}
+            fp8 = self._fp8
             w1q, w2q = fp8.get((li, "ff1")), fp8.get((li, "ff2"))
             if w1q is not None and w2q is not None:
                 hq = ops.gemm_mxfp8_q(*ops.quantize_mxfp8(n), w1q[0], w1q[1], blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)

@@ -821,17 +821,17 @@ __global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnPar
         }
 }
 
+// CU count of the current device (per-device cache; the tail-split plan and its workspace size depend on it)
 int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else
-            cus = 256;   // MI355X
+    static std::atomic<int> cus[kFinoMaxDevices];
+    const int dev = fino_current_device();
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int n = 0;
+        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cus[dev].store(c, std::memory_order_relaxed);
     }
-    return cus;
+    return c;
 }
 
 // Tail split plan.  One workgroup occupies a CU (2 waves/SIMD x 256 registers) and an XCD's CUs take its blocks in
@@ -862,22 +862,15 @@ inline SplitPlan plan_split(int batch, int heads, int nqb, int nt) {
 template <typename T, int D, int VAR>
 int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
-    static bool attr_set = false;
-    static bool pingpong = true;
-    if (!attr_set) {
+    static const bool pingpong = [] {
         const char* ev = getenv("FINO_ATTN_PP");          // A/B knob: 0 selects the one-barrier loop
-        pingpong = !(ev && ev[0] == '0') && kWaves == 8;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pp_kernel<T, D, VAR>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            fino_set_error("fino_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return FINO_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+        return !(ev && ev[0] == '0') && kWaves == 8;
+    }();
+    static FinoPerDeviceOnce once_a, once_b;
+    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
+        return rc;
+    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_pp_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
+        return rc;
     const int hb = p.batch * p.heads;
     const int groups = (hb + 7) / 8;
     SplitPlan sp{groups * p.nqb, 0, 0, 1};
@@ -934,6 +927,13 @@ extern "C" int fino_attn_fwd_ws(const void* q, const void* k, const void* v, voi
                    v_hs % 8 == 0 && o_hs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0,
                FINO_ERR_ARG, "fino_attn_fwd: pointers and strides must be 16-byte aligned");
     FINO_CHECK(scale > 0.f, FINO_ERR_ARG, "fino_attn_fwd: scale must be > 0");
+    // the kernels address the K/V rows of one (batch, head) through a buffer resource: 32-bit byte count and offsets
+    {
+        const int64_t kmax = k_rs > v_rs ? k_rs : v_rs;
+        FINO_CHECK(((lk - 1) * kmax + head_dim) * 2 < (1ll << 31), FINO_ERR_UNSUPPORTED,
+                   "fino_attn_fwd: Lk=%lld keys x row stride %lld exceed the 2 GiB one (batch, head) K/V slice may span",
+                   (long long)lk, (long long)kmax);
+    }
     if (lq == 0) return FINO_OK;
     AttnParams p;
     p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o;

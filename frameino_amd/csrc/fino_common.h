@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/frameino_hip.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -94,5 +96,28 @@ void fino_set_error(const char* fmt, ...);
             return FINO_ERR_LAUNCH;                                                \
         }                                                                          \
     } while (0)
+
+// Per-device one-time setup (a process may drive several GPUs, possibly from several host threads; hipFuncSetAttribute
+// applies to the current device only).  The guarded action is idempotent, so a benign double initialisation is harmless.
+constexpr int kFinoMaxDevices = 64;
+static inline int fino_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kFinoMaxDevices) dev = 0;
+    return dev;
+}
+struct FinoPerDeviceOnce {
+    std::atomic<int> done[kFinoMaxDevices];
+};
+static inline int fino_max_smem_once(FinoPerDeviceOnce& once, const void* fn, int bytes, const char* who) {
+    const int dev = fino_current_device();
+    if (once.done[dev].load(std::memory_order_acquire)) return FINO_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        fino_set_error("%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
+        return FINO_ERR_LAUNCH;
+    }
+    once.done[dev].store(1, std::memory_order_release);
+    return FINO_OK;
+}
 
 static inline bool fino_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -439,16 +439,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
 
 template <typename T, int EPI, bool GENERIC, bool CONV = false>
 int launch_gemm_t(const GemmParams& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, GENERIC, CONV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        if (e != hipSuccess) {
-            fino_set_error("fino_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return FINO_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static FinoPerDeviceOnce once;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_kernel<T, EPI, GENERIC, CONV>), kSmemBytes, "fino_gemm")) return rc;
     gemm_kernel<T, EPI, GENERIC, CONV><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
@@ -456,16 +448,8 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
 
 template <typename T, int EPI>
 int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        if (e != hipSuccess) {
-            fino_set_error("fino_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return FINO_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static FinoPerDeviceOnce once;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI>), kSmemBytes, "fino_gemm")) return rc;
     gemm_pp_kernel<T, EPI><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;

@@ -212,16 +212,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_mxfp8_kernel(const Fp8Params
 
 template <typename T, int EPI, bool QOUT = false>
 int launch_mxfp8(const Fp8Params& fp, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel<T, EPI, QOUT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemF8);
-        if (e != hipSuccess) {
-            fino_set_error("fino_gemm_mxfp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return FINO_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static FinoPerDeviceOnce once;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_mxfp8_kernel<T, EPI, QOUT>), kSmemF8, "fino_gemm_mxfp8")) return rc;
     gemm_mxfp8_kernel<T, EPI, QOUT><<<dim3((unsigned)(fp.g.tiles_m * fp.g.tiles_n)), kThreads, kSmemF8, st>>>(fp);
     FINO_LAUNCH_CHECK();
     return FINO_OK;

@@ -26,9 +26,15 @@ import torch.distributed as dist
 
 
 class TokenShard:
-    def __init__(self, rank, ways, group=None):
-        self.rank, self.ways, self.group = rank, ways, group
+    def __init__(self, rank, ways, group=None, force=False):
+        # force: take the sharded code path (separate K|V / Q projections, all-gather through the communicator) even
+        # with one shard -- how a single GPU exercises the RCCL call sequence (tests/test_parallel_gpu.py)
+        self.rank, self.ways, self.group, self.force = rank, ways, group, force
         self._buf = {}
+
+    @property
+    def active(self):
+        return self.ways > 1 or self.force
 
     def rows(self, L):
         lpad = (L + self.ways - 1) // self.ways
@@ -79,10 +85,12 @@ class ParallelPlan:
         self.cfg_ways, self.token_ways = cfg_ways, token_ways
         self.cfg_idx, self.tok_rank = rank // token_ways, rank % token_ways
         self.token_group, self.cfg_group = token_group, cfg_group
-        self.shard = TokenShard(self.tok_rank, token_ways, token_group)
+        force = world == 1                    # single-rank rehearsal of the N>1 call sequence
+        self.shard = TokenShard(self.tok_rank, token_ways, token_group, force)
         # interleaved plan: a second shard object (own buffers, own communicator) for the second CFG branch
         self.interleave = token_group_b is not None
-        self.shards = (self.shard, TokenShard(self.tok_rank, token_ways, token_group_b)) if self.interleave else None
+        self.shards = (self.shard, TokenShard(self.tok_rank, token_ways, token_group_b, force)) \
+            if self.interleave else None
         self._buf = None
 
     @property
@@ -107,9 +115,11 @@ class ParallelPlan:
         return self._buf[0], self._buf[1]
 
 
-def make_plan(rank, world, cfg_parallel=True, mode="split"):
+def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False):
+    """`allow_single`: build the plan for world == 1 too (the sharded code path forced through real communicators of
+    one rank -- the rehearsal a 1-GPU box can run)."""
     if mode == "interleave":
-        if world < 2:
+        if world < 2 and not allow_single:
             raise ValueError("the interleaved plan needs at least 2 ranks")
         ga = dist.new_group(list(range(world)))      # one communicator per branch: their collectives are independent
         gb = dist.new_group(list(range(world)))
@@ -120,7 +130,7 @@ def make_plan(rank, world, cfg_parallel=True, mode="split"):
     # every rank creates every group, in the same order
     for c in range(cfg_ways):
         ranks = list(range(c * token_ways, (c + 1) * token_ways))
-        g = dist.new_group(ranks) if token_ways > 1 else None
+        g = dist.new_group(ranks) if (token_ways > 1 or allow_single) else None
         if rank in ranks:
             token_group = g
     for t in range(token_ways):
@@ -131,10 +141,10 @@ def make_plan(rank, world, cfg_parallel=True, mode="split"):
     return ParallelPlan(rank, world, cfg_ways, token_ways, token_group, cfg_group)
 
 
-def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None):
-    plan = plan or make_plan(rank, world, cfg_parallel, mode)
+def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None, allow_single=False):
+    plan = plan or make_plan(rank, world, cfg_parallel, mode, allow_single)
     pipe.parallel = plan
     pipe.parallel_desc = plan.desc
     pipe.token_shards = plan.token_ways
-    pipe.transformer.parallel = plan.shard if plan.token_ways > 1 else None
+    pipe.transformer.parallel = plan.shard if plan.shard.active else None
     return plan

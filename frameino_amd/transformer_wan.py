@@ -178,11 +178,40 @@ class WanTransformer3DModel(nn.Module):
                 keep32 = any(s in k for s in self._keep_in_fp32_modules)
                 t = sd[k].to(torch.float32 if keep32 else (dtype or sd[k].dtype))
                 p.data = t.to(p.device).contiguous()
-        self._packed = None
-        self._text_cache.clear()
+        if self.reset_caches():
+            self.enable_mxfp8_linears()
         return self
 
-    # ------------------------------------------------------------------ packed weights
+    # ------------------------------------------------------------------ derived state
+    def reset_caches(self):
+        """Drop everything derived from the parameters or the prompt: packed/fused weight copies, MXFP8 weights, text
+        K/V, RoPE tables, workspaces.  Called whenever the parameters may have changed or moved."""
+        had_fp8 = bool(self._fp8)
+        self._packed = None
+        self._fp8 = {}
+        self._text_cache.clear()
+        self._rope_cache.clear()
+        self._ws.clear()
+        return had_fp8
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .half() / .float(): parameters move or change
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_text_cache") and self.reset_caches():
+            self.enable_mxfp8_linears()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if self.reset_caches():
+            self.enable_mxfp8_linears()
+        return out
+
+    def _default_processors(self):
+        # exactly our processor (not a subclass): the fused path in forward_steps IS that processor's body; anything
+        # else the user installed (set_processor, at any time) is called through the plugin protocol instead.
+        return all(type(b.attn1.processor) is MI355WanAttnProcessor and type(b.attn2.processor) is MI355WanAttnProcessor
+                   for b in self.blocks)
+
     def _pack(self):
         """One-time repack for the fused kernels: fused QKV / KV weights, flat patch-embed weight, the 30 per-block
         scale_shift_tables stacked (fp32)."""
@@ -198,10 +227,6 @@ class WanTransformer3DModel(nn.Module):
             pk.layers.append(e)
         pk.sst = torch.stack([b.scale_shift_table.detach().float()[0] for b in self.blocks])        # [layers, 6, D]
         pk.w_patch = self.patch_embedding.weight.detach().reshape(d, -1).contiguous()
-        # exactly our processor (not a subclass): the fused path below IS that processor's body; anything else the
-        # user installed (set_processor) is called through the plugin protocol instead.
-        pk.default_procs = all(type(b.attn1.processor) is MI355WanAttnProcessor and
-                               type(b.attn2.processor) is MI355WanAttnProcessor for b in self.blocks)
         self._packed = pk
         return pk
 
@@ -228,6 +253,10 @@ class WanTransformer3DModel(nn.Module):
         """one of a block's large linears: MXFP8 when enabled (and K is a multiple of 128), else the model-dtype GEMM"""
         wq = self._fp8.get((li, key)) if self._fp8 else None
         o = self.ops
+        if wq is None and self._fp8 and key in ("kv", "q"):
+            # token shards project K|V and Q separately: quantise those row blocks of the fused weight on first use
+            # (MX scales are per output row, so this equals slicing the quantised fused weight)
+            wq = self._fp8[(li, key)] = o.quantize_mxfp8(w.detach().contiguous())
         if wq is None:
             return o.gemm(x, w, b, epi, **kw)
         xq, xs = o.quantize_mxfp8(x)
@@ -282,12 +311,10 @@ class WanTransformer3DModel(nn.Module):
 
     def _text_kv(self, encoder_hidden_states, pk):
         """text_embedder (:185) + the 30 layers' attn2 K (after norm_k) and V: step-invariant, cached per
-        cache_context name and prompt tensor identity."""
-        key = (self._ctx_name, encoder_hidden_states.data_ptr(), encoder_hidden_states._version,
-               tuple(encoder_hidden_states.shape))
+        cache_context name for as long as the caller passes the SAME prompt tensor object, unmodified."""
         hit = self._text_cache.get(self._ctx_name)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0] is encoder_hidden_states and hit[1] == encoder_hidden_states._version:
+            return hit[2]
         ce = self.condition_embedder
         d = self.inner_dim
         ctx = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1])
@@ -299,7 +326,9 @@ class WanTransformer3DModel(nn.Module):
             self.ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
             kvs.append(kv)
         val = SimpleNamespace(txt=txt, kv=kvs)
-        self._text_cache[self._ctx_name] = (key, val)
+        # the entry holds the prompt tensor itself: identity (`is`) + in-place version, never its address -- a freed
+        # prompt's address is handed to the next same-shape prompt by the caching allocator
+        self._text_cache[self._ctx_name] = (encoder_hidden_states, encoder_hidden_states._version, val)
         return val
 
     # ------------------------------------------------------------------ forward
@@ -330,6 +359,7 @@ class WanTransformer3DModel(nn.Module):
             attention_kwargs.pop("scale", None)                                    # LoRA scale (:463-476): no PEFT here
         b = hidden_states.shape[0]
         pk = self._packed or self._pack()
+        default_procs = self._default_processors()
         o = self.ops
         cfg = self.config
         _, c, nf, hh, ww = hidden_states.shape
@@ -342,7 +372,7 @@ class WanTransformer3DModel(nn.Module):
 
         # ---- token shard of this rank (frameino_amd/parallel.py); single GPU: the whole sequence ----
         sh = shard if shard is not None else self.parallel
-        sh = sh if (sh is not None and sh.ways > 1) else None
+        sh = sh if (sh is not None and sh.active) else None
         if sh is not None:
             if b != 1:
                 raise NotImplementedError("token-sharded execution runs one sample per call")
@@ -400,7 +430,7 @@ class WanTransformer3DModel(nn.Module):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
             # 1. self-attention (:334-336)
             o.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=nrm)
-            if not pk.default_procs:
+            if not default_procs:
                 if sh is not None:
                     raise NotImplementedError("token-sharded execution needs the built-in MI355WanAttnProcessor")
                 rot = _CompactRope((cos1, sin1))
@@ -416,16 +446,16 @@ class WanTransformer3DModel(nn.Module):
             else:
                 # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
-                o.gemm(nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n])
+                self._lin(li, "kv", nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n])
                 o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                 kv_all, work = sh.all_gather_kv(kv_loc)
-                o.gemm(nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
+                self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
                 o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
                 if work is not None:
                     work.wait()
                 kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
                 o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
-            if pk.default_procs:
+            if default_procs:
                 self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x, gate=m[:, 2], sel=sel, out=x)
             # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange
@@ -434,7 +464,7 @@ class WanTransformer3DModel(nn.Module):
                 o.layernorm(x, n2.weight, n2.bias, cfg.eps, out=nrm)
             else:
                 nrm.copy_(x)
-            if pk.default_procs:
+            if default_procs:
                 self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=q2)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)

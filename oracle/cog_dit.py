@@ -8,7 +8,7 @@ diffusers pieces (CogVideoXLayerNormZero, AdaLayerNorm, FeedForward, nn.LayerNor
 import torch
 import torch.nn.functional as F
 
-from .wan_dit import linear, timestep_sinusoid
+from .wan_dit import linear, sdpa, timestep_sinusoid
 
 
 def cog_rope(x, cos, sin):
@@ -30,7 +30,7 @@ def cog_attention(sd, p, heads, eps, hidden_states, encoder_hidden_states, rotar
     if rotary is not None:
         q = torch.cat([q[:, :, :lt], cog_rope(q[:, :, lt:], *rotary)], dim=2)
         k = torch.cat([k[:, :, :lt], cog_rope(k[:, :, lt:], *rotary)], dim=2)
-    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, -1, heads * dh)
+    o = sdpa(q, k, v).transpose(1, 2).reshape(b, -1, heads * dh)
     o = linear(sd, p + ".to_out.0", o)
     return o[:, lt:], o[:, :lt]
 

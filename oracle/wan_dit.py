@@ -21,7 +21,7 @@ def timestep_sinusoid(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift
     """architecture/embeddings.py:27-78 (get_timestep_embedding), as configured by
     transformer_wan.py:158 (flip_sin_to_cos=True, downscale_freq_shift=0)."""
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32)
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
     exponent = exponent / (half - downscale_freq_shift)
     emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
     emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
@@ -37,11 +37,12 @@ def rope_1d(dim, max_len, theta=10000.0):
     return ang.cos().repeat_interleave(2, dim=1).float(), ang.sin().repeat_interleave(2, dim=1).float()
 
 
-def wan_rope(head_dim, max_seq_len, ppf, pph, ppw):
-    """WanRotaryPosEmbed (:192-253): t/h/w split of the head dim, tables [1,1,L,head_dim]."""
+def wan_rope(head_dim, max_seq_len, ppf, pph, ppw, device=None):
+    """WanRotaryPosEmbed (:192-253): t/h/w split of the head dim, tables [1,1,L,head_dim] (built on the CPU in fp64
+    like the reference's registered buffers, then moved)."""
     h_dim = w_dim = 2 * (head_dim // 6)
     t_dim = head_dim - h_dim - w_dim
-    tabs = [rope_1d(d, max_seq_len) for d in (t_dim, h_dim, w_dim)]
+    tabs = [tuple(t.to(device) for t in rope_1d(d, max_seq_len)) for d in (t_dim, h_dim, w_dim)]
 
     def build(i):
         f = tabs[0][i][:ppf].view(ppf, 1, 1, -1).expand(ppf, pph, ppw, -1)
@@ -83,6 +84,23 @@ def fp32_layer_norm(x, weight, bias, eps):
 
 
 # ----------------------------------------------------------------------------- attention
+def sdpa(q, k, v):
+    """F.scaled_dot_product_attention(q, k, v) (no mask, no dropout, non-causal, scale 1/sqrt(d)).  When the oracle is
+    run on a GPU as the full-size checker (tests/test_fullsize_oracle_gpu.py) the [H, Lq, Lk] score tensor of the
+    whole call would be tens of GB, so the same arithmetic is done a few heads at a time (heads are independent)."""
+    if not q.is_cuda or q.shape[1] * q.shape[2] * k.shape[2] <= (1 << 28):
+        return F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+    step = max(1, (1 << 31) // (q.shape[2] * k.shape[2]))            # <= 8 GiB of fp32 scores per chunk
+    out = torch.empty(q.shape[:-1] + (v.shape[-1],), dtype=q.dtype, device=q.device)
+    scale = q.shape[-1] ** -0.5
+    for bi in range(q.shape[0]):
+        for h0 in range(0, q.shape[1], step):
+            s = torch.matmul(q[bi, h0:h0 + step].float(), k[bi, h0:h0 + step].float().transpose(1, 2)) * scale
+            out[bi, h0:h0 + step] = torch.matmul(torch.softmax(s, dim=-1), v[bi, h0:h0 + step].float()).to(q.dtype)
+            del s
+    return out
+
+
 def wan_attention(sd, prefix, heads, eps, hidden_states, encoder_hidden_states=None, rotary_emb=None):
     """WanAttnProcessor2_0.__call__ (:43-119) with add_k_proj=None (TI2V-5B)."""
     ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
@@ -97,7 +115,7 @@ def wan_attention(sd, prefix, heads, eps, hidden_states, encoder_hidden_states=N
     if rotary_emb is not None:
         q = apply_wan_rope(q, *rotary_emb)
         k = apply_wan_rope(k, *rotary_emb)
-    o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+    o = sdpa(q, k, v)
     o = o.transpose(1, 2).flatten(2, 3).type_as(q)
     return linear(sd, prefix + ".to_out.0", o)
 
@@ -159,7 +177,7 @@ def wan_forward(sd, cfg, hidden_states, timestep, encoder_hidden_states):
     b, c, nf, hh, ww = hidden_states.shape
     pt, ph, pw = cfg["patch_size"]
     ppf, pph, ppw = nf // pt, hh // ph, ww // pw
-    rotary = wan_rope(cfg["attention_head_dim"], cfg["rope_max_seq_len"], ppf, pph, ppw)      # :484
+    rotary = wan_rope(cfg["attention_head_dim"], cfg["rope_max_seq_len"], ppf, pph, ppw, hidden_states.device)  # :484
 
     x = F.conv3d(hidden_states, sd["patch_embedding.weight"], sd["patch_embedding.bias"], stride=(pt, ph, pw))
     x = x.flatten(2).transpose(1, 2)                                                          # :486-487

@@ -1,0 +1,70 @@
+"""Host-side pieces of the product path that need no GPU: tables and caches."""
+import torch
+
+from frameino_amd.transformer_wan import WanTransformer3DModel, wan_rope_tables
+
+
+def test_product_rope_tables_equal_reference_tables_at_the_real_geometry(golden):
+    """`wan_rope_tables` (compact [L, 64] cos / sin) vs the rows recorded from the reference's WanRotaryPosEmbed at
+    (14, 22, 40), head_dim 128 (tests/golden/wan_rope.npz): the processor reads cos[..., 0::2] and sin[..., 1::2]
+    (architecture/transformer_wan.py:82-83), which is exactly what the compact table stores.  Bit-exact."""
+    _, _, a = golden("wan_rope")
+    f, h, w, d = a["shape"].tolist()
+    cos, sin = wan_rope_tables(d, 1024, f, h, w)
+    assert cos.shape == (f * h * w, d // 2) and cos.dtype == torch.float32
+    rows = a["rows"].long()
+    assert torch.equal(cos[rows], a["cos"][:, 0::2])
+    assert torch.equal(sin[rows], a["sin"][:, 1::2])
+    # the reference's table repeats every value pairwise (repeat_interleave_real): nothing is lost by the compaction
+    assert torch.equal(a["cos"][:, 0::2], a["cos"][:, 1::2]) and torch.equal(a["sin"][:, 0::2], a["sin"][:, 1::2])
+
+
+def _tiny():
+    return WanTransformer3DModel(num_attention_heads=2, attention_head_dim=24, in_channels=8, out_channels=4, text_dim=16,
+                                 freq_dim=32, ffn_dim=64, num_layers=2, rope_max_seq_len=64)
+
+
+def test_derived_state_is_dropped_when_parameters_move_or_change():
+    """`_packed` / `_text_cache` / `_fp8` are detached copies -- `.to()`, `load_state_dict` and
+    `load_reference_state_dict` must invalidate them."""
+    m = _tiny()
+    m._pack()
+    m._text_cache["cond"] = (torch.zeros(1), 0, None)
+    assert m._packed is not None
+    m.to(torch.float64)
+    assert m._packed is None and not m._text_cache
+    m._pack()
+    m.load_state_dict(m.state_dict())
+    assert m._packed is None
+    m._pack()
+    m.load_reference_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    assert m._packed is None
+
+
+def test_swapping_a_processor_after_the_first_forward_is_seen():
+    from frameino_amd.attention_processor import MI355WanAttnProcessor
+
+    class Mine(MI355WanAttnProcessor):
+        pass
+
+    m = _tiny()
+    m._pack()
+    assert m._default_processors()
+    m.blocks[1].attn2.set_processor(Mine())
+    assert not m._default_processors()           # evaluated per call, not frozen at pack time
+
+
+def test_bench_watchdog_prints_the_measured_line_and_exits_zero_on_a_stall():
+    """bench.py (N>1): once the first plan's JSON line exists, a stalled second phase must not lose it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(0); "
+            "d.arm('probe', 0.5, fallback='{\"metric\": \"x\"}'); time.sleep(30); print('NOT REACHED')" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == '{"metric": "x"}' and "stalled" in r.stderr
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(1); "
+            "d.arm('timed run', 0.5); time.sleep(30)" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and r.stdout.strip() == ""

@@ -1,5 +1,7 @@
 """N>1 path with the REAL kernels: two processes sharing one MI355X, the collectives of frameino_amd/parallel.py carried
-by gloo through host memory (RCCL needs one GPU per rank; the driver's 8-GPU node runs that).  Checks that the
+by gloo through host memory (RCCL needs one GPU per rank; the driver's 8-GPU node runs that) -- and, separately, the
+same code forced through REAL RCCL communicators of one rank (backend "nccl", world_size 1: the call sequence, the
+async all_gather_into_tensor issued from side streams, two communicators used concurrently on two streams).  Checks that the
 token-sharded forward (Lq = L/2 queries against the gathered K|V, padded shard buffers, attention tail split at those
 shapes) and the CFG-parallel step reproduce the single-process HIP result."""
 import os
@@ -74,3 +76,49 @@ def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc):
         # same kernels on the same rows; the sharded attention splits its blocks differently (fp32 summation order)
         assert rel_rms(out, single) < 5e-3, (rank, rel_rms(out, single))
     assert torch.equal(outs[0][2], outs[1][2])                # every rank holds the same latents
+
+
+def _nccl_worker(q, port, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from frameino_amd.parallel import shard_pipeline
+        assert dist.get_backend() == "nccl"
+        pipe, a = _pipe("cuda:0")
+        pipe.batch_cfg = False
+        single = _run(pipe, a, "cuda:0").cpu()
+        plan = shard_pipeline(pipe, 0, 1, cfg_parallel=False, mode=mode, allow_single=True)
+        assert plan.shard.force and pipe.transformer.parallel is plan.shard
+        assert dist.get_backend(plan.shard.group) == "nccl"
+        out = _run(pipe, a, "cuda:0")
+        # a second pass: buffers and communicators are reused, nothing stale
+        out2 = _run(pipe, a, "cuda:0")
+        torch.cuda.synchronize()
+        q.put((plan.desc, single, out.cpu(), out2.cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,desc", [("split", "cfg1xtoken1"), ("interleave", "token1x2branches-interleaved")])
+def test_sharded_path_through_rccl_single_rank(mode, desc):
+    """backend nccl (= RCCL), world_size 1: TokenShard.all_gather_kv -> all_gather_into_tensor(async_op=True) issued
+    on the branch's stream, work.wait() before the attention launch, all_gather_out, and -- interleave -- two
+    communicators driven alternately from two HIP streams.  One GPU cannot show bandwidth; it does prove the call
+    sequence, the stream semantics and that the result is the unsharded one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(q, _free_port(), mode))
+    p.start()
+    try:
+        d, single, out, out2 = q.get(timeout=600)
+    finally:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+    assert p.exitcode == 0
+    assert d == desc
+    assert torch.isfinite(out).all() and torch.equal(out, out2)
+    # separate K|V and Q projections instead of the fused QKV GEMM: same per-element arithmetic
+    assert rel_rms(out, single) < 5e-3, rel_rms(out, single)

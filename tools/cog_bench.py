@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Second backbone at BASELINE config 5's shape, in bf16 (the fp8 path is not built): CogVideoX-5B FrameINO,
+"""Second backbone at BASELINE config 5's shape, bf16 or (--mxfp8) MXFP8 linears + bf16 attention: CogVideoX-5B FrameINO,
 49 frames 480x720 -> model input [2, 14, 48, 60, 90] (CFG-batched, one ID frame), L = 226 + 18900 joint tokens,
 42 layers, 48 heads x 64.  Random-init weights on the device, synthetic latents; one step = the B=2 forward + guidance +
 v-prediction DDIM update (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944).  GPU box only."""
@@ -21,26 +21,15 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--mxfp8", action="store_true", help="QKV / out / FFN linears on the MXFP8 path (config 5)")
     a = ap.parse_args()
-    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
     from frameino_amd.schedulers import CogVideoXDDIMScheduler
     cfg = dict(COG5B)
     if a.layers:
         cfg["num_layers"] = a.layers
     dev = torch.device("cuda")
-    with torch.device("meta"):
-        m = CogVideoXTransformer3DModel(**cfg)
-    m = m.to_empty(device=dev)
-    g = torch.Generator(device=dev).manual_seed(0)
-    with torch.no_grad():
-        for name, p in m.named_parameters():
-            t = 0.02 * torch.randn(p.shape, generator=g, device=dev)
-            if name.endswith("norm.weight") or "norm_q.weight" in name or "norm_k.weight" in name:
-                t = 1.0 + t
-            p.data = t.bfloat16()
-        for name, b in m.named_buffers():
-            b.data = (0.02 * torch.randn(b.shape, generator=g, device=dev)).to(b.dtype)
-    m = m.eval()
+    from frameino_amd.random_init import random_cog_model
+    m = random_cog_model(cfg, dev)
+    g = torch.Generator(device=dev).manual_seed(1)
     if a.mxfp8:
         m.enable_mxfp8_linears()
     pipe = CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())
