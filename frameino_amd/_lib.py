@@ -17,6 +17,8 @@ c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
 SIGNATURES = {
     "fino_version": [],
     "fino_last_error": [],
+    "fino_tune_set": [c_int, c_int],
+    "fino_tune_get": [c_int],
     "fino_adaln_modulate": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_void_p,
                             c_float, c_int, c_void_p],
     "fino_layernorm": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_void_p, c_void_p, c_float, c_int, c_void_p],

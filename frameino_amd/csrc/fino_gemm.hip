@@ -553,6 +553,7 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
     p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
+    p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
     hipStream_t st = (hipStream_t)stream;
     const bool generic = (k % BK) != 0;
     if (dtype == FINO_BF16)
@@ -583,6 +584,7 @@ extern "C" int fino_conv3d(const void* x, const void* w, const void* bias, void*
     p.m = (int64_t)t_out * h_out * w_out; p.n = c_out_pad; p.k = (int64_t)kt * kh * kw * c_in_pad;
     p.lda = c_in_pad; p.ldw = p.k; p.ldc = c_out_pad; p.ldr = c_out_pad; p.mod_stride = 0;
     p.tiles_m = (int)((p.m + BM - 1) / BM); p.tiles_n = (int)((p.n + BN - 1) / BN);
+    p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
     p.to = t_out; p.ho = h_out; p.wo = w_out; p.ti = t_in; p.hi = h_in; p.wi = w_in;
     p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.sh = sh; p.sw = sw; p.pt = pt; p.ph = ph; p.pw = pw;
     p.up = upsample2x; p.cin_chunks = c_in_pad / BK; p.zero_page = (const uint16_t*)zero_page;

@@ -21,6 +21,7 @@ struct GemmParams {
     const int32_t* sel;
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
+    int group_m;                     // tile rows per raster group (tile_coords); 0 = default
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents
@@ -82,7 +83,7 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
     const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-    constexpr int GROUP_M = 4;
+    const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
     const int group = id / (GROUP_M * p.tiles_n);
     const int first_m = group * GROUP_M;
     const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;

@@ -267,6 +267,7 @@ static int mxfp8_fill(Fp8Params& fp, const void* aq, const void* a_scales, const
     p.m = m; p.n = n; p.k = k; p.lda = k; p.ldw = k;
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
+    p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
     fp.sa = (const uint8_t*)a_scales; fp.sw = (const uint8_t*)w_scales;
     fp.m_pad = (m + 255) / 256 * 256; fp.n_pad = (n + 255) / 256 * 256;
     return FINO_OK;
@@ -323,6 +324,7 @@ extern "C" int fino_gemm_mxfp8(const void* aq, const void* a_scales, const void*
     p.m = m; p.n = n; p.k = k; p.lda = k; p.ldw = k; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
+    p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
     fp.sa = (const uint8_t*)a_scales; fp.sw = (const uint8_t*)w_scales;
     fp.m_pad = (m + 255) / 256 * 256; fp.n_pad = (n + 255) / 256 * 256;
     hipStream_t st = (hipStream_t)stream;

@@ -34,6 +34,13 @@ enum {
 int fino_version(void);
 const char* fino_last_error(void);
 
+/* Tuning knobs for A/B timing of kernel variants inside one process (tools/): results never depend on them.
+ * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
+ * order.  FINO_TUNE_GEMM_RASTER: 0 = XCD-contiguous row groups, 1 = chip-wide super-windows. */
+enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_COUNT = 8 };
+int fino_tune_set(int key, int value);
+int fino_tune_get(int key);
+
 /* ---- normalisation + modulation (HBM-bound, one wave per token row) ------------------------------------
  * y = T( LN_fp32(x) * (1 + scale[r]) + shift[r] ),  LN without affine, statistics in fp32.
  * scale/shift are fp32 rows of a small modulation table: element (row, c) is  p[sel ? sel[row]*mod_stride : 0][c].
