@@ -554,6 +554,7 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
     p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
+    if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
     hipStream_t st = (hipStream_t)stream;
     const bool generic = (k % BK) != 0;
     if (dtype == FINO_BF16)

@@ -73,6 +73,18 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Raster group height of the plain GEMM (tile_coords), from the measured A/B of profiles/r02_gemm_raster.md: an XCD's 32
+// concurrent tiles form a G-row x 32/G-column window.  L2-fill traffic is lowest at G = 4 / 8 (12 operand panels per 32
+// tiles) but costs little (2.5x the traffic = +8 % time), and what wins per shape is the panel LENGTH: long-K GEMMs
+// prefer G = 1 (a window is whole output rows: one A panel and every W panel stream once), wide-N ones G = 2, and
+// N = 3072 (12 tile columns) G = 16.
+inline int gemm_default_group_m(int tiles_n, int64_t k) {
+    if (k >= 8192) return 1;
+    if (tiles_n >= 48) return 2;
+    if (tiles_n <= 12) return 16;
+    return 4;
+}
+
 // swizzle of the 16-byte chunk index inside a 128-byte tile row
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
