@@ -293,7 +293,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 // LDS: two 64-KiB stages.  Stage (t+1)%2 held tile t-1: its A half of a group is dead after that group's LOAD(t-1),
 // its W after G1's LOAD(t-1) (phase 2t-1), so every DMA above starts in a free region and has >= one whole phase to land.
 // (Moving 2 or 4 of G0's eight W pieces per wave into G1's COMPUTE phase was measured: no difference.)
-template <typename T, int EPI>
+//
+// CONV = implicit-GEMM convolution on the same loop (Wan VAE, fino_conv3d): row m of A is output position (t, h, w) of a
+// channels-last activation, K runs tap-major / channel-minor.  Per lane the gather address of a piece changes only when
+// the K-tile crosses into the next tap (every cin_chunks tiles): the 4 offsets are recomputed there (a dozen VALU ops
+// each, amortised over >= 4 K-tiles in every Wan conv), the channel advance inside a tap rides in the scalar offset, and
+// taps that fall into the padding get an offset beyond the buffer resource's num_records, for which the hardware
+// writes zeros into LDS (no zero page, no branch).  The resource is re-based per workgroup to the first input frame
+// its rows can touch, so the offsets fit 32 bits on tensors of any size (fino_conv3d checks the per-tile span).
+template <typename T, int EPI, bool CONV = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename T::vec8 vec8;
@@ -312,20 +320,77 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     // loop carries 12 address registers and no per-piece vector arithmetic (launch checks the operands span < 4 GiB).
     const int r8 = lane >> 3;
     const int sk = ((lane & 7) ^ ((4 * (wn & 1) + (lane >> 4)) & 7)) * 8;   // = (phys chunk ^ swz(row)) * 8 elements
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.a, 0, (int)(((p.m - 1) * p.lda + p.k) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.w, 0, (int)(((p.n - 1) * p.ldw + p.k) * 2), 0x00020000);
     // A piece q (0..3) of my group: tile rows wm*128 + q*32 + wn*8 + r8;  W piece q (0..7): rows q*32 + wn*8 + r8
     uint32_t a_off[4], w_off[8];
+    // CONV state: packed output position of my 4 A rows; the tap (dt, dh, dw) and channel chunk of the NEXT tile to stage
+    uint32_t pos[CONV ? 4 : 1];
+    int ck = 0, tap_t = 0, tap_h = 0, tap_w = 0, t_first = 0, t_in_first = 0;
+    const uint16_t* a_base_ptr = p.a;
+    int64_t a_bytes = ((p.m - 1) * p.lda + p.k) * 2;
+    if constexpr (CONV) {
+        const int hw = p.ho * p.wo;
+        t_first = (int)(m0 / hw);
+        t_in_first = t_first * p.st - p.pt;
+        t_in_first = t_in_first < 0 ? 0 : t_in_first;
+        const int64_t frame = (int64_t)p.hi * p.wi * p.lda;
+        a_base_ptr = p.a + (int64_t)t_in_first * frame;
+        a_bytes = (int64_t)(p.ti - t_in_first) * frame * 2;
+        a_bytes = a_bytes > 0x7fffffffll ? 0x7fffffffll : a_bytes;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int64_t gm = m0 + wm * 128 + q * 32 + wn * 8 + r8;
-        gm = gm < p.m ? gm : p.m - 1;
-        a_off[q] = (uint32_t)((gm * p.lda + sk) * 2);
+        for (int q = 0; q < 4; ++q) {
+            int64_t gm = m0 + wm * 128 + q * 32 + wn * 8 + r8;
+            gm = gm < p.m ? gm : p.m - 1;
+            const int t = (int)(gm / hw);
+            const int rem = (int)(gm - (int64_t)t * hw);
+            const int h = rem / p.wo;
+            pos[q] = ((uint32_t)(t - t_first) << 24) | ((uint32_t)h << 12) | (uint32_t)(rem - h * p.wo);
+        }
     }
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base_ptr, 0, (int)a_bytes, 0x00020000);
+    // offsets of my A pieces for the tap (tap_t, tap_h, tap_w); padding taps -> beyond num_records -> zeros
+    auto conv_offsets = [&]() {
+        const int hlim = p.up ? 2 * p.hi : p.hi, wlim = p.up ? 2 * p.wi : p.wi;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4; ++q) {
+            const int ti = (t_first + (int)(pos[q] >> 24)) * p.st + tap_t - p.pt;
+            int hi = (int)((pos[q] >> 12) & 0xfffu) * p.sh + tap_h - p.ph;
+            int wi = (int)(pos[q] & 0xfffu) * p.sw + tap_w - p.pw;
+            const bool ok = (unsigned)ti < (unsigned)p.ti && (unsigned)hi < (unsigned)hlim && (unsigned)wi < (unsigned)wlim;
+            if (p.up) { hi >>= 1; wi >>= 1; }
+            const uint32_t off = (uint32_t)(((((ti - t_in_first) * p.hi + hi) * p.wi + wi) * (int)p.lda + sk) * 2);
+            a_off[q] = ok ? off : 0x80000000u;
+        }
+    };
+    // state -> the K-tile after the one just staged
+    auto conv_next = [&]() {
+        if (++ck == p.cin_chunks) {
+            ck = 0;
+            if (++tap_w == p.kw) {
+                tap_w = 0;
+                if (++tap_h == p.kh) { tap_h = 0; ++tap_t; }
+            }
+            conv_offsets();
+        }
+    };
+    if constexpr (CONV) {
+        conv_offsets();
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int64_t gm = m0 + wm * 128 + q * 32 + wn * 8 + r8;
+            gm = gm < p.m ? gm : p.m - 1;
+            a_off[q] = (uint32_t)((gm * p.lda + sk) * 2);
+        }
+    }
+    // W pieces: CONV keeps ONE per-lane offset (piece 0) and moves the 32-row piece stride into the scalar offset
+    // (7 registers the gather state needs); pieces wholly past N (fino_conv3d requires N % 32 == 0) are skipped --
+    // their LDS rows only feed output columns >= N, which the epilogue never stores.
+    const int w_piece_bytes = (int)(32 * p.ldw * 2);
+    const int w_pieces = CONV ? (int)((p.n - n0 + 31) / 32) : 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {   // (CONV uses w_off[0] only; the rest is dead code there)
         int64_t gn = n0 + q * 32 + wn * 8 + r8;
         gn = gn < p.n ? gn : p.n - 1;
         w_off[q] = (uint32_t)((gn * p.ldw + sk) * 2);
@@ -333,11 +398,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
 #define PP_DMA_A(STAGE_, KT_, Q_)                                                                                 \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
         a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + (wm * 128 + (Q_) * 32 + wn * 8) * 128), 16,      \
-        a_off[Q_], (KT_) * (BK * 2), 0, 0);
+        a_off[Q_], CONV ? ck * (BK * 2) : (KT_) * (BK * 2), 0, 0);
 #define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
-        w_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + kTileBytes + ((Q_) * 32 + wn * 8) * 128), 16,    \
-        w_off[Q_], (KT_) * (BK * 2), 0, 0);
+    if (!CONV || (Q_) < w_pieces)                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
+            w_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + kTileBytes + ((Q_) * 32 + wn * 8) * 128), 16, \
+            w_off[CONV ? 0 : (Q_)], (KT_) * (BK * 2) + (CONV ? (Q_) * w_piece_bytes : 0), 0, 0);
 
     const int frow = lane & 15;
     const int pch0 = (lane >> 4) ^ (frow >> 1);
@@ -355,14 +421,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         PP_DMA_A(0, 0, q)
-        if (wm == 0) PP_DMA_W(0, 0, q) else PP_DMA_W(0, 0, 4 + q)
+        if (wm == 0) { PP_DMA_W(0, 0, q) } else { PP_DMA_W(0, 0, 4 + q) }
     }
+    if constexpr (CONV) conv_next();
     if (nk > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             PP_DMA_A(1, 1, q)
-            if (wm == 0) PP_DMA_W(1, 1, q) else PP_DMA_W(1, 1, 4 + q)
+            if (wm == 0) { PP_DMA_W(1, 1, q) } else { PP_DMA_W(1, 1, 4 + q) }
         }
+        if constexpr (CONV) conv_next();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -393,8 +461,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
             for (int q = 0; q < 4; ++q) PP_DMA_A(cur ^ 1, t + 1, q)
             if (wm == 0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) PP_DMA_W(cur ^ 1, t + 1, q)
+                for (int q = 0; q < 8; ++q) { PP_DMA_W(cur ^ 1, t + 1, q) }
             }
+            if constexpr (CONV) conv_next();
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -446,11 +515,11 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool CONV = false>
 int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     static FinoPerDeviceOnce once;
-    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI>), kSmemBytes, "fino_gemm")) return rc;
-    gemm_pp_kernel<T, EPI><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV>), kSmemBytes, "fino_gemm")) return rc;
+    gemm_pp_kernel<T, EPI, CONV><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -590,6 +659,20 @@ extern "C" int fino_conv3d(const void* x, const void* w, const void* bias, void*
     p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.sh = sh; p.sw = sw; p.pt = pt; p.ph = ph; p.pw = pw;
     p.up = upsample2x; p.cin_chunks = c_in_pad / BK; p.zero_page = (const uint16_t*)zero_page;
     hipStream_t s = (hipStream_t)stream;
+    // ping-pong loop with per-tap gather offsets: 32-bit offsets relative to the first input frame a tile can touch,
+    // output positions packed 8/12/12 bits
+    const int64_t hw_out = (int64_t)h_out * w_out;
+    const int64_t t_span = (BM - 1 + hw_out - 1) / hw_out + 1;                      // output frames a 256-row tile can straddle
+    const int64_t in_span_bytes = (t_span * st + kt) * (int64_t)h_in * w_in * c_in_pad * 2;
+    const bool pp = use_pingpong() && fino_tune_get(FINO_TUNE_CONV_LOOP) != 1 && in_span_bytes < (1ll << 31) &&
+                    h_out < 4096 && w_out < 4096 && t_span < 256 && c_out_pad % 32 == 0 && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
+    if (pp) {
+        if (dtype == FINO_BF16)
+            return epilogue == FINO_EPI_NONE ? launch_gemm_pp<BF16, FINO_EPI_NONE, true>(p, s)
+                                             : launch_gemm_pp<BF16, FINO_EPI_RESIDUAL, true>(p, s);
+        return epilogue == FINO_EPI_NONE ? launch_gemm_pp<F16, FINO_EPI_NONE, true>(p, s)
+                                         : launch_gemm_pp<F16, FINO_EPI_RESIDUAL, true>(p, s);
+    }
     if (dtype == FINO_BF16)
         return epilogue == FINO_EPI_NONE ? launch_gemm_t<BF16, FINO_EPI_NONE, false, true>(p, s)
                                          : launch_gemm_t<BF16, FINO_EPI_RESIDUAL, false, true>(p, s);

@@ -36,8 +36,9 @@ const char* fino_last_error(void);
 
 /* Tuning knobs for A/B timing of kernel variants inside one process (tools/): results never depend on them.
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
- * order.  FINO_TUNE_GEMM_RASTER: 0 = XCD-contiguous row groups, 1 = chip-wide super-windows. */
-enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_COUNT = 8 };
+ * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
+ * ping-pong one. */
+enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);
 int fino_tune_get(int key);
 
