@@ -42,6 +42,8 @@ SIGNATURES = {
     "fino_gemm_mxfp8_q": [c_void_p] * 7 + [c_i64] * 3 + [c_int, c_int, c_void_p],
     "fino_traj_paint": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fino_traj_blur_quantize": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "fino_resize_area_pad_u8": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
+    "fino_u8_hwc_to_chw_unit": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_skinny_linear": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
     "fino_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
@@ -50,6 +52,7 @@ SIGNATURES = {
     "fino_cfg_euler_step": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_int, c_int, c_void_p],
     "fino_cfg_unipc_step": [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_int, c_void_p],
     "fino_cfg_vpred_step": [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_void_p],
+    "fino_cfg_dpm_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_void_p],
     "fino_conv3d": [c_void_p] * 4 + [c_int] * 19 + [c_void_p, c_void_p, c_int, c_void_p],
     "fino_rmsnorm_silu_cl": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "fino_softmax_rows": [c_void_p, c_i64, c_int, c_i64, c_float, c_int, c_void_p],

@@ -74,7 +74,82 @@ __global__ __launch_bounds__(256) void blur_pass_kernel(const float* __restrict_
     }
 }
 
+// Pixel-area resampling (cv2.INTER_AREA's area relation) of an HWC uint8 image into the rectangle
+// [off_y, off_y+rh) x [off_x, off_x+rw) of an HWC uint8 canvas; everything outside the rectangle is `fill`.
+// app.py:303 (first frame -> resized_height x resized_width), :322-326 (pasted into the black inference canvas),
+// :662-681 (ID reference: scaled, centred, zero-padded to the canvas).  Destination pixel (y, x) of the rectangle covers
+// the source interval [y*sy, (y+1)*sy) x [x*sx, (x+1)*sx) (sy = src_h / rh, sx = src_w / rw); the value is the
+// overlap-weighted mean of the source pixels, accumulated in fp32 and rounded half-to-even (cv::saturate_cast).
+__global__ __launch_bounds__(256) void resize_area_pad_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                 int src_h, int src_w, int rh, int rw, int out_h,
+                                                                 int out_w, int off_y, int off_x, int fill) {
+    const int64_t total = (int64_t)out_h * out_w;
+    const float sy = (float)src_h / (float)rh, sx = (float)src_w / (float)rw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % out_w) - off_x, y = (int)(i / out_w) - off_y;
+        uint8_t* o = dst + i * 3;
+        if (x < 0 || x >= rw || y < 0 || y >= rh) {
+            o[0] = o[1] = o[2] = (uint8_t)fill;
+            continue;
+        }
+        const float fy0 = y * sy, fy1 = fminf((y + 1) * sy, (float)src_h);
+        const float fx0 = x * sx, fx1 = fminf((x + 1) * sx, (float)src_w);
+        const int y0 = (int)floorf(fy0), y1 = min(src_h, (int)ceilf(fy1));
+        const int x0 = (int)floorf(fx0), x1 = min(src_w, (int)ceilf(fx1));
+        float acc[3] = {0.f, 0.f, 0.f}, area = 0.f;
+        for (int yy = y0; yy < y1; ++yy) {
+            const float wy = fminf(fy1, (float)(yy + 1)) - fmaxf(fy0, (float)yy);
+            if (wy <= 0.f) continue;
+            for (int xx = x0; xx < x1; ++xx) {
+                const float wx = fminf(fx1, (float)(xx + 1)) - fmaxf(fx0, (float)xx);
+                if (wx <= 0.f) continue;
+                const uint8_t* p = src + ((int64_t)yy * src_w + xx) * 3;
+                const float w = wy * wx;
+                acc[0] += w * p[0]; acc[1] += w * p[1]; acc[2] += w * p[2];
+                area += w;
+            }
+        }
+        const float inv = area > 0.f ? 1.0f / area : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int q = __float2int_rn(acc[c] * inv);
+            o[c] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+    }
+}
+
+// HWC uint8 -> CHW fp32 in [-1, 1] (app.py:109-113 train_transforms + :692 permute; also the pipeline's image input)
+__global__ __launch_bounds__(256) void u8_hwc_to_chw_unit_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                                 int h, int w) {
+    const int64_t plane = (int64_t)h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c * plane + i] = (float)src[i * 3 + c] / 255.0f * 2.0f - 1.0f;
+    }
+}
+
 }  // namespace
+
+extern "C" int fino_resize_area_pad_u8(const void* src, void* dst, int src_h, int src_w, int region_h, int region_w,
+                                       int out_h, int out_w, int off_y, int off_x, int fill, void* stream) {
+    FINO_CHECK(src && dst, FINO_ERR_ARG, "fino_resize_area_pad_u8: null pointer");
+    FINO_CHECK(src_h > 0 && src_w > 0 && region_h > 0 && region_w > 0 && out_h > 0 && out_w > 0 && off_y >= 0 &&
+                   off_x >= 0 && off_y + region_h <= out_h && off_x + region_w <= out_w && fill >= 0 && fill <= 255,
+               FINO_ERR_ARG, "fino_resize_area_pad_u8: the resized region must lie inside the canvas");
+    const int64_t total = (int64_t)out_h * out_w;
+    resize_area_pad_u8_kernel<<<grid_1d(total), 256, 0, (hipStream_t)stream>>>(
+        (const uint8_t*)src, (uint8_t*)dst, src_h, src_w, region_h, region_w, out_h, out_w, off_y, off_x, fill);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_u8_hwc_to_chw_unit(const void* src, float* dst, int height, int width, void* stream) {
+    FINO_CHECK(src && dst && height > 0 && width > 0, FINO_ERR_ARG, "fino_u8_hwc_to_chw_unit: bad arguments");
+    u8_hwc_to_chw_unit_kernel<<<grid_1d((int64_t)height * width), 256, 0, (hipStream_t)stream>>>(
+        (const uint8_t*)src, dst, height, width);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
 
 extern "C" int fino_traj_paint(const int32_t* points, const int32_t* frame_offsets, float* canvas, int frames, int height,
                                int width, int radius, void* stream) {

@@ -383,6 +383,39 @@ __global__ __launch_bounds__(256) void cfg_vpred_step_kernel(const uint16_t* __r
     }
 }
 
+// CogVideoXDPMScheduler.step (diffusers, third-party; the sampler the CogVideoX-5B-I2V repo ships and the reference's
+// training-time validation builds, train_code/train_cogvideox_motion_FrameINO.py:692; pipeline call site :915-926):
+// SDE-DPM-Solver++ (2M) on v-prediction, fused with CFG.  Linear in {x, v, x0_old, noise}; the host folds the step's
+// scalars into coef = {sa, sb, m1, m2, m3, m4, mn, g, use_old}:
+//   v  = u + g*(c-u) (fp32: the pipeline takes noise_pred.float(), :897);  x0 = T(sa*x) - sb*v            (fp32)
+//   d  = use_old ? m3*x0 - m4*x0_old : x0;   x' = T( T(m1*x) - m2*d + T(mn*noise) );   x0_old <- x0
+// (products of the T-typed latent / noise with the scheduler's 0-dim coefficients stay in T under torch promotion.)
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_dpm_step_kernel(const uint16_t* __restrict__ pred, uint16_t* __restrict__ lat,
+                                                           float* __restrict__ x0_old, const uint16_t* __restrict__ noise,
+                                                           int64_t n_lat, int64_t batch_stride,
+                                                           const float* __restrict__ coef, int has_uncond) {
+    const float sa = coef[0], sb = coef[1], m1 = coef[2], m2 = coef[3], m3 = coef[4], m4 = coef[5], mn = coef[6];
+    const float g = coef[7];
+    const bool use_old = coef[8] != 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lat; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (has_uncond) {
+            const float u = T::to_f32(pred[i]);
+            const float c = T::to_f32(pred[batch_stride + i]);
+            v = u + g * (c - u);
+        } else {
+            v = T::to_f32(pred[i]);
+        }
+        const float x = T::to_f32(lat[i]);
+        const float x0 = round_to<T>(sa * x) - sb * v;
+        const float d = use_old ? m3 * x0 - m4 * x0_old[i] : x0;
+        const float nz = round_to<T>(mn * T::to_f32(noise[i]));
+        lat[i] = T::from_f32(round_to<T>(m1 * x) - m2 * d + nz);
+        x0_old[i] = x0;
+    }
+}
+
 // UniPC (bh2, predict-x0, flow sigmas) multistep update fused with CFG, one pass over the latents
 // (diffusers UniPCMultistepScheduler.step as Wan2.2-TI2V-5B-Diffusers configures it; pipeline :882-891).
 // Every tensor op of the published algorithm is linear in {x, last_sample, m0, m1, v}; the host folds the step's
@@ -654,6 +687,24 @@ extern "C" int fino_cfg_vpred_step(const void* pred, void* lat, int64_t n_lat, i
     else
         cfg_vpred_step_kernel<F16><<<grid_1d(n_lat), 256, 0, st>>>((const uint16_t*)pred, (uint16_t*)lat, n_lat,
                                                                   batch_stride, coef_dev, has_uncond);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_cfg_dpm_step(const void* pred, void* lat, float* x0_old, const void* noise, int64_t n_lat,
+                                 int64_t batch_stride, const float* coef_dev, int has_uncond, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_cfg_dpm_step: dtype %d", dtype);
+    FINO_CHECK(pred && lat && x0_old && noise && coef_dev && n_lat > 0 && (!has_uncond || batch_stride >= n_lat),
+               FINO_ERR_ARG, "fino_cfg_dpm_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        cfg_dpm_step_kernel<BF16><<<grid_1d(n_lat), 256, 0, st>>>((const uint16_t*)pred, (uint16_t*)lat, x0_old,
+                                                                 (const uint16_t*)noise, n_lat, batch_stride, coef_dev,
+                                                                 has_uncond);
+    else
+        cfg_dpm_step_kernel<F16><<<grid_1d(n_lat), 256, 0, st>>>((const uint16_t*)pred, (uint16_t*)lat, x0_old,
+                                                                (const uint16_t*)noise, n_lat, batch_stride, coef_dev,
+                                                                has_uncond);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

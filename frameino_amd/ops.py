@@ -361,6 +361,17 @@ def cfg_vpred_step_(lat, pred, coef_dev, has_uncond=True):
     return lat
 
 
+def cfg_dpm_step_(lat, pred, x0_old, noise, coef_dev, has_uncond=True):
+    """CogVideoXDPMScheduler step + CFG: lat [Fg, C, H, W] of T in place, pred [2|1, Ft, C, H, W] of T, x0_old fp32 like
+    lat (in/out), noise of T like lat, coef_dev fp32[9] = {sa, sb, m1, m2, m3, m4, mn, g, use_old}."""
+    assert lat.is_contiguous() and pred.is_contiguous() and noise.is_contiguous() and x0_old.is_contiguous()
+    assert coef_dev.dtype == torch.float32 and coef_dev.numel() >= 9 and lat.dtype == pred.dtype == noise.dtype
+    assert x0_old.dtype == torch.float32 and x0_old.numel() == lat.numel() == noise.numel()
+    _lib.check(_lib.lib().fino_cfg_dpm_step(_p(pred), _p(lat), _p(x0_old), _p(noise), lat.numel(), pred[0].numel(),
+                                           _p(coef_dev), int(has_uncond), _dt(lat), _stream()), "fino_cfg_dpm_step")
+    return lat
+
+
 # ------------------------------------------------------------------------------------------------ Wan VAE (channels-last)
 _ZERO_PAGE = {}
 

@@ -101,7 +101,7 @@ class CogVideoXImageToVideoPipeline:
     @torch.no_grad()
     def denoise(self, latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_prompt_embeds,
                 guidance_scale=6.0, num_inference_steps=50, use_dynamic_cfg=False, image_rotary_emb=None,
-                attention_kwargs=None, callback_on_step_end=None):
+                attention_kwargs=None, callback_on_step_end=None, generator=None):
         """reference :848-944.  latents / image_latents / traj_latents [1, F, C, h, w], id_latent [1, 1, C, h, w] or
         None; returns the final latents [1, F, C, h, w] in the transformer dtype."""
         tr = self.transformer
@@ -129,7 +129,11 @@ class CogVideoXImageToVideoPipeline:
         n = num_inference_steps
         gs = [1 + guidance_scale * ((1 - math.cos(math.pi * ((n - int(t)) / n) ** 5.0)) / 2) if use_dynamic_cfg
               else guidance_scale for t in ts.tolist()]
-        coefs = torch.cat([self.scheduler.coefs.to(dev), torch.tensor(gs, dtype=torch.float32, device=dev)[:, None]], 1)
+        gcol = torch.tensor(gs, dtype=torch.float32, device=dev)[:, None]
+        dpm = getattr(self.scheduler, "kind", "ddim") == "dpm"          # CogVideoXDPMScheduler branch (:915-926)
+        sc = self.scheduler.coefs.to(dev)
+        coefs = torch.cat([sc[:, :7], gcol, sc[:, 7:8]], 1) if dpm else torch.cat([sc, gcol], 1)
+        x0_old = torch.zeros(lat.shape, dtype=torch.float32, device=dev) if dpm else None
         for i, t in enumerate(ts):
             if self._interrupt:
                 continue
@@ -139,7 +143,11 @@ class CogVideoXImageToVideoPipeline:
             x = torch.cat([x, cond], dim=2).contiguous()                                       # :880
             pred = tr(hidden_states=x, encoder_hidden_states=prompt, timestep=t.expand(nb),
                       image_rotary_emb=image_rotary_emb, attention_kwargs=attention_kwargs, return_dict=False)[0]
-            ops.cfg_vpred_step_(lat, pred.contiguous(), coefs[i], has_uncond=cfg_on)            # :896-927
+            if dpm:
+                nz = self.scheduler.noise(i, lat.shape, generator, dev, dt)
+                ops.cfg_dpm_step_(lat, pred.contiguous(), x0_old, nz, coefs[i], has_uncond=cfg_on)
+            else:
+                ops.cfg_vpred_step_(lat, pred.contiguous(), coefs[i], has_uncond=cfg_on)        # :896-927
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": lat[None]})
                 if "latents" in out and out["latents"] is not None:
@@ -235,7 +243,8 @@ class CogVideoXImageToVideoPipeline:
             id_latent = idl.squeeze(2).contiguous().float().unsqueeze(1).to(dt)                    # [1, 1, C, h, w]
         gscale = guidance_scale if negative_prompt_embeds is not None else 1.0
         out = self.denoise(latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_prompt_embeds,
-                           gscale, num_inference_steps, use_dynamic_cfg, None, attention_kwargs, callback_on_step_end)
+                           gscale, num_inference_steps, use_dynamic_cfg, None, attention_kwargs, callback_on_step_end,
+                           generator if isinstance(generator, torch.Generator) else None)
         if output_type == "latent":
             video = out
         else:

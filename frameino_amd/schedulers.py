@@ -107,6 +107,59 @@ class CogVideoXDDIMScheduler:
         self.coefs = torch.tensor(rows, dtype=torch.float32, device=device)
 
 
+class CogVideoXDPMScheduler(CogVideoXDDIMScheduler):
+    """diffusers' CogVideoXDPMScheduler (third-party, restated from the published SDE-DPM-Solver++(2M) form it
+    implements -- parity unpinned): the class zai-org/CogVideoX-5b-I2V ships and the reference's validation
+    instantiates (train_code/train_cogvideox_motion_FrameINO.py:692); the pipeline dispatches on it at
+    pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:915-926 (extra arguments: the previous x0 prediction and the
+    previous timestep).  Same alpha-bar table and trailing spacing as the DDIM class.
+
+    Every step draws fresh noise: once on a first-order step (the first step, and the last where prev_timestep < 0),
+    TWICE on a second-order step (diffusers computes the first-order `prev_sample` before it knows it will discard
+    it) -- `noise(shape, ...)` below reproduces that stream for a given generator.  The update is linear, so
+    `set_timesteps` folds each step's scalars (float64, as diffusers' 0-dim tensors) into a row of `coefs`:
+    {sa, sb, m1, m2, m3, m4, mn, use_old} and the kernel is fino_cfg_dpm_step."""
+    kind = "dpm"
+
+    def set_timesteps(self, num_inference_steps, device=None, **unused):
+        super().set_timesteps(num_inference_steps, device)
+        n = self.config.num_train_timesteps
+        ts = self.timesteps.tolist()
+        rows = []
+        for i, t in enumerate(ts):
+            prev = t - n // num_inference_steps
+            a_t = self.alphas_cumprod[t]
+            a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+            a_b = self.alphas_cumprod[ts[i - 1]] if i > 0 else None
+            lamb = ((a_t / (1 - a_t)) ** 0.5).log()
+            lamb_next = ((a_p / (1 - a_p)) ** 0.5).log()
+            h = lamb_next - lamb
+            m1 = ((1 - a_p) / (1 - a_t)) ** 0.5 * (-h).exp()
+            m2 = (-2 * h).expm1() * a_p ** 0.5
+            mn = (1 - a_p) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+            use_old = a_b is not None and prev >= 0
+            m3 = m4 = 0.0
+            if use_old:
+                r = (lamb - ((a_b / (1 - a_b)) ** 0.5).log()) / h
+                m3, m4 = float(1 + 1 / (2 * r)), float(1 / (2 * r))
+            rows.append([float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(m1), float(m2), m3, m4, float(mn),
+                         1.0 if use_old else 0.0])
+        self.coefs = torch.tensor(rows, dtype=torch.float32, device=device)
+
+    def draws(self, i):
+        """number of standard-normal tensors diffusers' step consumes at step i"""
+        return 2 if self.coefs[i, 7].item() != 0 else 1
+
+    def noise(self, i, shape, generator, device, dtype):
+        """the draw step i uses (the LAST of its `draws(i)` draws), sampled like diffusers' randn_tensor: on the
+        generator's device, then moved"""
+        gdev = generator.device if generator is not None else device
+        out = None
+        for _ in range(self.draws(i)):
+            out = torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
+        return out.to(device)
+
+
 class UniPCMultistepScheduler:
     """diffusers' UniPCMultistepScheduler as Wan-AI/Wan2.2-TI2V-5B-Diffusers configures it (third-party, restated from
     the published algorithm -- parity unpinned): prediction_type="flow_prediction", use_flow_sigmas, flow_shift,

@@ -176,6 +176,16 @@ int fino_cfg_unipc_step(const void* cond_pred, const void* uncond_pred, float* x
 int fino_cfg_vpred_step(const void* pred, void* lat, int64_t n_lat, int64_t batch_stride, const float* coef_dev,
                         int has_uncond, int dtype, void* stream);
 
+/* CogVideoX SDE-DPM-Solver++ step (diffusers CogVideoXDPMScheduler, third-party; call site
+ * pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:915-926; the scheduler the reference's validation builds,
+ * train_code/train_cogvideox_motion_FrameINO.py:692), fused with CFG:
+ *   v = u + g*(c-u) (fp32);  x0 = T(sa*x) - sb*v;  d = use_old ? m3*x0 - m4*x0_old : x0;
+ *   x' = T(T(m1*x) - m2*d + T(mn*noise));  x0_old <- x0.
+ * coef_dev = {sa, sb, m1, m2, m3, m4, mn, g, use_old} (device).  pred / lat as fino_cfg_vpred_step; x0_old fp32 [n_lat]
+ * (in/out), noise [n_lat] of T: the step's standard-normal draw (the caller owns the RNG stream). */
+int fino_cfg_dpm_step(const void* pred, void* lat, float* x0_old, const void* noise, int64_t n_lat, int64_t batch_stride,
+                      const float* coef_dev, int has_uncond, int dtype, void* stream);
+
 /* ---- Wan 3D causal VAE (architecture/autoencoder_kl_wan.py) ------------------------------------------------------
  * Activations are channels-last [T, H, W, Cpad] of `dtype`, Cpad = channels zero-padded to a multiple of 64.
  * fino_conv3d: implicit-GEMM convolution (MFMA-bound) -- WanCausalConv3d (:134-176), the Conv2d of WanResample
@@ -242,6 +252,17 @@ int fino_traj_paint(const int32_t* points, const int32_t* frame_offsets, float* 
                     int radius, void* stream);
 int fino_traj_blur_quantize(const float* canvas, float* scratch, float* out, const float* taps_dev, int taps, int planes,
                             int height, int width, void* stream);
+
+
+/* Canvas / identity-reference builders of app.py (:270-350 build_canvas, :634-695 ID padding), on the device.
+ * fino_resize_area_pad_u8: pixel-area resampling (cv2.INTER_AREA's area relation; OpenCV is third-party and absent
+ *   offline: parity unpinned) of src uint8 [src_h, src_w, 3] to region_h x region_w, written at (off_y, off_x) of dst
+ *   uint8 [out_h, out_w, 3]; the rest of dst = fill.  build_canvas: region = resized size, offsets = top-left pads,
+ *   fill 0 (:303, :309, :322-326); ID reference: region = scaled size, centred, fill 0 (:662-681).
+ * fino_u8_hwc_to_chw_unit: uint8 [H, W, 3] -> fp32 [3, H, W] = v / 255 * 2 - 1 (:109-113, :692). */
+int fino_resize_area_pad_u8(const void* src, void* dst, int src_h, int src_w, int region_h, int region_w, int out_h,
+                            int out_w, int off_y, int off_x, int fill, void* stream);
+int fino_u8_hwc_to_chw_unit(const void* src, float* dst, int height, int width, void* stream);
 
 #ifdef __cplusplus
 }

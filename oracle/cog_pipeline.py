@@ -22,12 +22,21 @@ def ddim_tables(num_inference_steps, num_train_timesteps=1000, beta_start=0.0008
 
 
 def cog_denoise_loop(sd, cfg, latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_embeds,
-                     rotary, guidance, steps, dynamic_cfg=False):
+                     rotary, guidance, steps, dynamic_cfg=False, dpm_generator=None, use_dpm=False):
+    """`use_dpm`: the CogVideoXDPMScheduler branch of the loop (:915-926) through oracle.schedulers.CogDPMOracle (its
+    noise comes from `dpm_generator`, a CPU generator, drawn in the latent dtype like diffusers' randn_tensor)."""
     ac, ts = ddim_tables(steps)
+    dpm = None
+    if use_dpm:
+        from .schedulers import CogDPMOracle
+        dpm = CogDPMOracle()
+        dpm.set_timesteps(steps)
+        old = None
     nlf = latents.shape[1]
     prompt = torch.cat([negative_embeds, prompt_embeds], dim=0)                    # :768
     lat = latents.clone()
-    for t in ts.tolist():
+    tl = ts.tolist()
+    for i, t in enumerate(tl):
         x = torch.cat([lat] * 2)
         img, trj = torch.cat([image_latents] * 2), torch.cat([traj_latents] * 2)
         if id_latent is not None:                                                  # stage 1 (no ID frame): skip
@@ -42,6 +51,10 @@ def cog_denoise_loop(sd, cfg, latents, image_latents, traj_latents, id_latent, p
             g = 1 + guidance * ((1 - math.cos(math.pi * ((steps - t) / steps) ** 5.0)) / 2)
         u, c = pred.chunk(2)
         v = u + g * (c - u)
+        if dpm is not None:
+            lat, old = dpm.step(v, old, t, tl[i - 1] if i > 0 else None, lat, generator=dpm_generator)
+            lat = lat.to(latents.dtype)                                            # :927
+            continue
         prev = t - 1000 // steps
         a_t = ac[t]
         a_p = ac[prev] if prev >= 0 else torch.tensor(1.0, dtype=torch.float64)

@@ -68,3 +68,46 @@ def prepare_traj_tensor(full_pred_tracks, height, width, dot_radius, kernel=None
             out += k[dy, dx] * ink[:, rows[:, dy]][:, :, cols[:, dx]]
     q = (255.0 - out).astype(np.float32).astype(np.uint8).astype(np.float32)      # :172
     return np.transpose(q / 255.0 * 2.0 - 1.0, (0, 3, 1, 2)).astype(np.float32)   # :39-42, :187
+
+
+# ------------------------------------------------------------------------------------------------ canvas / ID builders
+def resize_area(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_AREA) restated from its documented semantics ("resampling
+    using pixel area relation"): destination pixel = overlap-weighted mean of the source pixels its footprint covers,
+    float accumulate, saturate_cast<uchar> (round half to even).  OpenCV is third-party and absent offline: UNPINNED
+    (its integer-factor fast path rounds half up, and its up-scaling branch uses its own coefficient rule)."""
+    src = np.asarray(img, dtype=np.float64)
+    h, w = src.shape[:2]
+
+    def weights(n_src, n_dst):
+        s = n_src / n_dst
+        m = np.zeros((n_dst, n_src))
+        for d in range(n_dst):
+            lo, hi = d * s, min((d + 1) * s, n_src)
+            for i in range(int(np.floor(lo)), min(n_src, int(np.ceil(hi)))):
+                ov = min(hi, i + 1) - max(lo, i)
+                if ov > 0:
+                    m[d, i] = ov
+        return m / m.sum(axis=1, keepdims=True)
+
+    wy, wx = weights(h, out_h), weights(w, out_w)
+    out = np.einsum("yh,hwc,xw->yxc", wy, src, wx)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def build_inference_canvas(first_frame, resized_h, resized_w, tl_h, tl_w, br_h, br_w):
+    """app.py:270-350 (`inference_canvas`)."""
+    eh, ew = resized_h + tl_h + br_h, resized_w + tl_w + br_w
+    canvas = np.zeros((eh, ew, 3), dtype=np.uint8)
+    canvas[tl_h:eh - br_h, tl_w:ew - br_w] = resize_area(first_frame, resized_h, resized_w)
+    return canvas
+
+
+def pad_id_reference(ref, canvas_h, canvas_w):
+    """app.py:662-681 (after the SAM mask)."""
+    rh, rw = ref.shape[:2]
+    scale_h, scale_w = canvas_h / max(rh, rw), canvas_w / max(rh, rw)
+    nh, nw = int(rh * scale_h), int(rw * scale_w)
+    img = resize_area(ref, nh, nw)
+    p1, q1 = (canvas_h - nh) // 2, (canvas_w - nw) // 2
+    return np.pad(img, ((p1, canvas_h - nh - p1), (q1, canvas_w - nw - q1), (0, 0)), mode="constant", constant_values=0)

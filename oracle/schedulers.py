@@ -133,3 +133,60 @@ class UniPCOracle:
             self.lower_order_nums += 1
         self.step_index += 1
         return prev
+
+
+class CogDPMOracle:
+    """Tensor-op by tensor-op restatement of diffusers' CogVideoXDPMScheduler (scaled-linear betas, SNR shift, zero
+    terminal SNR, trailing spacing, v-prediction): get_variables / get_mult / step as published.  Third-party, from the
+    published algorithm: UNPINNED.  Call site: pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:915-926."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.0120, snr_shift_scale=1.0):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0)
+        ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+        s = ac.sqrt()
+        a0, at = s[0].clone(), s[-1].clone()
+        self.alphas_cumprod = ((s - at) * (a0 / (a0 - at))) ** 2                 # rescale_zero_terminal_snr
+        self.final_alpha_cumprod = torch.tensor(1.0, dtype=torch.float64)
+        self.n_train = num_train_timesteps
+
+    def set_timesteps(self, n):
+        self.n = n
+        self.timesteps = torch.from_numpy(
+            np.round(np.arange(self.n_train, 0, -self.n_train / n)).astype(np.int64) - 1)
+
+    @staticmethod
+    def _variables(a_t, a_p, a_b=None):
+        lamb = ((a_t / (1 - a_t)) ** 0.5).log()
+        lamb_next = ((a_p / (1 - a_p)) ** 0.5).log()
+        h = lamb_next - lamb
+        if a_b is not None:
+            lamb_previous = ((a_b / (1 - a_b)) ** 0.5).log()
+            return h, (lamb - lamb_previous) / h
+        return h, None
+
+    @staticmethod
+    def _mult(h, r, a_t, a_p, a_b):
+        mult1 = ((1 - a_p) / (1 - a_t)) ** 0.5 * (-h).exp()
+        mult2 = (-2 * h).expm1() * a_p ** 0.5
+        if a_b is not None:
+            return mult1, mult2, 1 + 1 / (2 * r), 1 / (2 * r)
+        return mult1, mult2
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, generator=None):
+        prev_timestep = timestep - self.n_train // self.n
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        a_b = self.alphas_cumprod[timestep_back] if timestep_back is not None else None
+        pred_original_sample = (a_t ** 0.5) * sample - ((1 - a_t) ** 0.5) * model_output          # v-prediction
+        h, r = self._variables(a_t, a_p, a_b)
+        mult = self._mult(h, r, a_t, a_p, a_b)
+        mult_noise = (1 - a_p) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+        noise = torch.randn(sample.shape, generator=generator, dtype=sample.dtype)
+        prev_sample = mult[0] * sample - mult[1] * pred_original_sample + mult_noise * noise
+        if old_pred_original_sample is None or prev_timestep < 0:
+            return prev_sample, pred_original_sample
+        denoised_d = mult[2] * pred_original_sample - mult[3] * old_pred_original_sample
+        noise = torch.randn(sample.shape, generator=generator, dtype=sample.dtype)
+        x_advanced = mult[0] * sample - mult[1] * denoised_d + mult_noise * noise
+        return x_advanced, pred_original_sample

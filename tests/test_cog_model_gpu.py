@@ -124,6 +124,65 @@ def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):
     assert out.shape == ref.shape and r < 6e-2, r
 
 
+def test_cog_dpm_scheduler_loop_vs_oracle_loop(golden):
+    """CogVideoXDPMScheduler branch of the loop (:915-926; the scheduler the CogVideoX-5B-I2V repo ships): the fused
+    fino_cfg_dpm_step path vs the oracle loop that calls the op-by-op restatement of the published step, same seeded
+    CPU generator on both sides (one draw on first-order steps, two on second-order ones).  bf16 latents."""
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    from frameino_amd.schedulers import CogVideoXDPMScheduler
+    from oracle.cog_pipeline import cog_denoise_loop
+    cfg, sd, a = golden("cog_loop_tiny")
+    cfg = _cog_cfg(cfg)
+    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
+    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
+    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDPMScheduler())
+    d = lambda k: a[k].to(DEV)          # noqa: E731
+    steps = 5
+    out = pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+                       d("negative_embeds"), float(a["guidance"]), steps, generator=torch.Generator().manual_seed(5))
+    sdb = {k: v.bfloat16() for k, v in sd.items()}
+    b = lambda k: a[k].bfloat16()       # noqa: E731
+    ref = cog_denoise_loop(sdb, cfg, b("latents"), b("image_latents"), b("traj_latents"), b("id_latent"),
+                           b("prompt_embeds"), b("negative_embeds"), (a["cos"], a["sin"]), float(a["guidance"]), steps,
+                           use_dpm=True, dpm_generator=torch.Generator().manual_seed(5))
+    r = rel_rms(out, ref)
+    print(f"DPM loop, {steps} steps: hip vs bf16 oracle loop rel-RMS {r:.4f}")
+    assert out.shape == ref.shape and torch.isfinite(out.float()).all() and r < 6e-2, r
+    # and the sampler is what differs from DDIM: same inputs, other update, other result
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    pipe.scheduler = CogVideoXDDIMScheduler()
+    out_ddim = pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+                            d("negative_embeds"), float(a["guidance"]), steps)
+    assert rel_rms(out, out_ddim) > 1e-2
+
+
+@pytest.mark.parametrize("use_old,has_uncond", [(0.0, True), (1.0, True), (1.0, False)])
+def test_cfg_dpm_step_kernel(use_old, has_uncond):
+    """fino_cfg_dpm_step vs the rounding chain of diffusers' step on a T-typed sample and fp32 model output."""
+    from frameino_amd import ops
+    g = torch.Generator().manual_seed(9)
+    fg, ft, c, h, w = 3, 4, 2, 8, 8
+    lat = torch.randn(fg, c, h, w, generator=g).bfloat16()
+    pred = torch.randn(2 if has_uncond else 1, ft, c, h, w, generator=g).bfloat16()
+    x0_old = torch.randn(fg, c, h, w, generator=g)
+    nz = torch.randn(fg, c, h, w, generator=g).bfloat16()
+    coef = torch.tensor([0.83, 0.56, 1.07, -0.31, 1.4, 0.4, 0.22, 6.0, use_old])
+    sa, sb, m1, m2, m3, m4, mn, gg, _ = coef.tolist()
+    p32 = pred.float()[:, :fg]
+    v = p32[0] + gg * (p32[1] - p32[0]) if has_uncond else p32[0]
+    x = lat.float()
+    T = lambda t: t.bfloat16().float()      # noqa: E731
+    x0 = T(sa * x) - sb * v
+    dd = m3 * x0 - m4 * x0_old if use_old else x0
+    exp = (T(m1 * x) - m2 * dd + T(mn * nz.float())).bfloat16()
+    lat_d, x0_d = lat.to(DEV), x0_old.to(DEV)
+    ops.cfg_dpm_step_(lat_d, pred.to(DEV), x0_d, nz.to(DEV), coef.to(DEV), has_uncond=has_uncond)
+    torch.testing.assert_close(x0_d.cpu(), x0, atol=1e-6, rtol=1e-6)
+    # one bf16 ulp where fma contraction / summation order differ
+    assert (lat_d.cpu().float() - exp.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, exp.float().abs().max().item())
+
+
 class _FakeDist:
     def __init__(self, z):
         self.z = z

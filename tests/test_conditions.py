@@ -71,3 +71,76 @@ def test_hip_builder_app_resolution_runs():
     assert out.shape == (49, 3, 704, 1280)
     assert out.min().item() >= -1.0 and out.max().item() <= 1.0
     assert (out > 0.98).float().mean().item() > 0.9        # mostly white background (254 or 255 after truncation)
+
+
+# ---------------------------------------------------------------------------------------- canvas / ID builders (app.py)
+def test_oracle_area_resize_hand_computed_cases():
+    """INTER_AREA's pixel-area relation on cases small enough to do by hand."""
+    from oracle.conditions import resize_area
+    img = np.zeros((2, 4, 3), dtype=np.uint8)
+    img[..., 0] = [[10, 20, 30, 40], [50, 60, 70, 80]]
+    out = resize_area(img, 1, 2)                               # 2x2 boxes: (10+20+50+60)/4 = 35, (30+40+70+80)/4 = 55
+    assert out[0, :, 0].tolist() == [35, 55]
+    row = np.zeros((1, 3, 3), dtype=np.uint8)
+    row[0, :, 0] = [0, 90, 30]
+    out = resize_area(row, 1, 2)                               # footprints [0,1.5), [1.5,3): (0 + 45)/1.5 = 30, (45+30)/1.5 = 50
+    assert out[0, :, 0].tolist() == [30, 50]
+    assert np.array_equal(resize_area(img, 2, 4), img)         # identity
+    # constant images stay constant under any scale (weights sum to one), incl. up-scaling
+    c = np.full((5, 7, 3), 137, dtype=np.uint8)
+    assert (resize_area(c, 3, 4) == 137).all() and (resize_area(c, 9, 11) == 137).all()
+
+
+def test_host_builders_cpu():
+    from frameino_amd.conditions import (crop_unpadded, id_reference_geometry, sample_traj_by_length,
+                                         tracks_from_trajectories)
+    # arc-length sampling: an L-shaped polyline of length 10 + 10, 5 samples -> every 5 units
+    pts = sample_traj_by_length([(0, 0), (10, 0), (10, 10)], 5)
+    np.testing.assert_allclose(pts, [[0, 0], [5, 0], [10, 0], [10, 5], [10, 10]], atol=1e-9)
+    tr = tracks_from_trajectories([[[(0, 0), (100, 0)], [(0, 50), (100, 50)]], [[(10, 10), (10, 90)]]], 3, 704, 1280,
+                                  480, 720)
+    assert len(tr) == 3 and len(tr[0]) == 2 and len(tr[0][0]) == 2 and len(tr[0][1]) == 1
+    assert tr[2][0][0] == (int(100 * 1280 / 720), 0) and tr[1][1][0] == (int(10 * 1280 / 720), int(50 * 704 / 480))
+    with pytest.raises(ValueError, match="too short"):
+        tracks_from_trajectories([[[(1, 1)]]], 3, 64, 64, 64, 64)
+    assert id_reference_geometry(300, 600, 704, 1280) == (352, 1280, 176, 0)      # app.py:662-672
+    fr = torch.rand(2, 64, 96, 3)
+    c = crop_unpadded(fr, 8, 16, 24, 32)
+    assert c.shape == (2, 32, 48, 3) and c.dtype == torch.uint8
+    assert torch.equal(c, (fr[:, 8:40, 16:64] * 255).to(torch.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_hw,geom", [((90, 160), (64, 96, 16, 32, 16, 0)), ((480, 832), (448, 704, 0, 64, 32, 64)),
+                                          ((37, 53), (64, 64, 0, 0, 0, 0))])
+def test_inference_canvas_vs_oracle(src_hw, geom):
+    """app.py::build_canvas: first frame area-resampled into the black unbounded canvas (down- and up-scaling)."""
+    from frameino_amd.conditions import build_inference_canvas
+    from oracle import conditions as O
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, src_hw + (3,), dtype=np.uint8)
+    out = build_inference_canvas(img, *geom).cpu().numpy()
+    ref = O.build_inference_canvas(img, *geom)
+    assert out.shape == ref.shape
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3              # fp32 vs fp64 accumulation at exact .5 ties
+    rh, rw, tl_h, tl_w, br_h, br_w = geom
+    assert (out[:tl_h] == 0).all() and (out[:, :tl_w] == 0).all() and (out[tl_h + rh:] == 0).all()
+    with pytest.raises(ValueError, match="divisible by 32"):
+        build_inference_canvas(img, 60, 96, 0, 0, 0, 0)
+
+
+@pytest.mark.gpu
+def test_id_tensor_vs_oracle():
+    from frameino_amd.conditions import prepare_id_tensor
+    from oracle import conditions as O
+    rng = np.random.default_rng(2)
+    ref_img = rng.integers(0, 256, (150, 90, 3), dtype=np.uint8)
+    t = prepare_id_tensor(ref_img, 128, 192)
+    assert t.shape == (1, 3, 1, 128, 192) and t.dtype == torch.float32
+    exp = O.pad_id_reference(ref_img, 128, 192).astype(np.float32) / 255.0 * 2.0 - 1.0
+    got = t[0, :, 0].permute(1, 2, 0).cpu().numpy()
+    assert np.abs(got - exp).max() <= 2.0 / 255 + 1e-6 and (np.abs(got - exp) > 1e-6).mean() < 5e-3
+    # reference absent: the all-black placeholder = -1 everywhere (app.py:683-685)
+    z = prepare_id_tensor(None, 64, 96, model_code_name="CogVideoX")
+    assert z.shape == (3, 64, 96) and (z == -1).all()
