@@ -91,7 +91,7 @@ def resize_area(img, out_h, out_w):
         return m / m.sum(axis=1, keepdims=True)
 
     wy, wx = weights(h, out_h), weights(w, out_w)
-    out = np.einsum("yh,hwc,xw->yxc", wy, src, wx)
+    out = np.einsum("yh,hxc->yxc", wy, np.einsum("hwc,xw->hxc", src, wx, optimize=True), optimize=True)
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
