@@ -161,3 +161,22 @@ def test_product_and_oracle_configs_agree():
     from frameino_amd.configs import WAN22_5B_CFG as product
     from oracle.wan_dit import WAN22_5B_CFG as oracle_cfg
     assert product == oracle_cfg
+
+
+def test_unipc_loop_vs_reference_pipeline_run_with_unipc(golden):
+    """tests/golden/wan_pipe_unipc_tiny.npz: the REFERENCE pipeline's own `__call__` (weights / inputs of
+    wan_pipe_tiny) driven by a UniPC scheduler for 6 steps -- against the oracle loop + UniPCOracle.  (The scheduler
+    object the reference run used is the builder's stand-in for diffusers' class: the loop is pinned, the scheduler
+    arithmetic stays third-party / unpinned.)"""
+    import numpy as np
+    import os
+    from oracle.schedulers import UniPCOracle
+    from oracle.wan_pipeline import wan_denoise_loop
+    from tests.conftest import GOLDEN
+    cfg, sd, a = golden("wan_pipe_tiny")
+    u = np.load(os.path.join(GOLDEN, "wan_pipe_unipc_tiny.npz"))
+    dit_sd = {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}
+    ref = wan_denoise_loop(dit_sd, cfg, UniPCOracle(flow_shift=5.0), a["latents0"], a["condition"], a["traj_latents"],
+                           a["id_latent"], a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]),
+                           int(u["steps"]))
+    torch.testing.assert_close(ref, torch.from_numpy(u["out_latents"]), atol=2e-5, rtol=2e-5)

@@ -135,6 +135,22 @@ def test_unipc_loop_vs_oracle_loop(golden):
     assert torch.equal(out[:, :, 0].cpu(), a["condition"][:, :, 0])
 
 
+def test_unipc_loop_vs_reference_pipeline_run(golden):
+    """The fused UniPC+CFG kernel path against the REFERENCE pipeline's own loop driven by a UniPC scheduler
+    (tests/golden/wan_pipe_unipc_tiny.npz, recorded by tools/golden/make_golden.py::gen_wan_pipe)."""
+    import os
+
+    import numpy as np
+    from tests.conftest import GOLDEN
+    pipe, a = _unipc_pipe(golden)
+    u = np.load(os.path.join(GOLDEN, "wan_pipe_unipc_tiny.npz"))
+    d = lambda k: a[k].to(DEV)                    # noqa: E731
+    out = pipe.denoise(d("latents0"), d("condition"), d("traj_latents"), d("id_latent"), d("mask"),
+                       d("prompt_embeds"), d("negative_embeds"), float(a["guidance"]), int(u["steps"]))
+    r = rel_rms(out, torch.from_numpy(u["out_latents"]))
+    assert r < 5e-2, r
+
+
 def test_unipc_hip_graph_replay_equals_eager(golden):
     pipe, a = _unipc_pipe(golden)
     eager = _run(pipe, a)

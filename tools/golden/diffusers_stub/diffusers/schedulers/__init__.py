@@ -109,3 +109,97 @@ class CogVideoXDDIMScheduler(ConfigMixin):
         cb = a_prev ** 0.5 - a_t ** 0.5 * ca
         prev = ca * sample + cb * pred_x0
         return (prev, pred_x0)
+
+
+class UniPCMultistepScheduler(ConfigMixin):
+    """Stand-in for diffusers.UniPCMultistepScheduler as Wan-AI/Wan2.2-TI2V-5B-Diffusers configures it (third-party,
+    restated tensor-op by tensor-op from the published algorithm: flow sigmas, flow_prediction, predict_x0, bh2,
+    solver_order 2, lower_order_final, final sigma 0).  Lets the REFERENCE pipeline's own loop drive a UniPC run."""
+    order = 1
+
+    @register_to_config
+    def __init__(self, num_train_timesteps=1000, solver_order=2, prediction_type="flow_prediction", flow_shift=5.0,
+                 use_flow_sigmas=True, solver_type="bh2", predict_x0=True, lower_order_final=True,
+                 final_sigmas_type="zero"):
+        assert use_flow_sigmas and prediction_type == "flow_prediction" and predict_x0 and solver_type == "bh2"
+        self.model_outputs = [None] * solver_order
+        self._step_index = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        n, shift = self.config.num_train_timesteps, self.config.flow_shift
+        alphas = np.linspace(1, 1 / n, num_inference_steps + 1)
+        sig = 1.0 - alphas
+        sig = np.flip(shift * sig / (1 + (shift - 1) * sig))[:-1].copy()
+        self.timesteps = torch.from_numpy((sig * n).copy()).to(device=device, dtype=torch.int64)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.num_inference_steps = num_inference_steps
+        self.model_outputs = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self._step_index = None
+        self.this_order = 0
+
+    @staticmethod
+    def _lam(sigma):
+        return torch.log(1 - sigma) - torch.log(sigma)
+
+    def _update(self, x, m0, others, s_t, s_0, rks_lams, model_t=None):
+        """shared body of multistep_uni_p_bh_update (model_t None) / multistep_uni_c_bh_update"""
+        alpha_t = 1 - s_t
+        h = self._lam(s_t) - self._lam(s_0)
+        rks, d1s = [], []
+        for mi, lam_i in zip(others, rks_lams):
+            rk = (lam_i - self._lam(s_0)) / h
+            rks.append(rk)
+            d1s.append((mi - m0) / rk)
+        rks.append(torch.tensor(1.0))
+        rks = torch.stack(rks)
+        order = len(rks)
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        b_h = torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / b_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        R, b = torch.stack(R), torch.stack(b)
+        x_t_ = s_t / s_0 * x - alpha_t * h_phi_1 * m0
+        if model_t is None:                                            # predictor
+            if d1s:
+                rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+                pred = sum(rhos_p[k] * d1s[k] for k in range(len(d1s)))
+            else:
+                pred = 0
+            return (x_t_ - alpha_t * b_h * pred).to(x.dtype)
+        rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+        corr = sum(rhos_c[k] * d1s[k] for k in range(len(d1s))) if d1s else 0
+        return (x_t_ - alpha_t * b_h * (corr + rhos_c[-1] * (model_t - m0))).to(x.dtype)
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kw):
+        if self._step_index is None:
+            self._step_index = (self.timesteps == timestep).nonzero()[0].item()
+        i = self._step_index
+        use_corrector = i > 0 and self.last_sample is not None
+        sigma = self.sigmas[i]
+        m_t = sample - sigma * model_output                            # convert_model_output: flow prediction -> x0
+        if use_corrector:
+            o = self.this_order
+            others = [self.model_outputs[-(k + 1)] for k in range(1, o)]
+            lams = [self._lam(self.sigmas[i - (k + 1)]) for k in range(1, o)]
+            sample = self._update(self.last_sample, self.model_outputs[-1], others, self.sigmas[i], self.sigmas[i - 1],
+                                  lams, model_t=m_t)
+        self.model_outputs = self.model_outputs[1:] + [m_t]
+        this_order = min(self.config.solver_order, len(self.timesteps) - i) if self.config.lower_order_final \
+            else self.config.solver_order
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        others = [self.model_outputs[-(k + 1)] for k in range(1, self.this_order)]
+        lams = [self._lam(self.sigmas[i - k]) for k in range(1, self.this_order)]
+        prev = self._update(sample, self.model_outputs[-1], others, self.sigmas[i + 1], self.sigmas[i], lams)
+        if self.lower_order_nums < self.config.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return (prev,)

@@ -16,7 +16,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("FINO_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, os.path.join(HERE, "diffusers_stub"))
 sys.path.insert(0, "/root/reference")
 os.chdir("/root/reference")  # the reference does sys.path.append(os.path.abspath('.'))
@@ -127,7 +127,7 @@ def gen_wan_dit():
 # ----------------------------------------------------------------------------------- Wan pipeline
 def gen_wan_pipe():
     import PIL.Image
-    from diffusers.schedulers import FlowMatchEulerDiscreteScheduler
+    from diffusers.schedulers import FlowMatchEulerDiscreteScheduler, UniPCMultistepScheduler
     from architecture.autoencoder_kl_wan import AutoencoderKLWan
     from architecture.transformer_wan import WanTransformer3DModel
     from pipelines.pipeline_wan_i2v_motion_FrameINO import WanImageToVideoPipeline
@@ -172,6 +172,15 @@ def gen_wan_pipe():
     out_np = pipe(image=PIL.Image.fromarray(img), prompt_embeds=pe, negative_prompt_embeds=ne, traj_tensor=traj,
                   ID_tensor=idt, height=H, width=W, num_frames=F, num_inference_steps=steps, guidance_scale=5.0,
                   latents=lat0.clone(), output_type="np").frames
+    # the same call driven by the UniPC scheduler the released Wan2.2 folder ships (stand-in scheduler, reference loop):
+    # 6 steps = order-1 start, order-2 middle, order-1 final step, corrector throughout
+    pipe.scheduler = UniPCMultistepScheduler(flow_shift=5.0)
+    out_unipc = pipe(image=PIL.Image.fromarray(img), prompt_embeds=pe, negative_prompt_embeds=ne, traj_tensor=traj,
+                     ID_tensor=idt, height=H, width=W, num_frames=F, num_inference_steps=6, guidance_scale=5.0,
+                     latents=lat0.clone(), output_type="latent").frames
+    np.savez_compressed(os.path.join(OUT, "wan_pipe_unipc_tiny.npz"), out_latents=to_np(out_unipc), steps=np.array(6),
+                        timesteps=to_np(pipe.scheduler.timesteps))
+    print("wrote wan_pipe_unipc_tiny.npz (outputs only: weights and inputs are wan_pipe_tiny's)")
     sched.set_timesteps(steps)
     sd = {"dit." + k: v for k, v in dit.state_dict().items()}
     sd.update({"vae." + k: v for k, v in vae.state_dict().items()})
