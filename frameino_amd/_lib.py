@@ -42,6 +42,10 @@ SIGNATURES = {
     "fino_gemm_mxfp8_q": [c_void_p] * 7 + [c_i64] * 3 + [c_int, c_int, c_void_p],
     "fino_traj_paint": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fino_traj_blur_quantize": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "fino_groupnorm_workspace_bytes": [c_int],
+    "fino_groupnorm_cl": [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p] +
+                         [c_int] * 4 + [c_void_p, c_i64, c_int, c_void_p],
+    "fino_avg_pool_time2": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     "fino_resize_area_pad_u8": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
     "fino_u8_hwc_to_chw_unit": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
@@ -61,7 +65,8 @@ SIGNATURES = {
     "fino_vae_unpatchify_clamp": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     "fino_vae_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
 }
-_RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64, "fino_mxfp8_scale_bytes": c_i64}
+_RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64, "fino_mxfp8_scale_bytes": c_i64,
+             "fino_groupnorm_workspace_bytes": c_i64}
 
 
 def declared_symbols(header_path=HEADER_PATH):

@@ -459,3 +459,39 @@ def vae_patchify(x, c_pad, patch, dtype):
     _lib.check(_lib.lib().fino_vae_patchify(_p(x), _p(y), t, hp // patch, wp // patch, c_pad, c, patch, _dt(y),
                                            _stream()), "fino_vae_patchify")
     return y
+
+
+# ------------------------------------------------------------------------------------------------ CogVideoX VAE
+_GN_WS = {}
+
+
+def groupnorm_cl(x, c_valid, groups, gamma, beta, eps=1e-6, mod=None, silu=False, out=None):
+    """x [T, H, W, Cpad] channels-last -> T(GroupNorm(x)) [ * scale[z] + shift[z] ] [ -> silu ].  mod = (scale, shift),
+    each [Tz, hz, wz, Cpad] of x's dtype (CogVideoXSpatialNorm3D's conv_y / conv_b at latent resolution)."""
+    assert x.dim() == 4 and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    t, h, w, cp = x.shape
+    out = torch.empty_like(x) if out is None else out
+    need = _lib.lib().fino_groupnorm_workspace_bytes(cp)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, cp)
+    ws = _GN_WS.get(key)
+    if ws is None:
+        ws = _GN_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    ms = mh = None
+    tz = hz = wz = 0
+    if mod is not None:
+        ms, mh = mod
+        assert ms.shape == mh.shape and ms.shape[3] == cp and ms.is_contiguous() and mh.is_contiguous() \
+            and ms.dtype == x.dtype
+        tz, hz, wz = ms.shape[:3]
+    _lib.check(_lib.lib().fino_groupnorm_cl(_p(x), _p(out), t, h, w, c_valid, cp, groups, _p(gamma), _p(beta), eps,
+                                           _p(ms), _p(mh), tz, hz, wz, int(silu), _p(ws), need, _dt(x), _stream()),
+               "fino_groupnorm_cl")
+    return out
+
+
+def avg_pool_time2(x):
+    t, h, w, cp = x.shape
+    assert x.is_contiguous() and t > 1
+    out = torch.empty(((t & 1) + (t - (t & 1)) // 2, h, w, cp), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().fino_avg_pool_time2(_p(x), _p(out), t, h, w, cp, _dt(x), _stream()), "fino_avg_pool_time2")
+    return out

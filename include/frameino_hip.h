@@ -254,6 +254,23 @@ int fino_traj_blur_quantize(const float* canvas, float* scratch, float* out, con
                             int height, int width, void* stream);
 
 
+/* ---- CogVideoX 3D causal VAE (diffusers AutoencoderKLCogVideoX, third-party; call sites
+ * pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:380-396 encode, :426-431 decode, :809-826 condition encodes) ----
+ * Channels-last activations [T, H, W, Cpad] like the Wan VAE; convolutions are fino_conv3d.
+ * fino_groupnorm_cl: nn.GroupNorm(groups, channels, eps) over one frame batch (statistics per group over
+ *   C/G x T x H x W, fp32 partials + fp64 finalisation, deterministic), y = T(gn(x)); with mod_scale / mod_shift
+ *   (CogVideoXSpatialNorm3D: the conv_y / conv_b outputs at LATENT resolution [tz, hz, wz, Cpad] of T) it continues
+ *   y = T(T(y * scale[z]) + shift[z]) through F.interpolate's nearest index map (first frame of an odd-length batch
+ *   mapped on its own); silu != 0 appends T(silu(y)).  workspace: fino_groupnorm_workspace_bytes(c_pad) bytes.
+ * fino_avg_pool_time2: CogVideoXDownsample3D's temporal compression: frame pairs averaged, the first frame of an
+ *   odd-length batch kept -> [t_in/2 (+1), H, W, Cpad]. */
+int64_t fino_groupnorm_workspace_bytes(int c_pad);
+int fino_groupnorm_cl(const void* x, void* y, int t, int h, int w, int channels, int c_pad, int groups,
+                      const float* gamma, const float* beta, float eps, const void* mod_scale, const void* mod_shift,
+                      int tz, int hz, int wz, int silu, void* workspace, int64_t workspace_bytes, int dtype,
+                      void* stream);
+int fino_avg_pool_time2(const void* x, void* y, int t_in, int h, int w, int c_pad, int dtype, void* stream);
+
 /* Canvas / identity-reference builders of app.py (:270-350 build_canvas, :634-695 ID padding), on the device.
  * fino_resize_area_pad_u8: pixel-area resampling (cv2.INTER_AREA's area relation; OpenCV is third-party and absent
  *   offline: parity unpinned) of src uint8 [src_h, src_w, 3] to region_h x region_w, written at (off_y, off_x) of dst
