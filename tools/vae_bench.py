@@ -14,8 +14,31 @@ ap.add_argument("--frames", type=int, default=13)
 ap.add_argument("--h", type=int, default=44)
 ap.add_argument("--w", type=int, default=80)
 ap.add_argument("--encode", action="store_true")
+ap.add_argument("--cog", action="store_true", help="CogVideoX VAE (49 f 480x720: latent 13 x 60 x 90) instead of the Wan one")
 a = ap.parse_args()
 dev = torch.device("cuda")
+if a.cog:
+    from frameino_amd.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+    vae = AutoencoderKLCogVideoX().random_init_(seed=0, device=dev)
+    h, w = (60, 90) if (a.h, a.w) == (44, 80) else (a.h, a.w)
+    z = torch.randn(1, 16, a.frames, h, w, device=dev)
+    for it in range(2):
+        torch.cuda.reset_peak_memory_stats(); torch.cuda.synchronize(); t0 = time.time()
+        with ops.KernelTimer({"conv3d"}) as kt:
+            out = vae.decode(z).sample
+        torch.cuda.synchronize(); dt = time.time() - t0
+        s = kt.summary().get("conv3d", {})
+        print(f"cog decode {tuple(z.shape)} -> {tuple(out.shape)}: {dt:.3f} s; conv launches {s.get('launches')} total "
+              f"{s.get('total_ms', 0):.1f} ms, {kt.flops.get('conv3d', 0) / max(s.get('total_ms', 1), 1e-9) / 1e9:.1f} TFLOP/s "
+              f"(padded FLOPs {kt.flops.get('conv3d', 0):.3e}); peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+    assert torch.isfinite(out.float()).all()
+    vid = torch.rand(1, 3, 1 + 4 * (a.frames - 1), h * 8, w * 8, device=dev) * 2 - 1
+    for it in range(2):
+        torch.cuda.synchronize(); t0 = time.time()
+        m = vae.encode(vid).latent_dist.mode()
+        torch.cuda.synchronize()
+        print(f"cog encode {tuple(vid.shape)} -> {tuple(m.shape)}: {time.time() - t0:.3f} s", flush=True)
+    sys.exit(0)
 vae = AutoencoderKLWan(**WAN22_VAE).random_init_(seed=0, device=dev)
 z = torch.randn(1, 48, a.frames, a.h, a.w, device=dev)
 for it in range(2):
