@@ -129,6 +129,11 @@ class AutoencoderKLWan:
         self._dtype = torch.bfloat16
         self._device = torch.device("cpu")
         self.use_slicing = self.use_tiling = False
+        # frames per time chunk of the decoder's tail: results do not depend on it.  0 / None: whole sequence (fastest:
+        # 0.73 s and 36 GiB for 49 f 704x1280), n: chunks of n frames (8: 0.80 s, 20 GiB), "auto": whole sequence while
+        # its estimated activation peak stays under `decode_memory_budget_gib`, chunks of 8 above (1024x1792, 81 f).
+        self.decode_chunk_frames = "auto"
+        self.decode_memory_budget_gib = 48.0
 
     # ---- module-like surface ----
     @property
@@ -235,19 +240,29 @@ class AutoencoderKLWan:
         e = self._pk[name]
         return ops.conv3d_cl(x, e.w, e.b, e.k, stride, pad, out_thw, up, residual)
 
-    def _causal3(self, x, name, residual=None):
+    def _causal3(self, x, name, residual=None, caches=None):
+        """WanCausalConv3d over the whole sequence (kt - 1 zero frames in front) or, with `caches` (time-chunked tail
+        of the decoder), over one chunk whose history is the last kt - 1 input frames of the previous chunk: the same
+        arithmetic per output element either way (the reference streams exactly like this, :350-358)."""
         e = self._pk[name]
         kt, kh, kw = e.k
-        return self._conv(x, name, (kt - 1, kh // 2, kw // 2), residual=residual)
+        if caches is None or kt == 1:
+            return self._conv(x, name, (kt - 1, kh // 2, kw // 2), residual=residual)
+        prev = caches.get(name)
+        if prev is None:                               # first chunk: the history is zeros (same as the front padding)
+            prev = torch.zeros((kt - 1,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        xin = torch.cat([prev, x], dim=0)
+        caches[name] = xin[-(kt - 1):].clone()
+        return self._conv(xin, name, (0, kh // 2, kw // 2), residual=residual)
 
     def _norm(self, x, name, silu=True):
         e = self._pk[name]
         return ops.rmsnorm_silu_cl(x, e.g, e.c, silu)
 
-    def _res(self, x, p):
+    def _res(self, x, p, caches=None):
         h = self._causal3(x, p + ".conv_shortcut") if (p + ".conv_shortcut") in self._pk else x
-        y = self._causal3(self._norm(x, p + ".norm1.gamma"), p + ".conv1")
-        return self._causal3(self._norm(y, p + ".norm2.gamma"), p + ".conv2", residual=h)
+        y = self._causal3(self._norm(x, p + ".norm1.gamma"), p + ".conv1", caches=caches)
+        return self._causal3(self._norm(y, p + ".norm2.gamma"), p + ".conv2", residual=h, caches=caches)
 
     def _attn(self, x, p):
         """WanAttentionBlock (:402-427): one head of dim C over the h.w tokens of each frame."""
@@ -304,15 +319,19 @@ class AutoencoderKLWan:
         x = self._causal3(x, "decoder.conv_in")
         x = self._mid(x, "decoder.mid_block")
         nb = len(mult)
-        for i in range(nb):
+        ps = cfg.patch_size or 1
+
+        def up_block(x, i, caches=None):
+            """one WanResidualUpBlock (:626-716); with `caches`: on a time chunk (blocks without temporal upsampling)"""
             p = f"decoder.up_blocks.{i}"
             up_flag = i != nb - 1
             temporal = bool(tup[i]) if up_flag else False
             x_copy = x
             for r in range(cfg.num_res_blocks + 1):
-                x = self._res(x, f"{p}.resnets.{r}")
+                x = self._res(x, f"{p}.resnets.{r}", caches)
             if up_flag:
                 if temporal and x.shape[0] > 1:
+                    assert caches is None
                     e = pk[p + ".upsampler.time_conv"]
                     tt, hh, ww, cp = x.shape
                     y = self._causal3(x[1:].contiguous(), p + ".upsampler.time_conv")     # [T-1, H, W, 2*Cpad]
@@ -322,9 +341,42 @@ class AutoencoderKLWan:
                     x = xn
                 x = self._conv(x, p + ".upsampler.resample.1", (0, 1, 1), up=True)
                 x = ops.dup_up3d_add(x, x_copy, dec[i], dec[i + 1], 2 if temporal else 1, 2)
-        x = self._norm(x, "decoder.norm_out.gamma")
-        x = self._causal3(x, "decoder.conv_out")
-        out = ops.vae_unpatchify_clamp(x, cfg.out_channels // (cfg.patch_size or 1) ** 2, cfg.patch_size or 1)[None]
+            return x
+
+        def head(x, caches=None):
+            x = self._norm(x, "decoder.norm_out.gamma")
+            x = self._causal3(x, "decoder.conv_out", caches=caches)
+            return ops.vae_unpatchify_clamp(x, cfg.out_channels // ps ** 2, ps)              # [C, T, H*ps, W*ps] fp32
+
+        # The blocks up to and including the last temporal upsampling run once over the whole sequence; the tail --
+        # where the activations are largest (49 x 352 x 640 x 512 channels = 11 GB per tensor at 704x1280) and the frame
+        # count no longer changes -- runs in time chunks with the last two input frames of every causal conv carried
+        # over: identical results (each output element sees the same taps), activation memory of one chunk.
+        last_temporal = max([i for i in range(nb - 1) if tup[i]], default=-1)
+        for i in range(last_temporal + 1):
+            x = up_block(x, i)
+        chunk = self.decode_chunk_frames
+        tt = x.shape[0]
+        if chunk == "auto":
+            # measured: the whole-sequence peak is ~6.4 tensors of [T, H/2, W/2, decoder_base_dim] at the output size
+            sp = 2 ** (nb - 1 - (last_temporal + 1))
+            est = 6.4 * tt * x.shape[1] * sp * x.shape[2] * sp * cpad(cfg.decoder_base_dim) * 2 / 2 ** 30
+            chunk = 8 if est > self.decode_memory_budget_gib else 0
+        if not chunk or chunk >= tt or last_temporal + 1 >= nb:
+            for i in range(last_temporal + 1, nb):
+                x = up_block(x, i)
+            out = head(x)[None]
+        else:
+            caches, out = {}, None
+            for t0 in range(0, tt, chunk):
+                xc = x[t0:t0 + chunk]
+                for i in range(last_temporal + 1, nb):
+                    xc = up_block(xc, i, caches)
+                v = head(xc, caches)
+                if out is None:
+                    out = torch.empty((1, v.shape[0], tt) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+                out[0, :, t0:t0 + v.shape[1]] = v
+                del xc, v
         return (out,) if not return_dict else SimpleNamespace(sample=out)
 
     # ---- encode (reference :1145-1169, whole-sequence) ----

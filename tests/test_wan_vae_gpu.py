@@ -144,3 +144,22 @@ def test_full_width_vae_vs_oracle_small_video():
     p = psnr(out, ref_v)
     print(f"full-width VAE: encode rel-RMS {r_enc:.4f}, decode PSNR {p:.1f} dB")
     assert r_enc < 3e-2 and p > 35.0
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 3, 5])
+def test_time_chunked_decoder_tail_is_bit_identical_to_whole_sequence(chunk):
+    """`decode_chunk_frames`: the decoder's tail (the blocks after the last temporal upsampling + the head) run chunk
+    by chunk in time with the last two input frames of every causal conv carried over (what the reference's feat_cache
+    streaming does, :350-358) -- a memory schedule only: every output element sees the same taps in the same order."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    cfg = dict(base_dim=16, decoder_base_dim=16, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
+               temperal_downsample=[False, True, True], is_residual=True, in_channels=12, out_channels=12, patch_size=2,
+               scale_factor_temporal=4, scale_factor_spatial=16)
+    vae = AutoencoderKLWan(**cfg).random_init_(seed=4, device=DEV)
+    z = torch.randn(1, 4, 4, 3, 5, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))    # -> 13 frames
+    vae.decode_chunk_frames = 0
+    whole = vae.decode(z, return_dict=False)[0]
+    vae.decode_chunk_frames = chunk
+    chunked = vae.decode(z, return_dict=False)[0]
+    assert whole.shape == chunked.shape == (1, 3, 13, 48, 80)
+    assert torch.equal(whole, chunked)
