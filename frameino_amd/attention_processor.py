@@ -90,15 +90,19 @@ class Attention(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ helpers
 def _fused_weight(attn, names, key):
-    """cat of nn.Linear weights/biases, cached on the module and rebuilt when a source tensor changes."""
+    """cat of nn.Linear weights/biases, cached on the module and rebuilt when a source tensor is replaced (`.to()`,
+    a new Parameter) or modified in place (`load_state_dict`, optimiser step).  The entry keeps the source tensors
+    themselves: identity + in-place version, never an address the allocator may hand to another tensor."""
     mods = [getattr(attn, n) for n in names]
-    sig = tuple((m.weight.data_ptr(), m.weight._version) for m in mods)
+    srcs = [t for m in mods for t in (m.weight, m.bias) if t is not None]
     cache = attn.__dict__.setdefault("_fino_cache", {})
     hit = cache.get(key)
-    if hit is None or hit[0] != sig:
+    fresh = hit is not None and len(hit[0]) == len(srcs) and all(
+        a is t and v == t._version and a.device == t.device for (a, v), t in zip(hit[0], srcs))
+    if not fresh:
         w = torch.cat([m.weight.data for m in mods]).contiguous()
         b = torch.cat([m.bias.data for m in mods]).contiguous() if mods[0].bias is not None else None
-        cache[key] = (sig, w, b)
+        cache[key] = ([(t, t._version) for t in srcs], w, b)
         hit = cache[key]
     return hit[1], hit[2]
 
