@@ -140,6 +140,7 @@ class WanTransformer3DModel(nn.Module):
         self.ops = ops            # kernel front end (tests of the sharding logic inject a CPU stand-in)
         self.parallel = None      # frameino_amd.parallel.TokenShard or None
         self._fp8 = {}            # (layer, linear) -> (e4m3 weight bytes, MX scales); see enable_mxfp8_linears
+        self.dedup_shared_prefix = True   # A/B knob: CFG-batched call computes the branch-invariant prefix once
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -418,24 +419,44 @@ class WanTransformer3DModel(nn.Module):
         lt = encoder_hidden_states.shape[1]
 
         # ---- patch embedding (:486-487): gather + GEMM (the gather is 9 MB; every rank builds it, keeps its rows) ----
-        if b == 1:
+        # `shared`: the batch elements are the SAME latent (the pipeline's CFG-batched call passes x.expand(2, ...)) under
+        # the same timestep rows: everything up to the first text cross-attention is identical for them, so the patch
+        # embedding and layer 0's self-attention branch run once and their result is copied (exactly what each element
+        # would have computed).
+        shared = self.dedup_shared_prefix and b > 1 and sh is None and hidden_states.stride(0) == 0 and default_procs
+        if b == 1 or shared:
             a_rows = o.patchify(hidden_states[0], cfg.patch_size)[lo:lo + n]
         else:
             a_rows = torch.cat([o.patchify(hidden_states[i], cfg.patch_size) for i in range(b)])
-        x = o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=ws.x[:nr])
+        x = ws.x[:nr]
+        o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=x[:n] if shared else x)
         nrm, att, q2, ff = ws.n[:nr], ws.att[:nr], ws.q2[:nr], ws.ff[:nr]
         yield
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
             # 1. self-attention (:334-336)
-            o.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=nrm)
+            once = shared and li == 0
+            if not once:
+                o.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=nrm)
             if not default_procs:
                 if sh is not None:
                     raise NotImplementedError("token-sharded execution needs the built-in MI355WanAttnProcessor")
                 rot = _CompactRope((cos1, sin1))
                 a = blk.attn1(nrm.view(b, n, d), rotary_emb=rot, **(attention_kwargs or {}))
                 o.gated_residual(x, a.reshape(nr, d), m[:, 2], sel, out=x)
+            elif sh is None and shared and li == 0:
+                n1, q1, sel1 = nrm[:n], ws.qkv[:n], (None if sel is None else sel[:n])
+                o.adaln_modulate(x[:n], m[:, 0], m[:, 1], sel1, cfg.eps, out=n1)
+                self._lin(li, "qkv", n1, e.wqkv, e.bqkv, out=q1)
+                o.rmsnorm_rope_(q1[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos1, sin1, dh)
+                o.rmsnorm_rope_(q1[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos1, sin1, dh)
+                q3 = q1.view(1, n, 3 * d)
+                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att[:n].view(1, n, d))
+                self._lin(li, "out", att[:n], blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
+                          residual=x[:n], gate=m[:, 2], sel=sel1, out=x[:n])
+                for bi in range(1, b):
+                    x[bi * n:(bi + 1) * n].copy_(x[:n])
             elif sh is None:
                 qkv = ws.qkv[:nr]
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
@@ -455,7 +476,7 @@ class WanTransformer3DModel(nn.Module):
                     work.wait()
                 kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
                 o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
-            if default_procs:
+            if default_procs and not once:
                 self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x, gate=m[:, 2], sel=sel, out=x)
             # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange

@@ -130,3 +130,25 @@ def test_full_width_two_layers_vs_oracle():
     r32, rb = rel_rms(out, ref32), rel_rms(out, refb)
     print(f"full width, 2 layers: hip-vs-fp32 {r32:.4f}  hip-vs-bf16-oracle {rb:.4f}")
     assert out.shape == (1, 48, 4, 16, 32) and r32 < 3e-2 and rb < 1.5e-2
+
+
+def test_cfg_batch_of_one_latent_runs_the_shared_prefix_once(golden):
+    """The pipeline's CFG-batched call passes the SAME latent for both branches (x.expand(2, ...)): patch embedding and
+    layer 0's self-attention branch see identical inputs, are computed once and copied.  Must equal the batch built from
+    two materialised copies (which takes the general path) and the two separate batch-1 forwards of the reference loop."""
+    cfg, sd, a = golden("wan_dit_tiny")
+    m = hip_wan_model(cfg, sd, DEV)
+    x = a["x"].to(DEV).bfloat16()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    txt2 = torch.randn(2, 20, 16, device=DEV, generator=g).bfloat16()
+    ts = a["ts_tok"].to(DEV)
+    rows = (torch.tensor([0.0, 437.0], device=DEV), (ts[0] != 0).to(torch.int32))
+    kw = dict(timestep=None, return_dict=False, timestep_rows=rows)
+    shared = m(hidden_states=x.expand(2, -1, -1, -1, -1), encoder_hidden_states=txt2, **kw)[0]
+    general = m(hidden_states=x.repeat(2, 1, 1, 1, 1), encoder_hidden_states=txt2, **kw)[0]
+    assert shared.shape == general.shape == (2,) + tuple(a["y_tok"].shape[1:])
+    assert torch.equal(shared, general)
+    for i in range(2):
+        with m.cache_context(f"b{i}"):
+            single = m(hidden_states=x, encoder_hidden_states=txt2[i:i + 1], **kw)[0]
+        assert torch.equal(shared[i:i + 1], single)
