@@ -27,6 +27,7 @@ WORKLOADS = {
     # name: (latent frames generated, latent h, latent w)
     "wan2.2-5b-49f-704x1280": (13, 44, 80),
     "wan2.2-5b-49f-1024x1792": (13, 64, 112),
+    "wan2.2-5b-81f-704x1280": (21, 44, 80),          # the app's default clip length (app.py:543): L = 19360
     "tiny": (3, 8, 12),
 }
 
@@ -394,7 +395,11 @@ def main():
 
     if not a.no_secondary and a.workload == "wan2.2-5b-49f-704x1280" and not a.layers and not a.mxfp8:
         # (d) BASELINE config 4's per-GPU-independent part: the same model at 1024x1792 (L = 25088), whole on one GPU
-        secondary["config4_wan_1024x1792_L25088"] = config4_ms_per_step(pipe, make_inputs, cfg, dev)
+        secondary["config4_wan_1024x1792_L25088"] = other_workload_ms_per_step(
+            pipe, make_inputs, cfg, dev, "wan2.2-5b-49f-1024x1792")
+        # the app's default clip (81 frames 704x1280, app.py:543)
+        secondary["app_default_81f_704x1280_L19360"] = other_workload_ms_per_step(
+            pipe, make_inputs, cfg, dev, "wan2.2-5b-81f-704x1280")
         # (e) BASELINE config 5: CogVideoX-5B FrameINO 49f 480x720, bf16 and MXFP8 linears
         del pipe, st
         model.reset_caches()
@@ -473,10 +478,11 @@ def attention_probe(ops, dev, L, heads, dh, logit_scale):
     return out
 
 
-def config4_ms_per_step(pipe, make_inputs, cfg, dev, steps=2):
-    """BASELINE config 4's clip (49 f 1024x1792 + ID frame, L = 25088) on ONE GPU: what each of the 8 ranks' shards add
-    up to before the wire.  1 warm + `steps` timed steps."""
-    fg, lh, lw = WORKLOADS["wan2.2-5b-49f-1024x1792"]
+def other_workload_ms_per_step(pipe, make_inputs, cfg, dev, workload, steps=2):
+    """Another clip size through the same pipeline on ONE GPU, 1 warm + `steps` timed steps: BASELINE config 4's clip
+    (49 f 1024x1792 + ID frame, L = 25088: what the 8 ranks' shards add up to before the wire) and the app's default
+    81-frame clip (L = 19360)."""
+    fg, lh, lw = WORKLOADS[workload]
     inputs = make_inputs(fg, lh, lw, cfg["text_dim"])
     st = pipe.make_state(*inputs, 5.0)
     ts, dts = pipe.scheduler.timesteps.to(dev).float(), pipe.scheduler.dts.to(dev)
