@@ -6,26 +6,34 @@
 
 namespace {
 
-// WanRMS_norm (:201-202) + optional SiLU: y = act( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ), one wave per position.
-template <typename T>
+// WanRMS_norm (:201-202) + optional SiLU: y = act( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ).  A position's row of
+// `cpad` channels is LPR = min(64, cpad/8) lanes of 16 bytes (looped when cpad > 512), so a wave handles 64 / LPR
+// positions at once (2 at 256 channels -- the widths of the decoder's largest stages -- 8 at 64) and the sum of
+// squares is reduced inside each LPR-lane group.
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(const uint16_t* __restrict__ x,
                                                               uint16_t* __restrict__ y, int64_t rows, int cpad,
                                                               float sqrt_c, const float* __restrict__ gamma,
                                                               int silu) {
+    constexpr int kRowsPerWave = 64 / LPR;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const uint16_t* px = x + row * cpad;
+    const int sub = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave + lane / LPR;
+    const bool live = row < rows;
+    const uint16_t* px = x + (live ? row : 0) * cpad;
     float ss = 0.f;
-    for (int c = lane * 8; c < cpad; c += 512) {
-        float v[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(px + c), v);
+    if (live)
+        for (int c = sub * 8; c < cpad; c += LPR * 8) {
+            float v[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(px + c), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
-    }
-    ss = wave_sum(ss);
+            for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+        }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (!live) return;
     const float inv = sqrt_c / fmaxf(sqrtf(ss), 1e-12f);
-    for (int c = lane * 8; c < cpad; c += 512) {
+    for (int c = sub * 8; c < cpad; c += LPR * 8) {
         float v[8], o[8];
         unpack8<T>(*reinterpret_cast<const uint4*>(px + c), v);
         const float4 g0 = *reinterpret_cast<const float4*>(gamma + c);
@@ -61,27 +69,40 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(uint16_t* __restrict_
 
 // out = main + DupUp3D(x) (:90-131, whole-sequence: frame 0 keeps its last temporal copy).  channels-last.
 //   out[to, ho, wo, c] = main[...] + x[t, ho/fs, wo/fs, (((c*ft + a)*fs + b)*fs + d) / rep]
+// One thread = 8 consecutive output channels (16-byte main load / store); their 8 source channels k/rep are one 16-byte
+// load when they are consecutive too (rep == ft*fs*fs: equal widths), scalar gathers from a 16..32-byte window otherwise.
 template <typename T>
 __global__ __launch_bounds__(256) void dup_up3d_add_kernel(const uint16_t* __restrict__ mainp,
                                                            const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
                                                            int t_out, int h_out, int w_out, int c_out, int c_out_pad,
                                                            int h_in, int w_in, int c_in_pad, int ft, int fs, int rep) {
-    const int64_t total = (int64_t)t_out * h_out * w_out * c_out_pad;
+    const int chunks = c_out_pad >> 3;
+    const int64_t total = (int64_t)t_out * h_out * w_out * chunks;
+    const int factor = ft * fs * fs;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c_out_pad);
-        const int64_t pos = i / c_out_pad;
+        const int c0 = (int)(i % chunks) * 8;
+        const int64_t pos = i / chunks;
         const int wo = (int)(pos % w_out);
         const int ho = (int)((pos / w_out) % h_out);
         const int to = (int)(pos / ((int64_t)w_out * h_out));
-        float v = T::to_f32(mainp[i]);
-        if (c < c_out) {
-            int t, a;
-            if (to == 0) { t = 0; a = ft - 1; } else { t = 1 + (to - 1) / ft; a = (to - 1) % ft; }
-            const int k = ((c * ft + a) * fs + (ho % fs)) * fs + (wo % fs);
-            v += T::to_f32(x[(((int64_t)t * h_in + ho / fs) * w_in + wo / fs) * c_in_pad + k / rep]);
+        float v[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(mainp + pos * c_out_pad + c0), v);
+        int t, a;
+        if (to == 0) { t = 0; a = ft - 1; } else { t = 1 + (to - 1) / ft; a = (to - 1) % ft; }
+        const uint16_t* xr = x + (((int64_t)t * h_in + ho / fs) * w_in + wo / fs) * c_in_pad;
+        const int sub = (a * fs + (ho % fs)) * fs + (wo % fs);            // k = c * factor + sub
+        if (rep == factor && c0 + 8 <= c_out) {
+            float s[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(xr + c0), s);      // k / rep = c
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += s[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < c_out) v[j] += T::to_f32(xr[((c0 + j) * factor + sub) / rep]);
         }
-        out[i] = T::from_f32(v);
+        *reinterpret_cast<uint4*>(out + pos * c_out_pad + c0) = pack8<T>(v);
     }
 }
 
@@ -186,8 +207,24 @@ extern "C" int fino_rmsnorm_silu_cl(const void* x, void* y, int64_t rows, int c_
     FINO_CHECK(fino_aligned16(x) && fino_aligned16(y) && fino_aligned16(gamma), FINO_ERR_ARG,
                "fino_rmsnorm_silu_cl: 16-byte alignment required");
     if (rows == 0) return FINO_OK;
-    VAE_DISPATCH(rmsnorm_silu_cl_kernel, (unsigned)((rows + 3) / 4), (const uint16_t*)x, (uint16_t*)y, rows, c_pad,
-                 sqrtf((float)c_valid), gamma, silu);
+    hipStream_t st_ = (hipStream_t)stream;
+    const int lpr = c_pad / 8 >= 64 ? 64 : c_pad / 8;
+    const float sc = sqrtf((float)c_valid);
+#define RMS_LAUNCH(L_)                                                                                              \
+    {                                                                                                               \
+        const unsigned grid = (unsigned)((rows + 4 * (64 / L_) - 1) / (4 * (64 / L_)));                             \
+        if (dtype == FINO_BF16)                                                                                     \
+            rmsnorm_silu_cl_kernel<BF16, L_><<<grid, 256, 0, st_>>>((const uint16_t*)x, (uint16_t*)y, rows, c_pad, sc, gamma, silu); \
+        else                                                                                                        \
+            rmsnorm_silu_cl_kernel<F16, L_><<<grid, 256, 0, st_>>>((const uint16_t*)x, (uint16_t*)y, rows, c_pad, sc, gamma, silu);  \
+    }
+    if (lpr == 64) RMS_LAUNCH(64)
+    else if (lpr == 32) RMS_LAUNCH(32)
+    else if (lpr == 16) RMS_LAUNCH(16)
+    else if (lpr == 8) RMS_LAUNCH(8)
+    else RMS_LAUNCH(64)                    /* rows that are not a power-of-two number of chunks: one row per wave */
+#undef RMS_LAUNCH
+    FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
 
@@ -208,7 +245,8 @@ extern "C" int fino_dup_up3d_add(const void* main_in, const void* x, void* out, 
     const int factor = factor_t * factor_s * factor_s;
     FINO_CHECK((c_out * factor) % c_in == 0, FINO_ERR_ARG, "fino_dup_up3d_add: out_channels*factor %% in_channels");
     const int t_out = 1 + (t_in - 1) * factor_t;
-    const int64_t total = (int64_t)t_out * h_in * factor_s * w_in * factor_s * c_out_pad;
+    FINO_CHECK(c_out_pad % 8 == 0 && c_in_pad % 8 == 0, FINO_ERR_ARG, "fino_dup_up3d_add: padded widths %% 8");
+    const int64_t total = (int64_t)t_out * h_in * factor_s * w_in * factor_s * (c_out_pad / 8);
     VAE_DISPATCH(dup_up3d_add_kernel, grid_1d(total), (const uint16_t*)main_in, (const uint16_t*)x, (uint16_t*)out,
                  t_out, h_in * factor_s, w_in * factor_s, c_out, c_out_pad, h_in, w_in, c_in_pad, factor_t, factor_s,
                  c_out * factor / c_in);

@@ -63,3 +63,6 @@ import shutil; shutil.copy(cp, f"gpurun_out/{tag}_vae_kernel_stats.csv")
 print(json.dumps({k: v.get("mfma_busy_frac") for k, v in out["pmc_sum_over_dispatches"].items()}, indent=1)[:1500])
 PY
 st=$(ls gpurun_out/${tag}_trace/*/*kernel_stats.csv | head -1); cp $st gpurun_out/${tag}_kernel_stats.csv
+# raw traces are large (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf gpurun_out/${tag}_trace gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_sq gpurun_out/${tag}_vae_trace gpurun_out/${tag}_vae_sq gpurun_out/${tag}_vae_fetch
+ls -la gpurun_out/
