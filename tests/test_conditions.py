@@ -144,3 +144,31 @@ def test_id_tensor_vs_oracle():
     # reference absent: the all-black placeholder = -1 everywhere (app.py:683-685)
     z = prepare_id_tensor(None, 64, 96, model_code_name="CogVideoX")
     assert z.shape == (3, 64, 96) and (z == -1).all()
+
+
+def test_bicubic_resize_of_the_trajectory_canvas_hand_computed():
+    """`prepare_traj_tensor` resizes the painted canvases with torch's bicubic interpolation when original != target
+    size (the reference: cv2.resize INTER_CUBIC, data_loader/video_dataset_motion.py:169).  Both use the Keys cubic
+    with a = -0.75 on half-pixel centres; here the torch op is checked against that formula computed by hand on a
+    1-D ramp with a step (2x up-scaling: source coordinate = (dst + 0.5) / 2 - 0.5, taps at floor - 1 .. floor + 2,
+    borders clamped)."""
+    def keys(x, a=-0.75):
+        x = abs(x)
+        if x <= 1:
+            return (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1
+        if x < 2:
+            return a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a
+        return 0.0
+
+    src = [255.0, 255.0, 0.0, 255.0, 128.0, 255.0]
+    n = len(src)
+    exp = []
+    for d in range(2 * n):
+        s = (d + 0.5) / 2 - 0.5
+        f = int(np.floor(s))
+        exp.append(sum(keys(s - (f + k)) * src[min(max(f + k, 0), n - 1)] for k in (-1, 0, 1, 2)))
+    t = torch.tensor(src).view(1, 1, 1, n).repeat(1, 1, 3, 1)
+    out = torch.nn.functional.interpolate(t, size=(3, 2 * n), mode="bicubic", align_corners=False)[0, 0, 1]
+    np.testing.assert_allclose(out.numpy(), np.array(exp), rtol=0, atol=1e-3)
+    assert out.max() > 255.0                                    # cubic overshoot next to the step: not clamped here,
+    # the uint8 truncation at the end of prepare_traj_tensor (:172) happens after the blur
