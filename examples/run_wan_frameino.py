@@ -20,22 +20,24 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def synthetic_conditions(frames, height, width, seed=0):
-    """Stand-ins for the app's inputs (SURVEY 8c harness rows): a canvas that is black outside the first-frame region,
-    two objects moving on straight lines (the second one entering the frame late = 'frame in'), one identity image."""
+def synthetic_conditions(frames, height, width, device, seed=0):
+    """Stand-ins for the app's inputs (SURVEY 8c harness rows), built the way app.py builds the real ones (:270-350,
+    :582-620, :634-695) with the device-side builders of frameino_amd.conditions: a first frame area-resampled into the
+    black unbounded canvas, clicked trajectories (one object entering the frame late = 'frame in') resampled by arc
+    length into per-frame tracks, an identity reference scaled and zero-padded to the canvas."""
     import PIL.Image
+    from frameino_amd.conditions import build_inference_canvas, prepare_id_tensor, tracks_from_trajectories
     rng = np.random.default_rng(seed)
-    canvas = np.zeros((height, width, 3), dtype=np.uint8)
-    y0, y1, x0, x1 = height // 8, height - height // 8, width // 6, width - width // 6
-    canvas[y0:y1, x0:x1] = rng.integers(0, 255, (y1 - y0, x1 - x0, 3), dtype=np.uint8)
-    tracks = []
-    for f in range(frames):
-        a = f / max(frames - 1, 1)
-        obj0 = [(int(x0 + 40 + a * (x1 - x0 - 80)) + dx, int(height * 0.5) + dy) for dx in (0, 12) for dy in (0, 12)]
-        obj1 = [(int(-60 + a * (width * 0.6)), int(height * 0.3))]           # starts outside the canvas
-        tracks.append([obj0, obj1])
-    ident = rng.integers(0, 255, (height, width, 3), dtype=np.uint8)
-    return PIL.Image.fromarray(canvas), tracks, ident
+    pad_h, pad_w = (height // 8) // 16 * 16, (width // 6) // 16 * 16
+    first = rng.integers(0, 255, (360, 640, 3), dtype=np.uint8)                  # the user's photo, any size
+    canvas = build_inference_canvas(first, height - 2 * pad_h, width - 2 * pad_w, pad_h, pad_w, pad_h, pad_w, device)
+    uh, uw = 480, 720                                                            # the UI board the user clicks on
+    clicks = [[[(uw * 0.25, uh * 0.5), (uw * 0.75, uh * 0.5)], [(uw * 0.27, uh * 0.52), (uw * 0.77, uh * 0.52)]],
+              [[(-20.0, uh * 0.3), (uw * 0.55, uh * 0.3)]]]                      # second object starts outside
+    tracks = tracks_from_trajectories(clicks, frames, height, width, uh, uw)
+    ident = rng.integers(0, 255, (300, 200, 3), dtype=np.uint8)                  # already-masked reference, portrait
+    id_tensor = prepare_id_tensor(ident, height, width, "Wan", device)           # [1, 3, 1, H, W] in [-1, 1]
+    return PIL.Image.fromarray(canvas.cpu().numpy()), tracks, id_tensor, (pad_h, pad_w, pad_h, pad_w)
 
 
 def main():
@@ -64,9 +66,20 @@ def main():
 
     tokenizer = text_encoder = None
     if a.ckpt:
-        from frameino_amd.loading import load_wan_transformer, load_wan_vae
+        from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan as _V
+        from frameino_amd.configs import WAN22_5B_CFG, WAN22_VAE_CFG
+        from frameino_amd.loading import config_report, load_scheduler, load_wan_transformer, load_wan_vae, read_config
+        from frameino_amd.transformer_wan import WanTransformer3DModel as _T
+        # the hyper-parameters this package assumes offline were written from memory: say, key by
+        # key, where the checkpoint disagrees -- the checkpoint wins, a surprise here is worth knowing before the clip
+        for sub, assumed, cls in (("transformer", WAN22_5B_CFG, _T), ("vae", WAN22_VAE_CFG, _V)):
+            for line in config_report(read_config(os.path.join(a.ckpt, sub)), assumed, cls, f"{sub}/config.json"):
+                print("[config]", line)
         transformer = load_wan_transformer(os.path.join(a.ckpt, "transformer"), torch.bfloat16, dev)
         vae = load_wan_vae(os.path.join(a.ckpt, "vae"), torch.bfloat16, dev)
+        if os.path.isfile(os.path.join(a.ckpt, "scheduler", "scheduler_config.json")):
+            sched = load_scheduler(os.path.join(a.ckpt, "scheduler"))
+            print("[config] scheduler from the checkpoint:", type(sched).__name__, dict(sched.config))
         if os.path.isdir(os.path.join(a.ckpt, "text_encoder")):
             from transformers import AutoTokenizer, UMT5EncoderModel
             tokenizer = AutoTokenizer.from_pretrained(os.path.join(a.ckpt, "tokenizer"))
@@ -94,10 +107,9 @@ def main():
 
     pipe = WanImageToVideoPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=sched,
                                    transformer=transformer, expand_timesteps=True)
-    canvas, tracks, ident = synthetic_conditions(a.frames, a.height, a.width)
     t0 = time.perf_counter()
+    canvas, tracks, id_tensor, pads = synthetic_conditions(a.frames, a.height, a.width, dev)
     traj = prepare_traj_tensor(tracks, a.height, a.width, 6, a.width, a.height, device=dev)        # [F, 3, H, W]
-    id_tensor = (torch.from_numpy(ident).to(dev).float() / 255.0 * 2.0 - 1.0).permute(2, 0, 1)[None, :, None]
     kw = {}
     if text_encoder is None:                                   # no text encoder offline: synthetic prompt embeddings
         g = torch.Generator().manual_seed(0)
@@ -122,6 +134,9 @@ def main():
               f"{a.scheduler}) {t2 - t1:.2f} s{' (cold)' if rep == 0 and a.repeat > 1 else ''}, "
               f"frames in [{frames.min():.3f}, {frames.max():.3f}], peak device memory "
               f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    from frameino_amd.conditions import crop_unpadded
+    region = crop_unpadded(frames, *pads)                      # app.py:741-748: the original (un-extended) region
+    print(f"cropped region {tuple(region.shape)} uint8")
     if a.out:
         np.save(a.out, frames)
 

@@ -38,6 +38,27 @@ def _accepted(cls, cfg):
     return {k: v for k, v in cfg.items() if k in params}
 
 
+def config_report(cfg, assumed, cls=None, name="config.json"):
+    """What a checkpoint's config.json says against the hyper-parameters this package ASSUMES offline (configs.py: the
+    released folders could not be read in the build environment) and against the constructor of the
+    mirror: -> list of human-readable lines, one per key that differs, is unknown to the mirror, or is missing from the
+    file.  The checkpoint always wins; the report is what a first run on real weights should print and eyeball."""
+    import inspect
+    lines = []
+    norm = lambda v: list(v) if isinstance(v, (list, tuple)) else v      # noqa: E731
+    for k in sorted(set(cfg) | set(assumed)):
+        if k in cfg and k in assumed and norm(cfg[k]) != norm(assumed[k]):
+            lines.append(f"{name}: {k} = {cfg[k]!r} (this package assumed {assumed[k]!r} offline)")
+        elif k in assumed and k not in cfg:
+            lines.append(f"{name}: {k} absent, constructor default / assumed value {assumed[k]!r} is used")
+    if cls is not None:
+        params = inspect.signature(cls.__init__).parameters
+        for k in sorted(cfg):
+            if k not in params:
+                lines.append(f"{name}: {k} = {cfg[k]!r} is not a parameter of {cls.__name__} and is ignored")
+    return lines
+
+
 def load_wan_transformer(path, torch_dtype=torch.bfloat16, device="cuda"):
     """WanTransformer3DModel.from_pretrained equivalent (fp32 islands of transformer_wan.py:393 are kept fp32)."""
     from .transformer_wan import WanTransformer3DModel
@@ -60,3 +81,26 @@ def load_cogvideox_transformer(path, torch_dtype=torch.bfloat16, device="cuda", 
     cfg = dict(read_config(path), **overrides)
     m = CogVideoXTransformer3DModel(**_accepted(CogVideoXTransformer3DModel, cfg)).to(device)
     return m.load_reference_state_dict(read_state_dict(path), dtype=torch_dtype).eval()
+
+
+def load_cogvideox_vae(path, torch_dtype=torch.bfloat16, device="cuda"):
+    """AutoencoderKLCogVideoX.from_pretrained equivalent (`<repo>/vae` of zai-org/CogVideoX-5b-I2V, app.py:150-151)."""
+    from .autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+    cfg = read_config(path)
+    vae = AutoencoderKLCogVideoX(**_accepted(AutoencoderKLCogVideoX, cfg)).to(device)
+    return vae.load_reference_state_dict(read_state_dict(path), dtype=torch_dtype)
+
+
+def load_scheduler(path):
+    """`<repo>/scheduler/scheduler_config.json` -> the matching sampler of frameino_amd.schedulers (by `_class_name`:
+    the released Wan2.2 folder names UniPCMultistepScheduler, CogVideoX-5b-I2V CogVideoXDPMScheduler /
+    CogVideoXDDIMScheduler; FlowMatchEulerDiscreteScheduler is what the reference's training configures)."""
+    from . import schedulers
+    with open(os.path.join(path, "scheduler_config.json")) as f:
+        cfg = json.load(f)
+    name = cfg.get("_class_name", "")
+    cls = getattr(schedulers, name, None)
+    if cls is None:
+        raise NotImplementedError(f"scheduler {name!r}: the built samplers are FlowMatchEulerDiscreteScheduler, "
+                                  f"UniPCMultistepScheduler, CogVideoXDDIMScheduler, CogVideoXDPMScheduler")
+    return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})

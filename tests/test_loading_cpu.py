@@ -43,3 +43,41 @@ def test_wan_vae_folder_roundtrip(tmp_path):
     save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "diffusion_pytorch_model.safetensors"))
     vae = loading.load_wan_vae(str(tmp_path), device="cpu")
     assert vae.config.z_dim == 4 and set(vae.state_dict()) == set(sd)
+
+
+def test_config_report_names_every_difference():
+    from frameino_amd.configs import WAN22_5B_CFG
+    from frameino_amd.loading import config_report
+    from frameino_amd.transformer_wan import WanTransformer3DModel
+    cfg = dict(WAN22_5B_CFG, ffn_dim=13824, patch_size=[1, 2, 2], pos_embed_seq_len=None, brand_new_key=3)
+    del cfg["rope_max_seq_len"]
+    lines = config_report(cfg, WAN22_5B_CFG, WanTransformer3DModel, "transformer/config.json")
+    text = "\n".join(lines)
+    assert "ffn_dim = 13824 (this package assumed 14336 offline)" in text
+    assert "rope_max_seq_len absent" in text and "brand_new_key = 3 is not a parameter" in text
+    assert "patch_size" not in text                      # list vs tuple is not a difference
+    assert config_report(dict(WAN22_5B_CFG), WAN22_5B_CFG, WanTransformer3DModel) == []
+
+
+def test_scheduler_and_cog_vae_folders(tmp_path):
+    from safetensors.torch import save_file
+    from frameino_amd import loading
+    from frameino_amd.schedulers import CogVideoXDPMScheduler, UniPCMultistepScheduler
+    from oracle import cog_vae as V
+    (tmp_path / "scheduler_config.json").write_text(json.dumps(
+        {"_class_name": "UniPCMultistepScheduler", "_diffusers_version": "0.35.0", "flow_shift": 5.0,
+         "prediction_type": "flow_prediction", "use_flow_sigmas": True, "solver_order": 2, "num_train_timesteps": 1000}))
+    assert isinstance(loading.load_scheduler(str(tmp_path)), UniPCMultistepScheduler)
+    (tmp_path / "scheduler_config.json").write_text(json.dumps(
+        {"_class_name": "CogVideoXDPMScheduler", "snr_shift_scale": 1.0, "timestep_spacing": "trailing",
+         "prediction_type": "v_prediction", "rescale_betas_zero_snr": True}))
+    assert isinstance(loading.load_scheduler(str(tmp_path)), CogVideoXDPMScheduler)
+    cfg = dict(V.COGVIDEOX_VAE_CFG, block_out_channels=[16, 32, 32, 64], norm_num_groups=8, latent_channels=4,
+               layers_per_block=2)
+    sd = V.cog_vae_random_state_dict(cfg, 3)
+    d = tmp_path / "vae"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(cfg, _class_name="AutoencoderKLCogVideoX", sample_height=480)))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    vae = loading.load_cogvideox_vae(str(d), device="cpu")
+    assert vae.config.latent_channels == 4 and set(vae.state_dict()) == set(sd)
