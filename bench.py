@@ -425,7 +425,9 @@ def main():
                     "traffic_note": "K/V of one head (6.3 MB) exceed an XCD's 4 MiB L2 and are partly re-fetched; the "
                                     "kernel is MFMA-bound (traffic / duration = 0.4 TB/s of 8)",
                     "launches": ks["launches"], "avg_us": ks["avg_us"],
-                    "flops_per_launch": total_fl / ks["launches"], "batch_per_launch": batch}
+                    "flops_per_launch": total_fl / ks["launches"], "batch_per_launch": batch,
+                    "launch_mix": "per batch-2 forward 29 launches cover both CFG branches; layer 0's (identical for "
+                                  "the branches) covers one: achieved = summed algorithmic FLOPs / summed durations"}
     cpu = None if a.no_cpu_baseline else cpu_baseline(cfg, L)
     print(result_line(elapsed, "single", extra, roofline, cpu, use_graph=a.graph), flush=True)
 
