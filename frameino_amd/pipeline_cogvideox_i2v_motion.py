@@ -14,7 +14,7 @@ class CogVideoXImageToVideoPipeline(_FrameINOPipeline):
     @torch.no_grad()
     def denoise(self, latents, image_latents, traj_latents, prompt_embeds, negative_prompt_embeds, guidance_scale=6.0,
                 num_inference_steps=50, use_dynamic_cfg=False, image_rotary_emb=None, attention_kwargs=None,
-                callback_on_step_end=None):
+                callback_on_step_end=None, generator=None):
         return super().denoise(latents, image_latents, traj_latents, None, prompt_embeds, negative_prompt_embeds,
                                guidance_scale, num_inference_steps, use_dynamic_cfg, image_rotary_emb,
-                               attention_kwargs, callback_on_step_end)
+                               attention_kwargs, callback_on_step_end, generator)

@@ -77,6 +77,7 @@ class CogVideoXImageToVideoPipeline:
         self.vae_scale_factor_temporal = 4
         self.vae_scaling_factor_image = getattr(getattr(vae, "config", None), "scaling_factor", 0.7)
         self._interrupt = False
+        self.use_hip_graph = False           # replay the step from a captured hipGraph (as the Wan pipeline)
 
     def enable_model_cpu_offload(self, *a, **k):
         return self
@@ -119,7 +120,6 @@ class CogVideoXImageToVideoPipeline:
             pad = torch.zeros_like(idl)
             img, trj = torch.cat([img, pad], dim=1), torch.cat([trj, pad], dim=1)              # :874-876
         nb = 2 if cfg_on else 1
-        cond = torch.cat([img, trj], dim=2).expand(nb, -1, -1, -1, -1)
         prompt = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dt) if cfg_on else prompt_embeds.to(dt)
         if image_rotary_emb is None:
             h = latents.shape[3] * self.vae_scale_factor_spatial
@@ -133,26 +133,60 @@ class CogVideoXImageToVideoPipeline:
         dpm = getattr(self.scheduler, "kind", "ddim") == "dpm"          # CogVideoXDPMScheduler branch (:915-926)
         sc = self.scheduler.coefs.to(dev)
         coefs = torch.cat([sc[:, :7], gcol, sc[:, 7:8]], 1) if dpm else torch.cat([sc, gcol], 1)
-        x0_old = torch.zeros(lat.shape, dtype=torch.float32, device=dev) if dpm else None
+
+        # Static buffers of the loop (what a captured step reads and writes).  The model input [nb, F(+1), 3C, h, w] =
+        # [noisy | first frame + 0 | trajectory + 0] on the channel axis, identity frame appended on the frame axis
+        # (:866-880): only the noisy C channels of the generated frames change from step to step, so everything else is
+        # written once here and each step copies `lat` into its slot (the reference re-concatenates all of it).
+        C = lat.shape[1]
+        nf_in = nlf + (0 if id_latent is None else id_latent.shape[1])
+        st = SimpleNamespace(lat=lat, nlf=nlf, C=C, cfg_on=cfg_on, dpm=dpm, prompt=prompt, rot=image_rotary_emb,
+                             attention_kwargs=attention_kwargs)
+        st.x = torch.zeros((nb, nf_in, 3 * C) + tuple(lat.shape[2:]), dtype=dt, device=dev)
+        if id_latent is not None:
+            st.x[:, nlf:, :C] = idl                                                             # :868 (img / trj pads stay 0)
+        st.x[:, :, C:2 * C] = img                              # (already zero-padded on the ID frame, :874-876)
+        st.x[:, :, 2 * C:] = trj
+        st.t = torch.zeros(nb, dtype=ts.dtype, device=dev)
+        st.coef = torch.zeros(coefs.shape[1], dtype=torch.float32, device=dev)
+        st.x0_old = torch.zeros(lat.shape, dtype=torch.float32, device=dev) if dpm else None
+        st.noise = torch.zeros_like(lat) if dpm else None
+        graph = None
         for i, t in enumerate(ts):
             if self._interrupt:
                 continue
-            x = lat[None].expand(nb, -1, -1, -1, -1)
-            if id_latent is not None:
-                x = torch.cat([x, idl.expand(nb, -1, -1, -1, -1)], dim=1)                       # :868
-            x = torch.cat([x, cond], dim=2).contiguous()                                       # :880
-            pred = tr(hidden_states=x, encoder_hidden_states=prompt, timestep=t.expand(nb),
-                      image_rotary_emb=image_rotary_emb, attention_kwargs=attention_kwargs, return_dict=False)[0]
+            st.t.copy_(t.expand(nb))                          # device-to-device: no host sync
+            st.coef.copy_(coefs[i])
             if dpm:
-                nz = self.scheduler.noise(i, lat.shape, generator, dev, dt)
-                ops.cfg_dpm_step_(lat, pred.contiguous(), x0_old, nz, coefs[i], has_uncond=cfg_on)
+                st.noise.copy_(self.scheduler.noise(i, lat.shape, generator, dev, dt))
+            if self.use_hip_graph and callback_on_step_end is None:
+                if graph is None:
+                    keep = [st.lat] + ([st.x0_old] if dpm else [])
+                    snap = [b.clone() for b in keep]
+                    self._step(st)                            # eager pass fills every lazy cache before the capture
+                    for b, sv in zip(keep, snap):
+                        b.copy_(sv)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._step(st)
+                graph.replay()
             else:
-                ops.cfg_vpred_step_(lat, pred.contiguous(), coefs[i], has_uncond=cfg_on)        # :896-927
+                self._step(st)
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": lat[None]})
                 if "latents" in out and out["latents"] is not None:
                     lat.copy_(out["latents"][0])
         return lat[None]
+
+    def _step(self, st):
+        """One denoise step on the static buffers `st` (no host sync, no data-dependent shapes: hipGraph-capturable)."""
+        st.x[:, :st.nlf, :st.C].copy_(st.lat)                                                   # broadcast over the CFG batch
+        pred = self.transformer(hidden_states=st.x, encoder_hidden_states=st.prompt, timestep=st.t,
+                                image_rotary_emb=st.rot, attention_kwargs=st.attention_kwargs, return_dict=False)[0]
+        if st.dpm:
+            ops.cfg_dpm_step_(st.lat, pred.contiguous(), st.x0_old, st.noise, st.coef, has_uncond=st.cfg_on)
+        else:
+            ops.cfg_vpred_step_(st.lat, pred.contiguous(), st.coef, has_uncond=st.cfg_on)       # :896-927
 
     # ---- condition encodes / decode around a user-supplied VAE (diffusers interface) ----
     def _need_vae(self):
