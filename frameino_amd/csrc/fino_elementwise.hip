@@ -19,13 +19,31 @@ struct RowRegs {
     float v[NP][8];
 };
 
-template <typename T, int NP>
+#ifndef FINO_EW_NT
+#define FINO_EW_NT 0          /* A/B build knob, ln_modulate_kernel: bit 0 non-temporal row loads, bit 1 non-temporal row stores.
+                                 Measured: stores alone 73 -> 51 us in isolation, and NOTHING on the step -- the
+                                 consumer GEMM then reads its A operand from HBM instead of the Infinity Cache.  Off. */
+#endif
+#define EW_STORE_NT(PTR_, VAL_)                                                                \
+    {                                                                                          \
+        const uint4 v__ = (VAL_);                                                              \
+        __builtin_nontemporal_store(u32x4_t{v__.x, v__.y, v__.z, v__.w}, reinterpret_cast<u32x4_t*>(PTR_)); \
+    }
+#define EW_STORE(PTR_, VAL_) (*reinterpret_cast<uint4*>(PTR_) = (VAL_))
+
+template <typename T, int NP, bool NT = false>
 __device__ __forceinline__ void load_row(const uint16_t* __restrict__ p, int dim, int lane, float (&v)[NP][8]) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c < dim) {
-            const uint4 u = *reinterpret_cast<const uint4*>(p + c);
+            uint4 u;
+            if constexpr (NT) {
+                const u32x4_t t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p + c));
+                u = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+            } else {
+                u = *reinterpret_cast<const uint4*>(p + c);
+            }
             unpack8<T>(u, v[i]);
         } else {
 #pragma unroll
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
     float v[NP][8];
-    load_row<T, NP>(x + row * ldx, dim, lane, v);
+    load_row<T, NP, (FINO_EW_NT & 1) != 0>(x + row * ldx, dim, lane, v);
     float mean, rstd;
     ln_stats<NP>(v, dim, lane, eps, mean, rstd);
     const int64_t moff = (MODE != 1 && sel) ? (int64_t)sel[row] * mod_stride : 0;
@@ -103,7 +121,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
                 o[j] = t;
             }
         }
-        *reinterpret_cast<uint4*>(y + row * ldy + c) = pack8<T>(o);
+        if constexpr ((FINO_EW_NT & 2) != 0) EW_STORE_NT(y + row * ldy + c, pack8<T>(o))
+        else EW_STORE(y + row * ldy + c, pack8<T>(o));
     }
 }
 
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint1
                 o[2 * j + 1] = x1 * ss[j] + x2 * cc[j];
             }
         }
-        *reinterpret_cast<uint4*>(x + row * ldx + c) = pack8<T>(o);
+        EW_STORE(x + row * ldx + c, pack8<T>(o));
     }
 }
 
