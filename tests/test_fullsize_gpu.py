@@ -138,3 +138,29 @@ def test_vae_decode_full_size_is_causal_in_time():
     assert full.shape == (1, 3, 17, 704, 1280) and head.shape == (1, 3, 5, 704, 1280)
     assert torch.isfinite(full).all()
     assert (full[:, :, :5] - head).abs().max().item() < 2e-2     # bf16 activations; identical taps, other tile order
+
+
+def test_vae_decode_full_size_chunked_tail_equals_whole_sequence():
+    """49 frames 704x1280: the whole-sequence decode addresses activation tensors of 5.6-11 GB (per-workgroup re-based
+    32-bit gather offsets in the conv kernel), the time-chunked tail never exceeds 2 GB per tensor -- both must give
+    the same bits (every output element sees the same taps in the same order), and the chunked schedule must stay under
+    half the memory."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=3, device=DEV)
+    z = torch.randn(1, 48, 13, 44, 80, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    with torch.no_grad():
+        vae.decode_chunk_frames = 8
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        chunked = vae.decode(z, return_dict=False)[0]
+        peak_chunked = torch.cuda.max_memory_allocated() - base
+        vae.decode_chunk_frames = 0
+        torch.cuda.reset_peak_memory_stats()
+        whole = vae.decode(z, return_dict=False)[0]
+        peak_whole = torch.cuda.max_memory_allocated() - base
+    assert whole.shape == (1, 3, 49, 704, 1280) and torch.isfinite(whole).all()
+    assert torch.equal(whole, chunked)
+    print(f"peak activation memory: whole {peak_whole / 2**30:.1f} GiB, chunked {peak_chunked / 2**30:.1f} GiB")
+    assert peak_chunked < 0.7 * peak_whole
