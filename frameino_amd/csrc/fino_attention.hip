@@ -774,12 +774,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
 }
 
 // Merge the key-range partials of each tail block: m = max m_s, O = sum O_s 2^(m_s-m), l likewise; store bf16.
+// grid = (8 * rem_x, D / 32): one workgroup per (tail block, 32-column d-tile) -- a block's 64 KB of fp32 partials per
+// piece are four independent column slices, so the few tail blocks (48 at the bench shape) become 4x the workgroups
+// (the single-slice form took 43 us per launch on 48 of 256 CUs).
 template <typename T, int D>
 __global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnParams p) {
     constexpr int kDT = D / 32;
     constexpr int NT = kWaves * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int xcd = blockIdx.x & 7, tb = blockIdx.x >> 3;
+    const int dt = blockIdx.y;
     const int bx = p.full_x + tb;
     const int hb = xcd + 8 * (bx / p.nqb);
     const int qb = bx % p.nqb;
@@ -795,30 +799,28 @@ __global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnPar
 #define PART_PTR(C_) (p.ws + (int64_t)(((xcd * p.nwg) + (C_)) * 2 + (tb - (int)(((int64_t)(C_) * p.per) / ntall))) * partial_floats<D>())
     float m = -INFINITY;
     for (int c = c_first; c <= c_last; ++c) m = fmaxf(m, PART_PTR(c)[kDT * 16 * NT + tid]);
-    float acc[kDT * 16];
+    float acc[16];
 #pragma unroll
-    for (int i = 0; i < kDT * 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float l = 0.f;
     for (int c = c_first; c <= c_last; ++c) {
         const float* w = PART_PTR(c);
         const float a = __builtin_amdgcn_exp2f(w[kDT * 16 * NT + tid] - m);
         l += a * w[kDT * 16 * NT + NT + tid];
 #pragma unroll
-        for (int i = 0; i < kDT * 16; ++i) acc[i] += a * w[i * NT + tid];
+        for (int i = 0; i < 16; ++i) acc[i] += a * w[(dt * 16 + i) * NT + tid];
     }
 #undef PART_PTR
     const float inv = 1.0f / l;
     uint16_t* orow = p.o + bi * p.o_bs + head * p.o_hs + (int64_t)qrow * p.o_rs;
 #pragma unroll
-    for (int dt = 0; dt < kDT; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = dt * 32 + 8 * g + 4 * h;
-            const float* a4 = acc + dt * 16 + 4 * g;
-            uint32_t x0 = (uint32_t)T::from_f32(a4[0] * inv) | ((uint32_t)T::from_f32(a4[1] * inv) << 16);
-            uint32_t x1 = (uint32_t)T::from_f32(a4[2] * inv) | ((uint32_t)T::from_f32(a4[3] * inv) << 16);
-            *reinterpret_cast<uint2*>(orow + d0) = make_uint2(x0, x1);
-        }
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        const float* a4 = acc + 4 * g;
+        uint32_t x0 = (uint32_t)T::from_f32(a4[0] * inv) | ((uint32_t)T::from_f32(a4[1] * inv) << 16);
+        uint32_t x1 = (uint32_t)T::from_f32(a4[2] * inv) | ((uint32_t)T::from_f32(a4[3] * inv) << 16);
+        *reinterpret_cast<uint2*>(orow + d0) = make_uint2(x0, x1);
+    }
 }
 
 // CU count of the current device (per-device cache; the tail-split plan and its workspace size depend on it)
@@ -890,7 +892,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
         attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     if (sp.rem_x > 0) {
-        attn_combine_kernel<T, D><<<dim3((unsigned)(8 * sp.rem_x)), kWaves * 64, 0, st>>>(p);
+        attn_combine_kernel<T, D><<<dim3((unsigned)(8 * sp.rem_x), (unsigned)(D / 32)), kWaves * 64, 0, st>>>(p);
         FINO_LAUNCH_CHECK();
     }
     return FINO_OK;
