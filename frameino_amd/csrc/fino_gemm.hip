@@ -12,6 +12,7 @@
 // A generic variant (register-staged, predicated, zero-filled) covers ragged K and is used for tiny shapes.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "fino_gemm_common.h"
@@ -301,18 +302,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 // taps that fall into the padding get an offset beyond the buffer resource's num_records, for which the hardware
 // writes zeros into LDS (no zero page, no branch).  The resource is re-based per workgroup to the first input frame
 // its rows can touch, so the offsets fit 32 bits on tensors of any size (fino_conv3d checks the per-tile span).
-template <typename T, int EPI, bool CONV = false>
-__global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The main loop of one output tile over K-tiles [kb, kb + nk): everything between the tile coordinates and the
+// accumulators (the whole-tile kernel passes kb = 0, nk = K / 64; the stream-K kernel a key... a K range).
+template <typename T, bool CONV>
+__device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, const int64_t m0, const int64_t n0,
+                                            const int kb, const int nk, f32x4_t (&acc)[8][4], const int tid,
+                                            const int lane, const int wave, const int wm, const int wn) {
     typedef typename T::vec8 vec8;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2;  // group
-    const int wn = wave & 3;
-    int tm, tn;
-    tile_coords(p, tm, tn);
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
     // ---- LDS-DMA pieces: 8 tile rows x 128 B per wave-instruction; swizzle on the source chunk ----
     // buffer_load_dwordx4 ... lds: the per-lane part of the address is ONE 32-bit byte offset per piece (row base +
@@ -398,25 +394,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
 #define PP_DMA_A(STAGE_, KT_, Q_)                                                                                 \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
         a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + (wm * 128 + (Q_) * 32 + wn * 8) * 128), 16,      \
-        a_off[Q_], CONV ? ck * (BK * 2) : (KT_) * (BK * 2), 0, 0);
+        a_off[Q_], CONV ? ck * (BK * 2) : (kb + (KT_)) * (BK * 2), 0, 0);
 #define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
     if (!CONV || (Q_) < w_pieces)                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
             w_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + kTileBytes + ((Q_) * 32 + wn * 8) * 128), 16, \
-            w_off[CONV ? 0 : (Q_)], (KT_) * (BK * 2) + (CONV ? (Q_) * w_piece_bytes : 0), 0, 0);
+            w_off[CONV ? 0 : (Q_)], (kb + (KT_)) * (BK * 2) + (CONV ? (Q_) * w_piece_bytes : 0), 0, 0);
 
     const int frow = lane & 15;
     const int pch0 = (lane >> 4) ^ (frow >> 1);
     const int a_base = (wm * 128 + frow) * 128;
     const int w_base = kTileBytes + (wn * 64 + frow) * 128;
 
-    f32x4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)(p.k / BK);
     // prologue: tiles 0 and 1 whole (each group its A half and half of W)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -503,7 +497,92 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef PP_DMA_A
 #undef PP_DMA_W
+}
+
+template <typename T, int EPI, bool CONV = false>
+__global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;  // group
+    const int wn = wave & 3;
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    f32x4_t acc[8][4];
+    pp_mainloop<T, CONV>(p, smem, m0, n0, 0, (int)(p.k / BK), acc, tid, lane, wave, wm, wn);
     gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
+}
+
+// ---- stream-K for the partial last round of tiles (long-K GEMMs) ----------------------------------------------------
+// With T tiles on C CUs the last round holds rem = T mod C tiles and lasts a whole tile time (FFN-down: 1164 tiles = 4.55
+// rounds, K = 14336: 270 us for 55 % of the CUs).  Here the first T - rem tiles run as whole tiles (gemm_pp_kernel on a
+// grid of T - rem), then the rem tail tiles' rem x nk K-tile units are dealt to up to C workgroups in equal contiguous
+// ranges of `per` units (a range touches at most two tiles since per < nk): every piece leaves its fp32 accumulators in a
+// caller-owned workspace in thread order (this kernel carries no epilogue: nothing but the main loop's registers), and
+// gemm_sk_combine_kernel sums a tile's 1-3 pieces and runs the normal epilogue.
+// Pays only for long K: the partials cost ~0.5 MB of traffic per tail tile whatever K is (profiles/r02_gemm_raster.md).
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void gemm_sk_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;
+    const int wn = wave & 3;
+    const int nk = (int)(p.k / BK);
+    f32x4_t acc[8][4];
+    const int w = (int)blockIdx.x;
+    const int64_t u0 = (int64_t)w * p.sk_per;
+    const int64_t uend = (int64_t)p.sk_rem * nk;
+    const int64_t u1 = u0 + p.sk_per < uend ? u0 + p.sk_per : uend;
+    const int t_first = (int)(u0 / nk);
+    const int npieces = (int)((u1 - 1) / nk) - t_first + 1;
+    for (int piece = 0; piece < npieces; ++piece) {
+        if (piece > 0) __syncthreads();                      // the previous piece's LDS stages are free
+        const int tl = t_first + piece;
+        const int64_t b0 = (int64_t)tl * nk;
+        const int kb = u0 > b0 ? (int)(u0 - b0) : 0;
+        const int ke = u1 - b0 < nk ? (int)(u1 - b0) : nk;
+        int tm, tn;
+        tile_raster(p, p.sk_full + tl, tm, tn);
+        pp_mainloop<T, false>(p, smem, (int64_t)tm * BM, (int64_t)tn * BN, kb, ke - kb, acc, tid, lane, wave, wm, wn);
+        f32x4_t* part = reinterpret_cast<f32x4_t*>(p.sk_ws) + ((int64_t)w * 2 + piece) * (32 * kThreads);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(i * 4 + j) * kThreads + tid] = acc[i][j];
+    }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(kThreads, 2) void gemm_sk_combine_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = (int)(p.k / BK);
+    const int tl = blockIdx.x;
+    const int c_first = (int)(((int64_t)tl * nk) / p.sk_per);
+    const int c_last = (int)((((int64_t)tl + 1) * nk - 1) / p.sk_per);
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int c = c_first; c <= c_last; ++c) {
+        const int piece = tl - (int)(((int64_t)c * p.sk_per) / nk);
+        const f32x4_t* part = reinterpret_cast<const f32x4_t*>(p.sk_ws) + ((int64_t)c * 2 + piece) * (32 * kThreads);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += part[(i * 4 + j) * kThreads + tid];
+    }
+    int tm, tn;
+    tile_raster(p, p.sk_full + tl, tm, tn);
+    gemm_epilogue<T, EPI>(acc, p, smem, (int64_t)tm * BM, (int64_t)tn * BN, tid, lane, wm, wn);
 }
 
 template <typename T, int EPI, bool GENERIC, bool CONV = false>
@@ -524,6 +603,56 @@ int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
+// Stream-K plan for the partial last round: worth it only when a tile is long (K >= 8192: the fp32 partials cost the same
+// ~0.5 MB per tail tile whatever K is) and the last round leaves most of the chip idle.  Measured (tools/gemm_sk_ab.py,
+// K = 14336): the tail kernel + combine cost ~130 us on top of the tail's share of a round (partials written and read
+// back, a second pipeline ramp in ranges that straddle two tiles), a round is ~350 us: M = 12320 (76 tail tiles, 30 % of
+// a round) 984 -> 884 us, M = 24640 (141 tail tiles, 55 %) 1713 -> 1721 us.  Hence: only when the tail fills <= 40 %.
+struct SkPlan { int full, rem, per, nwg; };
+inline SkPlan plan_stream_k(int tiles, int nk, int cus) {
+    SkPlan sp{tiles, 0, 1, 0};
+    const int rem = tiles % cus;
+    const int max_fill = fino_tune_get(FINO_TUNE_GEMM_STREAM_K) == 2 ? 90 : 40;          // 2 = A/B: split whenever legal
+    if (fino_tune_get(FINO_TUNE_GEMM_STREAM_K) == 1) return sp;                          // 1 = A/B: never
+    if (tiles < cus || rem == 0 || nk < 128 || rem * 100 > cus * max_fill) return sp;
+    const int64_t units = (int64_t)rem * nk;
+    const int per = (int)((units + cus - 1) / cus);
+    if (per >= nk || per < 8) return sp;
+    sp.full = tiles - rem;
+    sp.rem = rem;
+    sp.per = per;
+    sp.nwg = (int)((units + per - 1) / per);
+    return sp;
+}
+inline int gemm_device_cus() {
+    static std::atomic<int> cus[kFinoMaxDevices];
+    const int dev = fino_current_device();
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int n = 0;
+        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+constexpr int64_t kSkPartialBytes = (int64_t)32 * kThreads * 16;        // one piece: 256 x 256 fp32
+
+template <typename T, int EPI>
+int launch_gemm_sk(const GemmParams& p, hipStream_t st) {
+    static FinoPerDeviceOnce once_a, once_b, once_c;
+    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&gemm_sk_kernel<T>), kSmemBytes, "fino_gemm")) return rc;
+    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&gemm_sk_combine_kernel<T, EPI>), kSmemBytes, "fino_gemm")) return rc;
+    if (int rc = fino_max_smem_once(once_c, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, false>), kSmemBytes, "fino_gemm")) return rc;
+    // whole tiles: the ordinary kernel on the leading sk_full tiles of the raster (a multiple of the CU count)
+    gemm_pp_kernel<T, EPI, false><<<dim3((unsigned)p.sk_full), kThreads, kSmemBytes, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    gemm_sk_kernel<T><<<dim3((unsigned)p.sk_nwg), kThreads, kSmemBytes, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    gemm_sk_combine_kernel<T, EPI><<<dim3((unsigned)p.sk_rem), kThreads, kSmemBytes, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
 inline bool use_pingpong() {
     static int v = -1;
     if (v < 0) {
@@ -536,6 +665,15 @@ inline bool use_pingpong() {
 template <typename T, bool GENERIC>
 int launch_gemm_e(const GemmParams& p, int epi, hipStream_t st) {
     const bool fits32 = ((p.m - 1) * p.lda + p.k) * 2 < (1ll << 31) && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
+    if (!GENERIC && use_pingpong() && fits32 && p.sk_rem > 0) {
+        switch (epi) {
+            case FINO_EPI_NONE: return launch_gemm_sk<T, FINO_EPI_NONE>(p, st);
+            case FINO_EPI_GELU_TANH: return launch_gemm_sk<T, FINO_EPI_GELU_TANH>(p, st);
+            case FINO_EPI_RESIDUAL: return launch_gemm_sk<T, FINO_EPI_RESIDUAL>(p, st);
+            case FINO_EPI_GATED_RESIDUAL_STAGED: return launch_gemm_sk<T, FINO_EPI_GATED_RESIDUAL_STAGED>(p, st);
+            default: return launch_gemm_sk<T, FINO_EPI_GATED_RESIDUAL>(p, st);
+        }
+    }
     if (!GENERIC && use_pingpong() && fits32) {
         switch (epi) {
             case FINO_EPI_NONE: return launch_gemm_pp<T, FINO_EPI_NONE>(p, st);
@@ -596,9 +734,24 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 
 }  // namespace
 
+extern "C" int64_t fino_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0 || k % BK != 0) return 0;
+    const int tiles = (int)((m + BM - 1) / BM) * (int)((n + BN - 1) / BN);
+    const SkPlan sp = plan_stream_k(tiles, (int)(k / BK), gemm_device_cus());
+    return sp.rem > 0 ? (int64_t)sp.nwg * 2 * kSkPartialBytes : 0;
+}
+
 extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
                          int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
                          const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream) {
+    return fino_gemm_ws(a, w, bias, c, m, n, k, lda, ldw, ldc, epilogue, r, ldr, gate, mod_stride, sel, dtype, nullptr, 0,
+                        stream);
+}
+
+extern "C" int fino_gemm_ws(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
+                            int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
+                            const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm: dtype %d", dtype);
     FINO_CHECK(a && w && c, FINO_ERR_ARG, "fino_gemm: null pointer");
     FINO_CHECK(m >= 0 && n > 0 && k > 0, FINO_ERR_ARG, "fino_gemm: bad shape M=%lld N=%lld K=%lld", (long long)m,
@@ -626,6 +779,16 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
     if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
     hipStream_t st = (hipStream_t)stream;
     const bool generic = (k % BK) != 0;
+    if (workspace && !generic) {
+        FINO_CHECK(fino_aligned16(workspace), FINO_ERR_ARG, "fino_gemm_ws: workspace must be 16-byte aligned");
+        const SkPlan sp = plan_stream_k(p.tiles_m * p.tiles_n, (int)(k / BK), gemm_device_cus());
+        if (sp.rem > 0) {
+            const int64_t need = (int64_t)sp.nwg * 2 * kSkPartialBytes;
+            FINO_CHECK(workspace_bytes >= need, FINO_ERR_ARG, "fino_gemm_ws: workspace %lld B < %lld B",
+                       (long long)workspace_bytes, (long long)need);
+            p.sk_full = sp.full; p.sk_rem = sp.rem; p.sk_per = sp.per; p.sk_nwg = sp.nwg; p.sk_ws = (float*)workspace;
+        }
+    }
     if (dtype == FINO_BF16)
         return generic ? launch_gemm_e<BF16, true>(p, epilogue, st) : launch_gemm_e<BF16, false>(p, epilogue, st);
     return generic ? launch_gemm_e<F16, true>(p, epilogue, st) : launch_gemm_e<F16, false>(p, epilogue, st);

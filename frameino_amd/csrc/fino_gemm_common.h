@@ -22,6 +22,10 @@ struct GemmParams {
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
     int group_m;                     // tile rows per raster group (tile_coords); 0 = default
+    // stream-K over the partial last round (gemm_sk_kernel): the first sk_full tiles run whole, the K-tile units of the
+    // last sk_rem tiles are dealt in ranges of sk_per units; fp32 partials in sk_ws ([range][2 pieces][32][512] x 16 B)
+    int sk_full, sk_rem, sk_per, sk_nwg;
+    float* sk_ws;
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents
@@ -90,11 +94,13 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 // ================= device pieces shared by the bf16/fp16 kernels (fino_gemm.hip) and the MXFP8 kernel =================
 // ---- tile id -> (tm, tn): contiguous id range per XCD, 4-tile-high groups inside (operand reuse in that XCD's L2) ----
-__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int orig = blockIdx.x;
+// blocks b, b + 8, ... share an XCD: give each XCD a contiguous range of the `nwg` ids (bijective for any nwg)
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
-    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+}
+// linear raster id -> (tm, tn): groups of GROUP_M tile rows, column-major inside a group
+__device__ __forceinline__ void tile_raster(const GemmParams& p, int id, int& tm, int& tn) {
     const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
     const int group = id / (GROUP_M * p.tiles_n);
     const int first_m = group * GROUP_M;
@@ -102,6 +108,10 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
     const int in_group = id - group * GROUP_M * p.tiles_n;
     tm = first_m + in_group % gsz;
     tn = in_group / gsz;
+}
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
+    // (with a stream-K tail the grid holds only the sk_full leading tiles of the raster)
+    tile_raster(p, xcd_remap((int)blockIdx.x, p.sk_rem > 0 ? p.sk_full : p.tiles_m * p.tiles_n), tm, tn);
 }
 
 // Shared by both main-loop variants.  Every wave must be past its last LDS operand read (barrier) before the call.

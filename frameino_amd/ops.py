@@ -195,6 +195,20 @@ def attention(q, k, v, heads, out=None, scale=None):
     return out
 
 
+_gemm_ws = {}      # (device index, stream) -> fp32 workspace of the stream-K tail (caller-owned per the C ABI; grown on demand)
+
+
+def _gemm_workspace(m, n, k, device):
+    need = _lib.lib().fino_gemm_workspace_bytes(m, n, k)
+    if need <= 0:
+        return None, 0
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _gemm_ws[key] = torch.empty(need // 4, dtype=torch.float32, device=device)
+    return ws, need
+
+
 def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None):
     """C = epilogue(A.W^T + bias).  a [M, K] row-strided, w [N, K] (nn.Linear weight)."""
     a2, m, k, lda = _rows2d(a)
@@ -210,8 +224,9 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     if bias is not None:
         assert bias.dtype == a.dtype and bias.is_contiguous()
     ev = _timed("gemm")
-    _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
-                                   ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
+    ws, ws_bytes = _gemm_workspace(m, n, k, a.device)
+    _lib.check(_lib.lib().fino_gemm_ws(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
+                                      ldr, _p(gate), ms, _p(sel), _dt(a), _p(ws), ws_bytes, _stream()), "fino_gemm_ws")
     if ev is not None:
         ev.record()
         KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k

@@ -37,8 +37,9 @@ const char* fino_last_error(void);
 /* Tuning knobs for A/B timing of kernel variants inside one process (tools/): results never depend on them.
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
  * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
- * ping-pong one. */
-enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_COUNT = 8 };
+ * ping-pong one.  FINO_TUNE_GEMM_STREAM_K: 1 = never use the stream-K tail of fino_gemm_ws, 2 = whenever legal. */
+enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_STREAM_K = 3,
+       FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);
 int fino_tune_get(int key);
 
@@ -129,6 +130,17 @@ enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EP
 int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
               int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
+/* fino_gemm with a caller-owned fp32 workspace of fino_gemm_workspace_bytes(M, N, K) bytes (0 = not needed): for long K
+ * (>= 8192) a partial last round of 256x256 tiles that fills <= 40 % of the CUs is run stream-K -- its K-tile units dealt to
+ * all CUs in equal ranges, partial accumulators summed by a small further launch that also runs the epilogue.  Same
+ * results up to fp32 summation order in the split tiles.  (FFN-down of a Wan block on one CFG branch, nn.Linear
+ * 14336 -> 3072 at M = 12320: 588 tiles = 2.3 rounds of 256 CUs: 984 -> 884 us.) */
+int64_t fino_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int fino_gemm_ws(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k, int64_t lda,
+                 int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
+                 int64_t mod_stride, const int32_t* sel, int dtype, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
 
 /* Skinny fp32-accurate linear for the conditioning MLPs (M <= 16 rows):
  * y[m,n] = act( sum_k x[m,k] w[n,k] + b[n] ), x/y fp32, w/b fp32 (w_dtype=-1) or T; act: 0 none, 1 SiLU on the INPUT
