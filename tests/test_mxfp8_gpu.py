@@ -150,3 +150,34 @@ def test_gemm_mxfp8_random_shapes(case):
     out = ops.gemm_mxfp8(aq, sa, wq, sw, bias, epi, res, gate, sel)
     ref = gemm_ref(dequant(aq, sa, m, k).to(DEV), dequant(wq, sw, n, k).to(DEV), bias, epi, res, gate, sel)
     assert rel_rms(out, ref.float()) < 2.0 ** -7
+
+
+def test_token_sharded_branch_uses_the_mxfp8_projections():
+    """with `enable_mxfp8_linears()` the token-sharded forward must run its separate K|V and Q projections on
+    the MXFP8 path too (row blocks of the fused QKV weight, quantised on first use): same result as the unsharded MXFP8
+    forward, where the fused projection is one MXFP8 GEMM (MX scales are per output row, so the row blocks quantise
+    identically)."""
+    import torch.distributed as dist
+    from frameino_amd.configs import WAN22_5B_CFG
+    from frameino_amd.parallel import TokenShard
+    from frameino_amd.random_init import random_wan_model
+    cfg = dict(WAN22_5B_CFG, num_attention_heads=2, num_layers=2, ffn_dim=512, text_dim=128, in_channels=8,
+               out_channels=4)
+    m = random_wan_model(cfg, torch.device(DEV), seed=5).enable_mxfp8_linears()
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(1, 8, 3, 16, 16, device=DEV, generator=g).bfloat16()
+    txt = torch.randn(1, 32, 128, device=DEV, generator=g).bfloat16()
+    ts = torch.tensor([500.0], device=DEV)
+    base = m(hidden_states=x, timestep=ts, encoder_hidden_states=txt, return_dict=False)[0]
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+    try:
+        m.parallel = TokenShard(0, 1, None, force=True)
+        sharded = m(hidden_states=x, timestep=ts, encoder_hidden_states=txt, return_dict=False)[0]
+        assert (0, "kv") in m._fp8 and (0, "q") in m._fp8           # the sharded projections were quantised
+    finally:
+        m.parallel = None
+        if own_group:
+            dist.destroy_process_group()
+    assert rel_rms(sharded, base.float()) < 2e-3, rel_rms(sharded, base.float())
