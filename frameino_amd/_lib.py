@@ -36,6 +36,11 @@ SIGNATURES = {
     "fino_attn_fwd_ws": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 12 +
                         [c_float, c_int, c_void_p, c_i64, c_void_p],
     "fino_attn_workspace_bytes": [c_int, c_int, c_i64, c_i64, c_int],
+    "fino_attn_partial_bytes": [c_int, c_int, c_i64, c_int],
+    "fino_attn_partial": [c_void_p] * 3 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 9 + [c_float, c_int, c_void_p,
+                                                                                               c_i64, c_void_p],
+    "fino_attn_merge": [c_void_p, c_int, c_int, c_i64, c_int, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int,
+                        c_void_p],
     "fino_mxfp8_scale_bytes": [c_i64, c_i64],
     "fino_quantize_mxfp8": [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p],
     "fino_gemm_mxfp8": [c_void_p] * 6 + [c_i64] * 4 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
@@ -69,7 +74,8 @@ SIGNATURES = {
     "fino_vae_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
 }
 _RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64, "fino_mxfp8_scale_bytes": c_i64,
-             "fino_groupnorm_workspace_bytes": c_i64, "fino_gemm_workspace_bytes": c_i64}
+             "fino_groupnorm_workspace_bytes": c_i64, "fino_gemm_workspace_bytes": c_i64,
+             "fino_attn_partial_bytes": c_i64}
 
 
 def declared_symbols(header_path=HEADER_PATH):

@@ -62,6 +62,9 @@ struct AttnParams {
     // blocks form one stream that `nwg` workgroups cut into ranges of `per` tiles, leaving (O, m, l) partials in `ws`.
     int full_x, rem_x, nwg, per;
     float* ws;
+    // all_partial (fino_attn_partial): EVERY block leaves its (O, m, l) in ws[(head-batch * nqb + q-block)] instead of
+    // storing O -- attention over one key range of several, merged by fino_attn_merge
+    int all_partial;
 };
 
 // floats per partial: O^T accumulators in thread order + per-thread m and l
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     const int hb = xcd + 8 * (bx / p.nqb);
     const int qb = bx % p.nqb;
     if (hb >= p.batch * p.heads) continue;
+    if (p.all_partial) part = hb * p.nqb + qb;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
 
@@ -442,6 +446,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     const int hb = xcd + 8 * (bx / p.nqb);
     const int qb = bx % p.nqb;
     if (hb >= p.batch * p.heads) continue;
+    if (p.all_partial) part = hb * p.nqb + qb;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
 
@@ -823,6 +828,52 @@ __global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnPar
     }
 }
 
+// Merge the (O, m, l) partials that fino_attn_partial left for the SAME queries over disjoint key ranges (up to 3: the
+// token-sharded DiT attends to its own K/V chunk while the other ranks' chunks are still on the wire, then to what
+// arrived before / after it): m = max m_s, O = sum_s O_s 2^(m_s - m), l likewise, store O / l.
+struct MergeParams {
+    const float* part[3];
+    int n_parts;
+    uint16_t* o;
+    int batch, heads, lq, nqb;
+    int64_t o_bs, o_rs, o_hs;
+};
+template <typename T, int D>
+__global__ __launch_bounds__(kWaves * 64) void attn_merge_kernel(const MergeParams p) {
+    constexpr int kDT = D / 32;
+    constexpr int NT = kWaves * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int blk = blockIdx.x, dt = blockIdx.y;
+    const int hb = blk / p.nqb, qb = blk - hb * p.nqb;
+    const int bi = hb / p.heads, head = hb - bi * p.heads;
+    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
+    if (qrow >= p.lq) return;
+    float m = -INFINITY;
+    for (int s = 0; s < p.n_parts; ++s)
+        m = fmaxf(m, p.part[s][(int64_t)blk * partial_floats<D>() + kDT * 16 * NT + tid]);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float l = 0.f;
+    for (int s = 0; s < p.n_parts; ++s) {
+        const float* w = p.part[s] + (int64_t)blk * partial_floats<D>();
+        const float a = __builtin_amdgcn_exp2f(w[kDT * 16 * NT + tid] - m);
+        l += a * w[kDT * 16 * NT + NT + tid];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += a * w[(dt * 16 + i) * NT + tid];
+    }
+    const float inv = 1.0f / l;
+    uint16_t* orow = p.o + bi * p.o_bs + head * p.o_hs + (int64_t)qrow * p.o_rs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        const float* a4 = acc + 4 * g;
+        uint32_t x0 = (uint32_t)T::from_f32(a4[0] * inv) | ((uint32_t)T::from_f32(a4[1] * inv) << 16);
+        uint32_t x1 = (uint32_t)T::from_f32(a4[2] * inv) | ((uint32_t)T::from_f32(a4[3] * inv) << 16);
+        *reinterpret_cast<uint2*>(orow + d0) = make_uint2(x0, x1);
+    }
+}
+
 // CU count of the current device (per-device cache; the tail-split plan and its workspace size depend on it)
 int device_cus() {
     static std::atomic<int> cus[kFinoMaxDevices];
@@ -876,7 +927,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     const int hb = p.batch * p.heads;
     const int groups = (hb + 7) / 8;
     SplitPlan sp{groups * p.nqb, 0, 0, 1};
-    if (p.ws) {
+    if (p.ws && !p.all_partial) {
         sp = plan_split(p.batch, p.heads, p.nqb, (p.lk + kKV - 1) / kKV);
         const int64_t need = (int64_t)8 * sp.nwg * 2 * partial_floats<D>() * 4;
         if (sp.rem_x > 0 && need > ws_bytes) {
@@ -884,6 +935,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
             return FINO_ERR_ARG;
         }
     }
+    if (p.all_partial) sp = SplitPlan{groups * p.nqb, 0, 0, 1};       // no tail split: every block is a partial anyway
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
     if (pingpong)
@@ -912,12 +964,26 @@ extern "C" int64_t fino_attn_workspace_bytes(int batch, int heads, int64_t lq, i
     return (int64_t)8 * sp.nwg * 2 * pf * 4;
 }
 
-extern "C" int fino_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
-                                int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
-                                int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
-                                int64_t o_rs, int64_t o_hs, float scale, int dtype, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
+static int64_t attn_partial_bytes(int batch, int heads, int64_t lq, int head_dim) {
+    const int64_t pf = head_dim == 128 ? partial_floats<128>() : partial_floats<64>();
+    return (int64_t)batch * heads * ((lq + kQBlock - 1) / kQBlock) * pf * 4;
+}
+
+static int attn_common(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                       int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
+                       int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
+                       int64_t o_rs, int64_t o_hs, float scale, int dtype, void* workspace,
+                       int64_t workspace_bytes, int all_partial, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_fwd: dtype %d", dtype);
+    if (all_partial) {
+        static const uint16_t dummy_o[8] __attribute__((aligned(16))) = {0};
+        o = (void*)dummy_o;                                    // never written in this mode
+        o_bs = o_rs = o_hs = 0;
+        FINO_CHECK(head_dim == 128 || head_dim == 64, FINO_ERR_UNSUPPORTED, "fino_attn_partial: head_dim %d", head_dim);
+        FINO_CHECK(workspace && workspace_bytes >= attn_partial_bytes(batch, heads, lq, head_dim), FINO_ERR_ARG,
+                   "fino_attn_partial: workspace of %lld bytes needed",
+                   (long long)attn_partial_bytes(batch, heads, lq, head_dim));
+    }
     FINO_CHECK(q && k && v && o, FINO_ERR_ARG, "fino_attn_fwd: null pointer");
     FINO_CHECK(batch > 0 && heads > 0 && lq >= 0 && lk > 0, FINO_ERR_ARG,
                "fino_attn_fwd: bad shape B=%d H=%d Lq=%lld Lk=%lld", batch, heads, (long long)lq, (long long)lk);
@@ -945,12 +1011,63 @@ extern "C" int fino_attn_fwd_ws(const void* q, const void* k, const void* v, voi
     p.scale_log2 = scale * 1.4426950408889634f;
     p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
     p.ws = (workspace && workspace_bytes > 0) ? (float*)workspace : nullptr;
+    p.all_partial = all_partial;
     FINO_CHECK(((uintptr_t)workspace & 15) == 0, FINO_ERR_ARG, "fino_attn_fwd_ws: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int64_t wb = workspace_bytes;
     if (dtype == FINO_BF16)
         return head_dim == 128 ? launch_attn<BF16, 128>(p, wb, st) : launch_attn<BF16, 64>(p, wb, st);
     return head_dim == 128 ? launch_attn<F16, 128>(p, wb, st) : launch_attn<F16, 64>(p, wb, st);
+}
+
+extern "C" int fino_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                                int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
+                                int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
+                                int64_t o_rs, int64_t o_hs, float scale, int dtype, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    return attn_common(q, k, v, o, batch, heads, lq, lk, head_dim, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs,
+                       o_bs, o_rs, o_hs, scale, dtype, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int64_t fino_attn_partial_bytes(int batch, int heads, int64_t lq, int head_dim) {
+    if (batch <= 0 || heads <= 0 || lq <= 0 || (head_dim != 64 && head_dim != 128)) return 0;
+    return attn_partial_bytes(batch, heads, lq, head_dim);
+}
+
+extern "C" int fino_attn_partial(const void* q, const void* k, const void* v, int batch, int heads, int64_t lq, int64_t lk,
+                                 int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs,
+                                 int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, float scale, int dtype,
+                                 void* partial, int64_t partial_bytes, void* stream) {
+    return attn_common(q, k, v, nullptr, batch, heads, lq, lk, head_dim, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs,
+                       v_hs, 0, 0, 0, scale, dtype, partial, partial_bytes, 1, stream);
+}
+
+extern "C" int fino_attn_merge(void* o, int batch, int heads, int64_t lq, int head_dim, int64_t o_bs, int64_t o_rs,
+                               int64_t o_hs, const void* part0, const void* part1, const void* part2, int dtype,
+                               void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_merge: dtype %d", dtype);
+    FINO_CHECK(o && part0 && batch > 0 && heads > 0 && lq > 0 && (head_dim == 64 || head_dim == 128), FINO_ERR_ARG,
+               "fino_attn_merge: bad arguments");
+    FINO_CHECK(fino_aligned16(o) && o_rs % 8 == 0 && o_hs % 8 == 0 && o_bs % 8 == 0, FINO_ERR_ARG,
+               "fino_attn_merge: output must be 16-byte aligned");
+    MergeParams mp;
+    mp.part[0] = (const float*)part0; mp.part[1] = (const float*)part1; mp.part[2] = (const float*)part2;
+    mp.n_parts = part1 ? (part2 ? 3 : 2) : 1;
+    FINO_CHECK(part1 || !part2, FINO_ERR_ARG, "fino_attn_merge: part2 without part1");
+    mp.o = (uint16_t*)o; mp.batch = batch; mp.heads = heads; mp.lq = (int)lq;
+    mp.nqb = (int)((lq + kQBlock - 1) / kQBlock);
+    mp.o_bs = o_bs; mp.o_rs = o_rs; mp.o_hs = o_hs;
+    const dim3 grid((unsigned)(batch * heads * mp.nqb), (unsigned)(head_dim / 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16) {
+        if (head_dim == 128) attn_merge_kernel<BF16, 128><<<grid, kWaves * 64, 0, st>>>(mp);
+        else attn_merge_kernel<BF16, 64><<<grid, kWaves * 64, 0, st>>>(mp);
+    } else {
+        if (head_dim == 128) attn_merge_kernel<F16, 128><<<grid, kWaves * 64, 0, st>>>(mp);
+        else attn_merge_kernel<F16, 64><<<grid, kWaves * 64, 0, st>>>(mp);
+    }
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
 }
 
 extern "C" int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,

@@ -195,6 +195,40 @@ def attention(q, k, v, heads, out=None, scale=None):
     return out
 
 
+def attention_partial_floats(batch, heads, lq, head_dim):
+    return _lib.lib().fino_attn_partial_bytes(batch, heads, lq, head_dim) // 4
+
+
+def attention_partial(q, k, v, heads, out=None, scale=None):
+    """Attention of q [B, Lq, H*Dh] over ONE key range k/v [B, Lk, H*Dh]: -> fp32 partial buffer (unnormalised O, m, l per
+    (head, q-block)) for `attention_merge`."""
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
+    b, lq, hd = q.shape
+    lk = k.shape[1]
+    dh = hd // heads
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.is_cuda
+    need = _lib.lib().fino_attn_partial_bytes(b, heads, lq, dh)
+    if out is None or out.numel() * 4 < need:
+        out = torch.empty(need // 4, dtype=torch.float32, device=q.device)
+    scale = dh ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().fino_attn_partial(_p(q), _p(k), _p(v), b, heads, lq, lk, dh, q.stride(0), q.stride(1), dh,
+                                           k.stride(0), k.stride(1), dh, v.stride(0), v.stride(1), dh, float(scale),
+                                           _dt(q), _p(out), need, _stream()), "fino_attn_partial")
+    return out
+
+
+def attention_merge(parts, batch, lq, heads, head_dim, dtype, out=None):
+    """1..3 partials of `attention_partial` (same queries, disjoint key ranges) -> o [B, Lq, H*Dh]."""
+    assert 1 <= len(parts) <= 3
+    if out is None:
+        out = torch.empty((batch, lq, heads * head_dim), dtype=dtype, device=parts[0].device)
+    ps = list(parts) + [None] * (3 - len(parts))
+    _lib.check(_lib.lib().fino_attn_merge(_p(out), batch, heads, lq, head_dim, out.stride(0), out.stride(1), head_dim,
+                                         _p(ps[0]), _p(ps[1]), _p(ps[2]), _dt(out), _stream()), "fino_attn_merge")
+    return out
+
+
 _gemm_ws = {}      # (device index, stream) -> fp32 workspace of the stream-K tail (caller-owned per the C ABI; grown on demand)
 
 

@@ -8,6 +8,8 @@ The reference has no multi-GPU inference path; this is new des
   151 MB at L=12320) and one tiny all-gather of the projected output.  The all-gather is launched asynchronously right
   after the K|V projection so that it overlaps the Q projection.  xGMI is point-to-point (7 links/GPU): RCCL's
   all-gather over a fully connected in-node group uses all links of a GPU concurrently.
+  The self-attention itself is split to hide more of it: local keys first (needs nothing from the wire), then the
+  gathered keys before / after the own chunk, merged through (O, m, l) partials (`TokenShard.overlap_local`).
 * **CFG branches** -- the cond and uncond forwards of a step are independent; with an even number of ranks they run on
   two rank groups that exchange `noise_pred` once per step (no per-layer traffic).
 
@@ -31,6 +33,9 @@ class TokenShard:
         # with one shard -- how a single GPU exercises the RCCL call sequence (tests/test_parallel_gpu.py)
         self.rank, self.ways, self.group, self.force = rank, ways, group, force
         self._buf = {}
+        # attend to the LOCAL K/V chunk while the other ranks' chunks are still on the wire, then to what arrived, and
+        # merge the partials (fino_attn_partial / fino_attn_merge): hides up to 1/ways of the attention under the gather.
+        self.overlap_local = True
 
     @property
     def active(self):
@@ -53,6 +58,12 @@ class TokenShard:
 
     def kv_local(self, lpad, width, dtype, dev):
         return self._get("kv_loc", (lpad, width), dtype, dev)
+
+    def partial_buf(self, i, floats, dev):
+        """fp32 partial buffer number i of the local-first attention (None on CPU: the stand-in ops allocate)"""
+        if torch.device(dev).type != "cuda":
+            return None
+        return self._get(f"part{i}", (floats,), torch.float32, dev)
 
     def out_local(self, lpad, width, dtype, dev):
         return self._get("out_loc", (lpad, width), dtype, dev)

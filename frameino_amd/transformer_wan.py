@@ -472,10 +472,26 @@ class WanTransformer3DModel(nn.Module):
                 kv_all, work = sh.all_gather_kv(kv_loc)
                 self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
                 o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
-                if work is not None:
-                    work.wait()
-                kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
-                o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
+                if getattr(sh, "overlap_local", False):
+                    # local keys first -- nothing of it waits for the wire -- then what the gather delivered before /
+                    # after the own chunk; the (O, m, l) partials are merged (same softmax up to fp32 summation order)
+                    qv = q2.view(1, n, d)
+                    pf = o.attention_partial_floats(1, heads, n, dh) if hasattr(o, "attention_partial_floats") else 0
+                    parts = [o.attention_partial(qv, kv_loc[:n, :d][None], kv_loc[:n, d:][None], heads,
+                                                 out=sh.partial_buf(0, pf, dev))]
+                    if work is not None:
+                        work.wait()
+                    kv3 = kv_all.view(1, -1, 2 * d)
+                    for pi, (k0, k1) in enumerate(((0, lo), (lo + lpad, L))):
+                        if k1 > k0:
+                            parts.append(o.attention_partial(qv, kv3[:, k0:k1, :d], kv3[:, k0:k1, d:], heads,
+                                                             out=sh.partial_buf(1 + pi, pf, dev)))
+                    o.attention_merge(parts, 1, n, heads, dh, dt, out=att.view(1, n, d))
+                else:
+                    if work is not None:
+                        work.wait()
+                    kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
+                    o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
             if default_procs and not once:
                 self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x, gate=m[:, 2], sel=sel, out=x)

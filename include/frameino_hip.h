@@ -100,6 +100,19 @@ int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batc
                   int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs,
                   int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs,
                   int64_t o_hs, float scale, int dtype, void* stream);
+/* Attention over ONE key range of several, for the same queries: fino_attn_partial leaves every (head, 256-row
+ * q-block)'s unnormalised O, running max m and sum l in `partial` (fp32, fino_attn_partial_bytes(B, H, Lq, Dh) bytes)
+ * instead of storing O; fino_attn_merge combines up to three such partials (disjoint key ranges) into O.  Lets the
+ * token-sharded DiT attend to its own K/V chunk while the other ranks' chunks are still arriving (frameino_amd/parallel.py):
+ * softmax(q.[K_a; K_b]^T).[V_a; V_b] = merge(partial(K_a, V_a), partial(K_b, V_b)) up to fp32 summation order. */
+int64_t fino_attn_partial_bytes(int batch, int heads, int64_t lq, int head_dim);
+int fino_attn_partial(const void* q, const void* k, const void* v, int batch, int heads, int64_t lq, int64_t lk,
+                      int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                      int64_t v_bs, int64_t v_rs, int64_t v_hs, float scale, int dtype, void* partial,
+                      int64_t partial_bytes, void* stream);
+int fino_attn_merge(void* o, int batch, int heads, int64_t lq, int head_dim, int64_t o_bs, int64_t o_rs, int64_t o_hs,
+                    const void* part0, const void* part1, const void* part2, int dtype, void* stream);
+
 
 /* Same product with a caller-owned workspace that enables the TAIL SPLIT: one workgroup (256 query rows of one
  * head) occupies a CU, so an XCD's 32 CUs take its blocks in rounds; when the last round holds fewer blocks than

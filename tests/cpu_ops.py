@@ -61,6 +61,25 @@ def attention(q, k, v, heads, out=None, scale=None):
     return o if out is None else out.copy_(o)
 
 
+def attention_partial(q, k, v, heads, out=None, scale=None):
+    """(unnormalised O, row max m, row sum l) of attention over one key range (contract of fino_attn_partial)"""
+    b, lq, hd = q.shape
+    dh = hd // heads
+    f = lambda t: t.reshape(b, -1, heads, dh).transpose(1, 2).float()      # noqa: E731
+    s_ = f(q) @ f(k).transpose(2, 3) * (dh ** -0.5 if scale is None else scale)
+    m = s_.amax(dim=-1, keepdim=True)
+    p_ = torch.exp(s_ - m)
+    return p_ @ f(v), m, p_.sum(dim=-1, keepdim=True)
+
+
+def attention_merge(parts, batch, lq, heads, head_dim, dtype, out=None):
+    m = torch.stack([p[1] for p in parts]).amax(dim=0)
+    num = sum(p[0] * torch.exp(p[1] - m) for p in parts)
+    den = sum(p[2] * torch.exp(p[1] - m) for p in parts)
+    o = (num / den).transpose(1, 2).reshape(batch, lq, heads * head_dim).to(dtype)
+    return o if out is None else out.copy_(o)
+
+
 def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None):
     y = F.linear(a, w, bias)
     if epilogue == EPI_GELU_TANH:

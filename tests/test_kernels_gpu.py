@@ -407,3 +407,25 @@ def test_cfg_unipc_step(dtype, has_uncond):
         torch.testing.assert_close(b1.cpu(), m0, atol=0, rtol=0)
         torch.testing.assert_close(bl.cpu(), xc, atol=2e-6, rtol=2e-6)
         torch.testing.assert_close(bx.cpu(), xn, atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("heads,dh,lq,splits", [(2, 128, 300, (0, 64, 500)), (3, 64, 77, (0, 200, 201, 650)),
+                                                (24, 128, 3080, (0, 3080, 6160))])
+def test_attention_partials_over_key_ranges_merge_to_the_full_attention(heads, dh, lq, splits):
+    """fino_attn_partial + fino_attn_merge: attention over 1-3 disjoint key ranges merged through (O, m, l) equals the
+    single pass over all keys up to fp32 summation order (what the token-sharded forward does with its own K/V chunk
+    and the gathered ones)."""
+    from frameino_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(17)
+    d = heads * dh
+    lk = splits[-1]
+    q = torch.randn(2, lq, d, device=DEV, generator=g).bfloat16()
+    kv = (torch.randn(2, lk, 2 * d, device=DEV, generator=g) * 1.5).bfloat16()
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    full = ops.attention(q, k, v, heads)
+    parts = [ops.attention_partial(q, k[:, a:b], v[:, a:b], heads) for a, b in zip(splits[:-1], splits[1:])]
+    merged = ops.attention_merge(parts, 2, lq, heads, dh, q.dtype)
+    assert torch.isfinite(merged.float()).all()
+    assert rel_rms(merged, full.float()) < 2.0 ** -8, rel_rms(merged, full.float())
+    one = ops.attention_merge([ops.attention_partial(q, k, v, heads)], 2, lq, heads, dh, q.dtype)
+    assert rel_rms(one, full.float()) < 2.0 ** -9

@@ -73,7 +73,8 @@ def test_two_rank_plans_match_single_process(cfg_parallel, desc):
         assert p.exitcode == 0
     for rank, d, out in outs:
         assert d == desc
-        torch.testing.assert_close(out, single, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)   # fp32; the local-first attention merges
+        # (O, m, l) partials of two or three key ranges: another summation order than the single softmax pass
 
 
 @pytest.mark.parametrize("mode,desc", [("split", "cfg2xtoken2"), ("interleave", "token4x2branches-interleaved")])
@@ -93,7 +94,8 @@ def test_four_rank_plans_match_single_process(mode, desc):
         assert p.exitcode == 0
     for rank, d, out in outs:
         assert d == desc
-        torch.testing.assert_close(out, single, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)   # fp32; the local-first attention merges
+        # (O, m, l) partials of two or three key ranges: another summation order than the single softmax pass
 
 
 def test_token_shard_rows_cover_sequence_with_padding():
