@@ -323,7 +323,8 @@ def main():
 
         def line_for(el, plan):
             return result_line(el, plan.desc, {"rccl_ranks": world, "backend": backend, "plan_probe_ms_per_step": probe,
-                                               "kv_allgather_us_per_layer_call": gather_us.get(plan.desc)})
+                                               "kv_allgather_us_per_layer_call": gather_us.get(plan.desc),
+                                               "local_first_attention": bool(plan.shard.overlap_local)})
 
         best = (elapsed, first)
         line = line_for(*best)

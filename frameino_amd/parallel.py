@@ -35,7 +35,10 @@ class TokenShard:
         self._buf = {}
         # attend to the LOCAL K/V chunk while the other ranks' chunks are still on the wire, then to what arrived, and
         # merge the partials (fino_attn_partial / fino_attn_merge): hides up to 1/ways of the attention under the gather.
-        self.overlap_local = True
+
+    # attend to the own K/V chunk while the gather is in flight and merge (O, m, l) partials; False = one attention
+    # launch over the gathered keys after the wait (bit-identical arithmetic to the unsharded forward)
+    overlap_local = True
 
     @property
     def active(self):

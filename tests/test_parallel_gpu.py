@@ -33,11 +33,13 @@ def _run(pipe, a, dev):
                         d("prompt_embeds"), d("negative_embeds"), float(a["guidance"]), int(a["steps"]))
 
 
-def _worker(rank, world, port, cfg_parallel, q, mode="split"):
+def _worker(rank, world, port, cfg_parallel, q, mode="split", overlap_local=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from frameino_amd import parallel
         from frameino_amd.parallel import shard_pipeline
+        parallel.TokenShard.overlap_local = overlap_local
         pipe, a = _pipe("cuda:0")
         plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode)
         out = _run(pipe, a, "cuda:0")
@@ -52,9 +54,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("cfg_parallel,desc", [(True, "cfg2xtoken1"), (False, "cfg1xtoken2"),
-                                               ("interleave", "token2x2branches-interleaved")])
-def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc):
+@pytest.mark.parametrize("cfg_parallel,desc,overlap_local",
+                         [(True, "cfg2xtoken1", True), (False, "cfg1xtoken2", False), (False, "cfg1xtoken2", True),
+                          ("interleave", "token2x2branches-interleaved", False),
+                          ("interleave", "token2x2branches-interleaved", True)])
+def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc, overlap_local):
     pipe, a = _pipe("cuda:0")
     pipe.batch_cfg = False                                     # two batch-1 forwards, as each rank group runs them
     single = _run(pipe, a, "cuda:0").cpu()
@@ -64,17 +68,28 @@ def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc):
     q = ctx.Queue()
     port = _free_port()
     mode = "interleave" if cfg_parallel == "interleave" else "split"
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_parallel is True, q, mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_parallel is True, q, mode, overlap_local))
+             for r in range(2)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=600) for _ in range(2)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    golden = a["out_latents"]
+    e_single = rel_rms(single, golden)
     for rank, d, out in outs:
         assert d == desc
-        # same kernels on the same rows; the sharded attention splits its blocks differently (fp32 summation order)
-        assert rel_rms(out, single) < 5e-3, (rank, rel_rms(out, single))
+        if cfg_parallel is True or not overlap_local:
+            # one attention launch over the gathered keys: same kernels on the same rows as the unsharded forward
+            assert rel_rms(out, single) < 5e-3, (rank, rel_rms(out, single))
+        else:
+            # local-first: the softmax is taken per key range against that range's running max and merged, so P is
+            # rounded to bf16 at other points than in the single pass.  Each attention is as close to fp32 as the single
+            # pass (tests/test_kernels_gpu.py); through 4 sampler steps of the random tiny model the two bf16 runs
+            # drift apart like any two bf16 runs do, so the bar is the fp32 oracle's golden, as for the unsharded loop
+            e = rel_rms(out, golden)
+            assert e < 5e-2 and e < 2.0 * e_single + 5e-3, (rank, e, e_single)
     assert torch.equal(outs[0][2], outs[1][2])                # every rank holds the same latents
 
 
