@@ -511,7 +511,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     tile_coords(p, tm, tn);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     f32x4_t acc[8][4];
-    pp_mainloop<T, CONV>(p, smem, m0, n0, 0, (int)(p.k / BK), acc, tid, lane, wave, wm, wn);
+    int nk = (int)(p.k / BK);
+#ifdef FINO_GEMM_DESYNC_EXP
+    // TIMING EXPERIMENT ONLY (wrong results): the first round's tiles stop after 1/8 .. 8/8 of K, so that the CUs leave
+    // lock step and the epilogue bursts of later rounds are spread in time
+    if (blockIdx.x < 256) nk = nk * (int)((blockIdx.x >> 3) % 8 + 1) / 8;
+#endif
+    pp_mainloop<T, CONV>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn);
     gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
