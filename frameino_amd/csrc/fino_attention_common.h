@@ -1,0 +1,66 @@
+// Shared by the attention kernels (fino_attention.hip: 8-wave ping-pong / one-barrier loops, partials, merge;
+// fino_attention_w4.hip: 4-wave, one wave per SIMD).
+#pragma once
+#include "fino_common.h"
+
+#define FINO_ATTN_WAVES 8      // waves per workgroup (4 waves x 2 workgroups per CU measured slower: 853 vs 935 TFLOP/s)
+
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+namespace fino_attn_ns {
+
+struct AttnParams {
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* v;
+    uint16_t* o;
+    int batch, heads;
+    int lq, lk;
+    int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
+    float scale_log2;
+    int nqb;  // q blocks per head
+    // tail split (see plan_split): per XCD the first `full_x` blocks run whole; the key tiles of the remaining `rem_x`
+    // blocks form one stream that `nwg` workgroups cut into ranges of `per` tiles, leaving (O, m, l) partials in `ws`.
+    int full_x, rem_x, nwg, per;
+    float* ws;
+    // all_partial (fino_attn_partial): EVERY block leaves its (O, m, l) in ws[(head-batch * nqb + q-block)] instead of
+    // storing O -- attention over one key range of several, merged by fino_attn_merge
+    int all_partial;
+};
+
+// floats per partial: O^T accumulators in thread order + per-thread m and l
+template <int D>
+constexpr int64_t partial_floats() { return (int64_t)(D / 32) * 16 * (FINO_ATTN_WAVES * 64) + 2 * (FINO_ATTN_WAVES * 64); }
+
+constexpr int kQRowsPerWave = 32;
+constexpr int kWaves = FINO_ATTN_WAVES;   // waves (32 query rows each) per workgroup
+constexpr int kQBlock = kQRowsPerWave * kWaves;  // 256
+constexpr int kKV = 64;
+constexpr float kRescaleThr = 8.0f;  // log2 units: P <= 256 between rescales
+
+// Byte offset of 16-byte chunk `ch` of row `row` inside a [kKV][D] tile.
+//  D=128 (256-B rows): ch ^ (((row&3)<<2) | ((row>>2)&3))
+//  D=64  (128-B rows): ch ^ (((row&3)<<1) | ((row>>2)&1))       (8 chunks per row)
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int ch) {
+    if constexpr (D == 128) {
+        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    } else {
+        return row * 128 + ((ch ^ (((row & 3) << 1) | ((row >> 2) & 1))) << 4);
+    }
+}
+
+
+}  // namespace fino_attn_ns
+
+// 4-wave kernel (head_dim 128, whole blocks, no partials): defined in fino_attention_w4.hip
+int fino_attn_launch_w4(const fino_attn_ns::AttnParams& p, int dtype, hipStream_t st);

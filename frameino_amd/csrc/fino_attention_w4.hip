@@ -1,0 +1,477 @@
+// Non-causal flash attention forward, head_dim 128: 4 waves per workgroup, ONE wave per SIMD with the whole
+// 512-register file (the "4-wave, one-wave-per-SIMD" structure of the gfx950 playbook, written for this path).
+// Same operator as fino_attention.hip (F.scaled_dot_product_attention at architecture/transformer_wan.py:108 of the
+// reference); same S^T = K.Q^T / O^T = V^T.P^T register layouts, same swizzled LDS tile image.
+//
+//   * workgroup = 4 waves = 256 query rows of one (batch, head); a wave owns 64 rows = two 32-row sub-blocks, so every
+//     K / V^T fragment read from LDS feeds two MFMAs (half the LDS traffic per FLOP of the 8-wave kernel).
+//   * K/V tiles of 64 keys arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, swizzle applied on the
+//     source chunk, rows past the last key zero-filled by the buffer range check) into 2 + 2 ring slots; ONE barrier per
+//     tile.
+//   * The wave software-pipelines itself: per tile two phases of 32 MFMAs,
+//       phase 1: S(t+1) = K(t+1).Q^T   ||  exp2 of the second sub-block of S(t), bf16 packing of P(t)
+//       phase 2: O^T += V(t)^T.P(t)^T  ||  row max of S(t+1), exp2 of its first sub-block
+//     with the vector work cut into slices that follow each MFMA in program order (a wave issues in order: the
+//     placement is the schedule).
+#include "fino_attention_common.h"
+using namespace fino_attn_ns;
+#include "fino_attention_w4_regs.h"
+
+#ifdef FINO_ATTN_STAMP
+__device__ unsigned long long fino_attn_w4_dbg[64];
+extern "C" int fino_attn_w4_debug_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_attn_w4_dbg), sizeof(unsigned long long) * 64);
+}
+#define W4_STAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define W4_STAMP(V_)
+#endif
+
+namespace {
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kW4Waves = 4;
+constexpr int kW4Threads = kW4Waves * 64;
+constexpr int kW4D = 128;
+constexpr int kW4TileBytes = kKV * kW4D * 2;     // 16 KiB
+constexpr int kW4Smem = 4 * kW4TileBytes;        // K ring (2) + V ring (2)
+
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+#define W4_LDS_PTR(TYPE_, ADDR_) ((FINO_LDS TYPE_*)(uintptr_t)(uint32_t)(ADDR_))
+
+// The MFMAs go through inline asm so that the register FILE of every operand is this file's decision: O^T (128
+// registers) and the Q fragments (64) live in AGPRs for the whole kernel, S / P / the LDS fragments in VGPRs.  Left to
+// the allocator (builtins), the 450 live registers are shuffled between the two files in bulk (1300 v_accvgpr moves
+// per two tiles, spills).  The asm hides the MFMA from the hazard recogniser: consumers of S sit a phase behind its
+// MFMAs by construction, and the places where O is touched by vector code are padded with explicit s_nop.
+// This file is compiled with -fno-honor-nans (Makefile): fmaxf then needs no canonicalising v_max of its inputs and
+// fuses to v_max3_f32 by itself (the asm helpers of the 8-wave kernel make the compiler pad every one with an s_nop).
+__device__ __forceinline__ float fmx(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float fmx3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+template <typename T>
+__device__ __forceinline__ uint32_t w4_pack2(float a, float b) {
+    typedef typename T::scalar sc2 __attribute__((ext_vector_type(2)));
+    const sc2 v = {(typename T::scalar)a, (typename T::scalar)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <typename T>
+__device__ __forceinline__ void w4_mfma_qk0(f32x16_t& d, const u32x4_t& a, const u32x4_t& bq) {
+    if constexpr (T::kId == FINO_BF16)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));
+}
+template <typename T>
+__device__ __forceinline__ void w4_mfma_qk(f32x16_t& d, const u32x4_t& a, const u32x4_t& bq) {
+    if constexpr (T::kId == FINO_BF16)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(bq));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(bq));
+}
+
+
+template <typename T, int VAR>
+__global__ __attribute__((amdgpu_flat_work_group_size(kW4Threads, kW4Threads), amdgpu_waves_per_eu(1, 1)))
+void attn_w4_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = kW4D;
+    constexpr int kKS = D / 16;   // 8 k-steps of QK^T
+    constexpr int kDT = D / 32;   // 4 d-tiles of O^T
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware block -> (head-batch, q-block): all q-blocks of a head share blockIdx % 8
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int hb = xcd + 8 * (slot / p.nqb);
+    const int qb = slot % p.nqb;
+    if (hb >= p.batch * p.heads) return;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    const int lk = p.lk;
+    const int nt = (lk + kKV - 1) / kKV;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[row][16*ks + 8h .. +7] of both sub-blocks ----
+    int qrow[2];
+    u32x4_t qf[2][kKS];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        qrow[qs] = qb * kQBlock + wave * 64 + qs * 32 + r;
+        const int qc = qrow[qs] < p.lq ? qrow[qs] : p.lq - 1;
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+            const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qc * p.q_rs + 16 * ks + 8 * h);
+            qf[qs][ks] = u32x4_t{u.x, u.y, u.z, u.w};
+        }
+    }
+
+    // ---- LDS-DMA pieces: wave w moves rows 16w .. 16w+15 of a tile as 4 pieces of 4 rows (1 KiB each) ----
+    // lane l of piece P = 4w + j lands at row 4P + (l >> 4), physical chunk l & 15; it fetches the logical chunk
+    // (l & 15) ^ swz(row), swz(row) = ((row & 3) << 2) | ((row >> 2) & 3) = (((l >> 4) & 3) << 2) | (j & 3).
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)kp, 0, (int)((((int64_t)lk - 1) * p.k_rs + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)vp, 0, (int)((((int64_t)lk - 1) * p.v_rs + D) * 2), 0x00020000);
+    uint32_t kvo[4], vvo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * wave + 4 * j + (lane >> 4);
+        const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | j);
+        kvo[j] = (uint32_t)((row * p.k_rs + ch * 8) * 2);
+        vvo[j] = (uint32_t)((row * p.v_rs + ch * 8) * 2);
+    }
+    const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
+    // K(t) -> slot t & 1 (bytes 0 / 16 K), V(t) -> slot 2 + (t & 1)
+#define W4_DMA_K(T_)                                                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) __builtin_amdgcn_raw_ptr_buffer_load_lds(                 \
+        k_rsrc, (FINO_LDS void*)(smem + ((T_) & 1) * kW4TileBytes + (4 * wave + j_) * 1024), 16, kvo[j_],      \
+        (T_) * k_tile_bytes, 0, 0);
+#define W4_DMA_K1(T_, SLOT_, J_)                                                                               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
+        k_rsrc, (FINO_LDS void*)(smem + (SLOT_) * kW4TileBytes + (4 * wave + (J_)) * 1024), 16, kvo[J_],       \
+        (T_) * k_tile_bytes, 0, 0);
+#define W4_DMA_V1(T_, SLOT_, J_)                                                                               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
+        v_rsrc, (FINO_LDS void*)(smem + (2 + (SLOT_)) * kW4TileBytes + (4 * wave + (J_)) * 1024), 16, vvo[J_], \
+        (T_) * v_tile_bytes, 0, 0);
+#define W4_DMA_V(T_)                                                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) __builtin_amdgcn_raw_ptr_buffer_load_lds(                 \
+        v_rsrc, (FINO_LDS void*)(smem + (2 + ((T_) & 1)) * kW4TileBytes + (4 * wave + j_) * 1024), 16, vvo[j_], \
+        (T_) * v_tile_bytes, 0, 0);
+
+    // ---- per-lane LDS fragment addresses (raw: the dynamic segment is the kernel's only LDS and starts at 0) ----
+    if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
+    const int tq = (lane & 15) >> 2;
+    const int tp = lane & 3;
+    const int g1 = (lane >> 4) & 1;
+    const uint32_t ka_base = lds_off<D>(r, h);
+    const uint32_t vl_base = 2 * kW4TileBytes + lds_off<D>(4 * h + tq, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+    const uint32_t vh_base = 2 * kW4TileBytes + lds_off<D>(4 * h + tq + 8, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+
+    w4_o_zero();                   // O^T: a128..a255, touched only through fino_attention_w4_regs.h
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+    const float c2 = p.scale_log2;
+
+    // row max of 8 accumulator registers
+#define W4_MAX8(S_, O_) fmx(fmx3(fmx3(S_[O_], S_[O_ + 1], S_[O_ + 2]), fmx3(S_[O_ + 3], S_[O_ + 4], S_[O_ + 5]), \
+                                S_[O_ + 6]), S_[O_ + 7])
+#define W4_SWAPMAX(MX_, OUT_)                                                                                  \
+    {                                                                                                          \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(MX_), __float_as_uint(MX_), false, false); \
+        OUT_ = fmx(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                        \
+    }
+    // keys past lk (zero K rows of a ragged last tile) leave the row max and get p = exp2(-inf) = 0
+#define W4_MASK(S_, T_)                                                                                        \
+    if ((T_) == nt - 1 && (lk & (kKV - 1))) {                                                                  \
+        const int kbase_ = (T_) * kKV + 4 * h;                                                                 \
+        _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) { \
+            const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);                                                \
+            if (key_ >= lk) S_[qs_][0][j_] = -INFINITY;                                                        \
+            if (key_ + 32 >= lk) S_[qs_][1][j_] = -INFINITY;                                                   \
+        }                                                                                                      \
+    }
+
+    // ---- prologue: K(0), V(0), K(1); S(0) = K(0).Q^T unpipelined; its max; first sub-block's exp2 ----
+    W4_DMA_K(0)
+    W4_DMA_V(0)
+    if (nt > 1) { W4_DMA_K(1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x16_t sa[2][2], sb[2][2];   // S of the tile in flight / of the next one: [sub-block][key half]
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        const uint32_t a = ka_base ^ (ks << 5);
+        const u32x4_t a0 = *W4_LDS_PTR(const u32x4_t, a);
+        const u32x4_t a1 = *W4_LDS_PTR(const u32x4_t, a + 32 * D * 2);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            if (ks == 0) {
+                w4_mfma_qk0<T>(sa[qs][0], a0, qf[qs][ks]);
+                w4_mfma_qk0<T>(sa[qs][1], a1, qf[qs][ks]);
+            } else {
+                w4_mfma_qk<T>(sa[qs][0], a0, qf[qs][ks]);
+                w4_mfma_qk<T>(sa[qs][1], a1, qf[qs][ks]);
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA results -> vector reads
+    W4_MASK(sa, 0)
+    float psum0 = 0.f;             // row sum of sub-block 0's P of the tile in flight (added to l_run in phase 1)
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const float mx = fmx(fmx3(W4_MAX8(sa[qs][0], 0), W4_MAX8(sa[qs][0], 8), W4_MAX8(sa[qs][1], 0)),
+                             W4_MAX8(sa[qs][1], 8));
+        float mxx;
+        W4_SWAPMAX(mx, mxx)
+        m_run[qs] = mxx * c2;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sa[0][kh][j] = __builtin_amdgcn_exp2f(sa[0][kh][j] * c2 - m_run[0]);
+            psum0 += sa[0][kh][j];
+        }
+
+    u32x4_t pb[2][4];              // P(t) packed bf16: pb[sub-block][2 * key half + (j >> 3)]
+
+    // The fragment reads of the tile loop are inline asm with hand-counted lgkmcnt waits.  As compiler-visible loads
+    // every ds_read issued after an LDS-DMA of the same tile would get an s_waitcnt vmcnt(0) in front of it (the DMA
+    // writes LDS and nothing tells the compiler that it is another ring slot): the wave would sit out the HBM latency
+    // of its own prefetch in every tile.  LDS returns data in order, so "lgkmcnt(n)" = all but the last n reads landed.
+#define W4_LD128(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_));
+#define W4_LDTR(DST_, ADDR_, OFF_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_));
+#define W4_WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory");
+    // loop-invariant fragment addresses: ring slots and the +32-row / +16-key-row steps are instruction offsets
+    uint32_t ka_addr[kKS], vl_addr[kDT], vh_addr[kDT];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) ka_addr[ks] = ka_base ^ (ks << 5);
+#pragma unroll
+    for (int dt = 0; dt < kDT; ++dt) {
+        vl_addr[dt] = (vl_base - 2 * kW4TileBytes) ^ (dt << 6);
+        vh_addr[dt] = (vh_base - 2 * kW4TileBytes) ^ (dt << 6);
+    }
+
+    // softmax pieces.  W4_FMA: y = c.s - m of element E_ (e = 16 * key half + j), one slice AHEAD of its exp2 so that the
+    // transcendental never waits for its operand; W4_EXPY: x = exp2(y), and the row sum takes the PREVIOUS x (a
+    // transcendental's result is not ready for the next issue).  The empty asm pins each piece to its slice: pure
+    // arithmetic otherwise sinks to its use, a phase later.
+#define W4_FMA(S_, QS_, E_, M_, Y_)                                                                            \
+    asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(Y_) : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "s"(c2), "v"(M_));
+#define W4_EXPY(S_, QS_, E_, Y_, SUM_, PEND_)                                                                  \
+    {                                                                                                          \
+        float x_;                                                                                              \
+        asm volatile("v_exp_f32 %0, %2\n\tv_add_f32 %1, %1, %3" : "=&v"(x_), "+v"(SUM_) : "v"(Y_), "v"(PEND_));  \
+        S_[QS_][(E_) >> 4][(E_) & 15] = x_;                                                                    \
+        PEND_ = x_;                                                                                            \
+    }
+    // pack elements (E_, E_ + 1) of sub-block QS_ (E_ even) into P's B-operand registers
+#define W4_PACK2(S_, QS_, E_)                                                                                  \
+    {                                                                                                          \
+        uint32_t w_;                                                                                           \
+        if constexpr (T::kId == FINO_BF16)                                                                     \
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w_)                                             \
+                         : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]));      \
+        else                                                                                                   \
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w_)                                              \
+                         : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]));      \
+        pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
+    }
+    // V^T fragment pair n (= 4 * key step + d-tile) of the V slot at byte VS_ -> ring entry n & 3 (two 64-bit halves)
+#define W4_LOADV(N_, VS_)                                                                                      \
+    {                                                                                                          \
+        W4_LDTR(vlo_[(N_) & 3], vl_addr[(N_) & 3], (VS_) + ((N_) >> 2) * 16 * D * 2)                           \
+        W4_LDTR(vhi_[(N_) & 3], vh_addr[(N_) & 3], (VS_) + ((N_) >> 2) * 16 * D * 2)                           \
+    }
+
+    // ---- one key tile t of parity PAR_ (literal): SC_ = S(t) (sub-block 0 already exp2'ed, its row sum in psum0),
+    //      SN_ = S(t+1).  Ring slots: K(t+1) is read from K slot 1 - PAR_, V(t) from V slot PAR_; the DMA of K(t+2)
+    //      goes to K slot PAR_ and that of V(t+1) to V slot 1 - PAR_ (both free since the barrier). ----
+#define W4_TILE(SC_, SN_, TT_, PAR_, HN_)                                                                      \
+    {                                                                                                          \
+        const int t_ = (TT_);                                                                                  \
+        constexpr bool has_next_ = (HN_);                                                                      \
+        constexpr int ks_off_ = (1 - (PAR_)) * kW4TileBytes;                  /* K slot read in phase 1 */     \
+        constexpr int vs_off_ = (2 + (PAR_)) * kW4TileBytes;                  /* V slot read in phase 2 */     \
+        W4_STAMP(ts0)                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        W4_STAMP(ts1)                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        W4_FENCE                                                                                               \
+        W4_STAMP(ts2)                                                                                          \
+        const bool dma_k_ = t_ + 2 < nt;     /* the 8 LDS-DMA pieces go out one per k-step of phase 1 */       \
+        W4_STAMP(ts3)                                                                                          \
+        /* ================= phase 1: S(t+1) = K(t+1).Q^T  ||  exp2 of sub-block 1 of S(t), packing ========= */ \
+        float psum1_ = 0.f, pend1_ = 0.f, y1_[2];                                                              \
+        u32x4_t ka_[2][2];                                                                                     \
+        u32x2_t vlo_[4], vhi_[4];                                                                              \
+        if (has_next_) {                                                                                       \
+            W4_LD128(ka_[0][0], ka_addr[0], ks_off_)                                                           \
+            W4_LD128(ka_[0][1], ka_addr[0], ks_off_ + 32 * D * 2)                                              \
+        }                                                                                                      \
+        W4_FMA(SC_, 1, 0, m_run[1], y1_[0])                                                                    \
+        W4_FENCE                                                                                               \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < kKS; ++ks_) {                                                \
+            if (has_next_ && ks_ + 1 < kKS) {                                                                  \
+                W4_LD128(ka_[(ks_ + 1) & 1][0], ka_addr[ks_ + 1], ks_off_)                                     \
+                W4_LD128(ka_[(ks_ + 1) & 1][1], ka_addr[ks_ + 1], ks_off_ + 32 * D * 2)                        \
+            }                                                                                                  \
+            if (ks_ == kKS - 2) { W4_LOADV(0, vs_off_) }                                                       \
+            if (ks_ == kKS - 1) { W4_LOADV(1, vs_off_) }                                                       \
+            /* K(ks) landed: behind it are K(ks+1) (2 reads), at ks = 6 also V pair 0, at ks = 7 V pairs 0, 1 */ \
+            if (has_next_) {                                                                                   \
+                if (ks_ < kKS - 2) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(4) }                                \
+            }                                                                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                 \
+                const int qs_ = i_ & 1, kh_ = i_ >> 1;                                                         \
+                const int s_ = 4 * ks_ + i_;                                                                   \
+                /* slice s: the fma of element s + 1 of sub-block 1 (FIRST: its exp2 opens the next slice), the  \
+                   MFMA, exp2 of element s, one packed pair (sub-block 0 first: exp2'ed a phase ago; then        \
+                   sub-block 1, a slice behind its exp2) */                                                    \
+                if (s_ + 1 < 32) { W4_FMA(SC_, 1, s_ + 1, m_run[1], y1_[(s_ + 1) & 1]) }                       \
+                if (has_next_) {                                                                               \
+                    if (ks_ == 0) w4_mfma_qk0<T>(SN_[qs_][kh_], ka_[ks_ & 1][kh_], qf[qs_][ks_]);              \
+                    else w4_mfma_qk<T>(SN_[qs_][kh_], ka_[ks_ & 1][kh_], qf[qs_][ks_]);                        \
+                }                                                                                              \
+                if (i_ == 1) {                                                                                 \
+                    if (ks_ < 4) { if (dma_k_) { W4_DMA_K1(t_ + 2, PAR_, ks_) } }                              \
+                    else if (has_next_) { W4_DMA_V1(t_ + 1, 1 - (PAR_), ks_ - 4) }                             \
+                }                                                                                              \
+                W4_EXPY(SC_, 1, s_, y1_[s_ & 1], psum1_, pend1_)                                               \
+                if (2 * s_ < 32) { W4_PACK2(SC_, 0, 2 * s_) }                                                  \
+                else if (2 * s_ - 32 < s_ - 1) { W4_PACK2(SC_, 1, 2 * s_ - 32) }                               \
+                W4_FENCE                                                                                       \
+            }                                                                                                  \
+        }                                                                                                      \
+        l_run[0] += psum0;                                                                                     \
+        l_run[1] += psum1_ + pend1_;                                                                           \
+        W4_PACK2(SC_, 1, 30)                          /* the pair whose exp2 came in the last slice */         \
+        W4_FENCE                                                                                               \
+        W4_STAMP(ts4)                                                                                          \
+        /* ================= phase 2: O^T += V(t)^T.P(t)^T  ||  row max of S(t+1), exp2 of its sub-block 0 == */ \
+        if (has_next_) { W4_MASK(SN_, t_ + 1) }                                                                \
+        float mxp_[2] = {-INFINITY, -INFINITY}, m_new_[2] = {m_run[0], m_run[1]};                              \
+        float psn_ = 0.f, pendn_ = 0.f, yn_[2] = {0.f, 0.f};                                                   \
+        _Pragma("unroll") for (int n_ = 0; n_ < 4 * kDT; ++n_) {                                               \
+            if (n_ + 2 < 4 * kDT) { W4_LOADV(n_ + 2, vs_off_) }                                                \
+            /* pair n landed: behind it are pairs n+1, n+2 (2 reads each) */                                   \
+            if (n_ + 2 < 4 * kDT) { W4_WAIT_LGKM(4) } else if (n_ + 1 < 4 * kDT) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(0) } \
+            const u32x4_t va_ = {vlo_[n_ & 3][0], vlo_[n_ & 3][1], vhi_[n_ & 3][0], vhi_[n_ & 3][1]};          \
+            _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) {                                              \
+                const int s_ = 2 * n_ + qs_;                             /* slice 0..31 */                     \
+                /* exp2 schedule of sub-block 0 of S(t+1): elements 2(s-5), 2(s-5)+1 in slices 5..9, element s  \
+                   from slice 10 on; every fma one slice (or half a slice) ahead of its exp2 */                \
+                if (has_next_ && s_ >= 10 && s_ + 1 < 32) { W4_FMA(SN_, 0, s_ + 1, m_new_[0], yn_[(s_ + 1) & 1]) } \
+                w4_o_mfma<T>(4 * qs_ + (n_ & 3), va_, pb[qs_][n_ >> 2]);                                       \
+                if (has_next_) {                                                                               \
+                    if (s_ < 4) {               /* a quarter of both sub-blocks' row maxima: two independent chains */ \
+                        const int kh_ = s_ >> 1, o_ = 8 * (s_ & 1);                                            \
+                        mxp_[0] = fmx(mxp_[0], W4_MAX8(SN_[0][kh_], o_));                                      \
+                        mxp_[1] = fmx(mxp_[1], W4_MAX8(SN_[1][kh_], o_));                                      \
+                        asm volatile("" : "+v"(mxp_[0]), "+v"(mxp_[1]));                                       \
+                    } else if (s_ == 4) {                                                                      \
+                        float mx0_, mx1_;                                                                      \
+                        W4_SWAPMAX(mxp_[0], mx0_)                                                              \
+                        W4_SWAPMAX(mxp_[1], mx1_)                                                              \
+                        m_new_[0] = fmx(m_run[0], mx0_ * c2);                                                  \
+                        m_new_[1] = fmx(m_run[1], mx1_ * c2);                                                  \
+                        if (!__any(fmx(m_new_[0] - m_run[0], m_new_[1] - m_run[1]) > kRescaleThr)) {           \
+                            m_new_[0] = m_run[0];                                                              \
+                            m_new_[1] = m_run[1];                                                              \
+                        }                                                                                      \
+                        asm volatile("" : "+v"(m_new_[0]), "+v"(m_new_[1]));                                   \
+                        W4_FMA(SN_, 0, 0, m_new_[0], yn_[0])                                                   \
+                        W4_FMA(SN_, 0, 1, m_new_[0], yn_[1])                                                   \
+                    } else if (s_ < 10) {                                                                      \
+                        W4_EXPY(SN_, 0, 2 * (s_ - 5), yn_[0], psn_, pendn_)                                    \
+                        W4_EXPY(SN_, 0, 2 * (s_ - 5) + 1, yn_[1], psn_, pendn_)                                \
+                        W4_FMA(SN_, 0, 2 * (s_ - 5) + 2, m_new_[0], yn_[0])        /* slice 9: element 10 */        \
+                        if (s_ < 9) { W4_FMA(SN_, 0, 2 * (s_ - 5) + 3, m_new_[0], yn_[1]) }                    \
+                    } else {                                                                                   \
+                        W4_EXPY(SN_, 0, s_, yn_[s_ & 1], psn_, pendn_)                                         \
+                    }                                                                                          \
+                }                                                                                              \
+                W4_FENCE                                                                                       \
+            }                                                                                                  \
+        }                                                                                                      \
+        /* deferred rescale, between tiles: O, l and m of a sub-block move together */                         \
+        if (has_next_) {                                                                                       \
+            if (__builtin_expect(__any(m_new_[0] != m_run[0] || m_new_[1] != m_run[1]), 0)) {                  \
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       /* MFMA writes of O -> vector reads */ \
+                _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) {                                          \
+                    const float alpha_ = __builtin_amdgcn_exp2f(m_run[qs_] - m_new_[qs_]);                     \
+                    m_run[qs_] = m_new_[qs_];                                                                  \
+                    l_run[qs_] *= alpha_;                                                                      \
+                    w4_o_scale(qs_, alpha_);                                                                   \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        psum0 = psn_ + pendn_;                                                                                 \
+        W4_FENCE                                                                                               \
+        W4_STAMP(ts5)                                                                                          \
+        W4_STAMP_ACC                                                                                           \
+    }
+
+#ifdef FINO_ATTN_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sa4 = 0;
+#define W4_STAMP_ACC { sa0 += ts1 - ts0; sa1 += ts2 - ts1; sa2 += ts3 - ts2; sa3 += ts4 - ts3; sa4 += ts5 - ts4; }
+#else
+#define W4_STAMP_ACC
+#endif
+    // tiles 0 .. nt-2 have a successor (two per trip: the S buffers and the ring slots swap roles); the last one does not
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+        W4_TILE(sa, sb, t, 0, true)
+        W4_TILE(sb, sa, t + 1, 1, true)
+    }
+    if (t + 1 < nt) {
+        W4_TILE(sa, sb, t, 0, true)
+        W4_TILE(sb, sa, t + 1, 1, false)
+    } else {
+        W4_TILE(sa, sb, t, 0, false)
+    }
+
+#ifdef FINO_ATTN_STAMP
+    if (blockIdx.x == 40 && lane == 0 && VAR == 0) {
+        fino_attn_w4_dbg[wave * 8 + 0] = sa0; fino_attn_w4_dbg[wave * 8 + 1] = sa1; fino_attn_w4_dbg[wave * 8 + 2] = sa2;
+        fino_attn_w4_dbg[wave * 8 + 3] = sa3; fino_attn_w4_dbg[wave * 8 + 4] = sa4; fino_attn_w4_dbg[wave * 8 + 5] = (unsigned long long)nt;
+    }
+#endif
+    // ---------------- epilogue: normalise, store O[q][d] ----------------
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // last MFMA writes of O -> vector reads
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qs]), __float_as_uint(l_run[qs]), false, false);
+        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const float inv = 1.0f / l;
+        uint16_t* orow = op + (int64_t)(qrow[qs] < p.lq ? qrow[qs] : 0) * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt) {
+            float f[16];
+            w4_o_read(4 * qs + dt, f);
+            if (qrow[qs] < p.lq) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = dt * 32 + 8 * g + 4 * h;
+                    const uint32_t w0 = w4_pack2<T>(f[4 * g + 0] * inv, f[4 * g + 1] * inv);
+                    const uint32_t w1 = w4_pack2<T>(f[4 * g + 2] * inv, f[4 * g + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_w4(const AttnParams& p, hipStream_t st) {
+    static FinoPerDeviceOnce once_a, once_b;
+    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_w4_kernel<T, 0>), kW4Smem, "fino_attn_fwd")) return rc;
+    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_w4_kernel<T, 1>), kW4Smem, "fino_attn_fwd")) return rc;
+    const int groups = (p.batch * p.heads + 7) / 8;
+    const dim3 grid((unsigned)(8 * groups * p.nqb));
+    if (p.lk > 1024)
+        attn_w4_kernel<T, 0><<<grid, kW4Threads, kW4Smem, st>>>(p);
+    else
+        attn_w4_kernel<T, 1><<<grid, kW4Threads, kW4Smem, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+}  // namespace
+
+int fino_attn_launch_w4(const AttnParams& p, int dtype, hipStream_t st) {
+    return dtype == FINO_BF16 ? launch_w4<BF16>(p, st) : launch_w4<F16>(p, st);
+}
