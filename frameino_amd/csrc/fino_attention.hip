@@ -873,7 +873,6 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
         return rc;
     if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_pp_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
         return rc;
-    if (D == 128 && !p.all_partial && fino_tune_get(FINO_TUNE_ATTN_KERNEL) == 2) return fino_attn_launch_w4(p, T::kId, st);
     const int hb = p.batch * p.heads;
     const int groups = (hb + 7) / 8;
     SplitPlan sp{groups * p.nqb, 0, 0, 1};
@@ -888,7 +887,13 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     if (p.all_partial) sp = SplitPlan{groups * p.nqb, 0, 0, 1};       // no tail split: every block is a partial anyway
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
-    if (pingpong)
+    // head_dim 128: the 4-wave kernel wins on long rows of many blocks (its block prologue is the heavier one: Lq 3080 x
+    // Lk 12320 on 312 blocks 967 vs 1008 TFLOP/s, text cross-attention Lk 512 570 vs 650; 12320^2 x 48 heads 1158 vs 1131)
+    const int tune_k = fino_tune_get(FINO_TUNE_ATTN_KERNEL);                 // A/B: 1 = 8-wave, 2 = 4-wave
+    const bool w4 = D == 128 && (tune_k == 2 || (tune_k == 0 && p.lk >= 4096 && (int64_t)groups * p.nqb * 8 >= 3 * device_cus()));
+    if (w4) {
+        if (int rc = fino_attn_launch_w4(p, T::kId, st)) return rc;
+    } else if (pingpong)
         attn_pp_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     else
         attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);

@@ -38,6 +38,11 @@ constexpr int kW4TileBytes = kKV * kW4D * 2;     // 16 KiB
 constexpr int kW4Smem = 4 * kW4TileBytes;        // K ring (2) + V ring (2)
 
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+// Between two inline-asm statements of which the second reads a register the first one writes, the hazard recogniser
+// (which counts inline asm as zero wait states) pads with an s_nop.  W4_SEP puts a real, ordered, instruction there.
+#ifndef W4_SEP
+#define W4_SEP        /* measured: s_setprio 0 there 1266 TFLOP/s, the recogniser's s_nop 1277 -- left to the s_nop */
+#endif
 #define W4_LDS_PTR(TYPE_, ADDR_) ((FINO_LDS TYPE_*)(uintptr_t)(uint32_t)(ADDR_))
 
 // The MFMAs go through inline asm so that the register FILE of every operand is this file's decision: O^T (128
@@ -86,20 +91,49 @@ void attn_w4_kernel(const AttnParams p) {
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    // XCD-aware block -> (head-batch, q-block): all q-blocks of a head share blockIdx % 8
+    // XCD-aware block -> (head-batch, q-block): all q-blocks of a head share blockIdx % 8.  Whole blocks first; then the
+    // XCD's last rem_x blocks as one stream of rem_x * nt key tiles cut into nwg equal ranges (tail split, same plan
+    // and same partial layout as the 8-wave kernel: attn_combine_kernel / attn_merge_kernel finish either).
     const int id = blockIdx.x;
     const int xcd = id & 7;
     const int slot = id >> 3;
-    const int hb = xcd + 8 * (slot / p.nqb);
-    const int qb = slot % p.nqb;
-    if (hb >= p.batch * p.heads) return;
+    const int ntall = (p.lk + kKV - 1) / kKV;
+    int npieces = 1, first_b = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (slot >= p.full_x) {
+        g0 = (int64_t)(slot - p.full_x) * p.per;
+        g1 = g0 + p.per < (int64_t)p.rem_x * ntall ? g0 + p.per : (int64_t)p.rem_x * ntall;
+        first_b = (int)(g0 / ntall);
+        npieces = (int)((g1 - 1) / ntall) - first_b + 1;
+    }
+  for (int piece = 0; piece < npieces; ++piece) {
+    if (piece > 0) __syncthreads();                 // every wave is done reading the previous piece's LDS tiles
+    int bx = slot, part = -1, t_begin = 0, t_end = ntall;
+    if (slot >= p.full_x) {
+        const int tb = first_b + piece;
+        const int64_t b0 = (int64_t)tb * ntall;
+        t_begin = g0 > b0 ? (int)(g0 - b0) : 0;
+        t_end = g1 - b0 < ntall ? (int)(g1 - b0) : ntall;
+        bx = p.full_x + tb;
+        if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
+    }
+    // (wave-uniform by construction; said explicitly, or the piece loop makes the compiler treat the K/V resources
+    //  and DMA offsets as divergent and wrap every LDS-DMA in a readfirstlane loop)
+    const int hb = __builtin_amdgcn_readfirstlane(xcd + 8 * (bx / p.nqb));
+    const int qb = __builtin_amdgcn_readfirstlane(bx % p.nqb);
+    t_begin = __builtin_amdgcn_readfirstlane(t_begin);
+    t_end = __builtin_amdgcn_readfirstlane(t_end);
+    part = __builtin_amdgcn_readfirstlane(part);
+    if (hb >= p.batch * p.heads) continue;
+    if (p.all_partial) part = hb * p.nqb + qb;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
     const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
-    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs;
-    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs + (int64_t)t_begin * kKV * p.k_rs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs + (int64_t)t_begin * kKV * p.v_rs;
     uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
-    const int lk = p.lk;
+    // keys of this workgroup's range, re-based to 0 (a multiple of kKV precedes it, so tail masks are unchanged)
+    const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;
     const int nt = (lk + kKV - 1) / kKV;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[row][16*ks + 8h .. +7] of both sub-blocks ----
@@ -175,11 +209,12 @@ void attn_w4_kernel(const AttnParams p) {
     // keys past lk (zero K rows of a ragged last tile) leave the row max and get p = exp2(-inf) = 0
 #define W4_MASK(S_, T_)                                                                                        \
     if ((T_) == nt - 1 && (lk & (kKV - 1))) {                                                                  \
-        const int kbase_ = (T_) * kKV + 4 * h;                                                                 \
+        int rem_ = lk - (T_) * kKV - 4 * h;            /* keys left from this lane's first one */               \
+        asm volatile("" : "+v"(rem_));                 /* opaque: or 32 loop-invariant lane masks are hoisted into SGPRs */ \
         _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) { \
-            const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);                                                \
-            if (key_ >= lk) S_[qs_][0][j_] = -INFINITY;                                                        \
-            if (key_ + 32 >= lk) S_[qs_][1][j_] = -INFINITY;                                                   \
+            const int key_ = (j_ & 3) + 8 * (j_ >> 2);                                                         \
+            if (key_ >= rem_) S_[qs_][0][j_] = -INFINITY;                                                      \
+            if (key_ + 32 >= rem_) S_[qs_][1][j_] = -INFINITY;                                                 \
         }                                                                                                      \
     }
 
@@ -254,6 +289,7 @@ void attn_w4_kernel(const AttnParams p) {
 #define W4_EXPY(S_, QS_, E_, Y_, SUM_, PEND_)                                                                  \
     {                                                                                                          \
         float x_;                                                                                              \
+        W4_SEP                                                                                                 \
         asm volatile("v_exp_f32 %0, %2\n\tv_add_f32 %1, %1, %3" : "=&v"(x_), "+v"(SUM_) : "v"(Y_), "v"(PEND_));  \
         S_[QS_][(E_) >> 4][(E_) & 15] = x_;                                                                    \
         PEND_ = x_;                                                                                            \
@@ -430,12 +466,27 @@ void attn_w4_kernel(const AttnParams p) {
         fino_attn_w4_dbg[wave * 8 + 3] = sa3; fino_attn_w4_dbg[wave * 8 + 4] = sa4; fino_attn_w4_dbg[wave * 8 + 5] = (unsigned long long)nt;
     }
 #endif
-    // ---------------- epilogue: normalise, store O[q][d] ----------------
+    // ---------------- epilogue: normalise, store O[q][d] (or leave the (O, m, l) partial) ----------------
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // last MFMA writes of O -> vector reads
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qs]), __float_as_uint(l_run[qs]), false, false);
         const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (part >= 0) {
+            // same layout as the 8-wave kernel's partials: its wave 2w + qs owns these 32 query rows
+            float* w = p.ws + (int64_t)part * partial_floats<D>();
+            const int tid8 = (2 * wave + qs) * 64 + lane;
+#pragma unroll
+            for (int dt = 0; dt < kDT; ++dt) {
+                float f[16];
+                w4_o_read(4 * qs + dt, f);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[(dt * 16 + j) * (kWaves * 64) + tid8] = f[j];
+            }
+            w[kDT * 16 * (kWaves * 64) + tid8] = m_run[qs];
+            w[kDT * 16 * (kWaves * 64) + kWaves * 64 + tid8] = l;
+            continue;
+        }
         const float inv = 1.0f / l;
         uint16_t* orow = op + (int64_t)(qrow[qs] < p.lq ? qrow[qs] : 0) * p.o_rs;
 #pragma unroll
@@ -453,6 +504,7 @@ void attn_w4_kernel(const AttnParams p) {
             }
         }
     }
+  }   // piece
 }
 
 template <typename T>
@@ -460,8 +512,7 @@ int launch_w4(const AttnParams& p, hipStream_t st) {
     static FinoPerDeviceOnce once_a, once_b;
     if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_w4_kernel<T, 0>), kW4Smem, "fino_attn_fwd")) return rc;
     if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_w4_kernel<T, 1>), kW4Smem, "fino_attn_fwd")) return rc;
-    const int groups = (p.batch * p.heads + 7) / 8;
-    const dim3 grid((unsigned)(8 * groups * p.nqb));
+    const dim3 grid((unsigned)(8 * (p.full_x + p.nwg)));
     if (p.lk > 1024)
         attn_w4_kernel<T, 0><<<grid, kW4Threads, kW4Smem, st>>>(p);
     else
@@ -472,6 +523,7 @@ int launch_w4(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
+// the main launch only: p carries the tail-split plan (full_x, rem_x, nwg, per) / all_partial; the caller runs the combine
 int fino_attn_launch_w4(const AttnParams& p, int dtype, hipStream_t st) {
     return dtype == FINO_BF16 ? launch_w4<BF16>(p, st) : launch_w4<F16>(p, st);
 }

@@ -35,10 +35,25 @@ for (b, heads, lq, lk, qscale) in [(1, 2, 64, 64, 1.0), (1, 2, 300, 500, 1.0), (
     print(f"B{b} H{heads} Lq{lq} Lk{lk} qx{qscale}: w8 vs fp32 {rel(o1, r):.5f}  w4 vs fp32 {rel(o2, r):.5f}  w4 vs w8 {rel(o2, o1):.5f}"
           f"  finite {bool(torch.isfinite(o2.float()).all())}", flush=True)
 
-for (b, heads, L) in [(2, 24, 12288), (2, 24, 12320)]:
+# partials over key ranges + merge through the 4-wave kernel
+for (b, heads, lq, splits) in [(2, 3, 300, (0, 64, 500)), (1, 24, 3080, (0, 3080, 6160, 12320))]:
     d = heads * 128
-    qkv = torch.randn(b, L, 3 * d, device=dev, generator=g).bfloat16()
-    q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+    q = torch.randn(b, lq, d, device=dev, generator=g).bfloat16()
+    kv = torch.randn(b, splits[-1], 2 * d, device=dev, generator=g).bfloat16()
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    lib.fino_tune_set(KEY, 1); full = ops.attention(q, k, v, heads)
+    lib.fino_tune_set(KEY, 2)
+    parts = [ops.attention_partial(q, k[:, a:c], v[:, a:c], heads) for a, c in zip(splits[:-1], splits[1:])]
+    mer = ops.attention_merge(parts, b, lq, heads, 128, q.dtype)
+    lib.fino_tune_set(KEY, 0)
+    print(f"partials B{b} H{heads} Lq{lq} ranges {splits}: merged(w4) vs single pass(w8) {rel(mer, full):.5f}", flush=True)
+
+for (b, heads, L, lkv) in [(2, 24, 12288, 0), (2, 24, 12320, 0), (1, 24, 12320, 0), (2, 24, 25088, 0), (1, 24, 3080, 12320),
+                           (2, 24, 12320, 512)]:
+    d = heads * 128
+    lkv = lkv or L
+    qkv = torch.randn(b, max(L, lkv), 3 * d, device=dev, generator=g).bfloat16()
+    q, k, v = qkv[:, :L, :d], qkv[:, :lkv, d:2 * d], qkv[:, :lkv, 2 * d:]
     out = torch.empty(b, L, d, device=dev, dtype=torch.bfloat16)
     t = {1: [], 2: []}
     for kk in (1, 2):
@@ -51,6 +66,6 @@ for (b, heads, L) in [(2, 24, 12288), (2, 24, 12320)]:
             for _ in range(3): ops.attention(q, k, v, heads, out=out)
             e.record(); torch.cuda.synchronize(); t[kk].append(s.elapsed_time(e) / 3 * 1e3)
     lib.fino_tune_set(KEY, 0)
-    fl = 4.0 * b * heads * L * L * 128
+    fl = 4.0 * b * heads * L * lkv * 128
     a, c = statistics.median(t[1]), statistics.median(t[2])
-    print(f"B{b} H{heads} L{L}: w8 {a:8.1f} us {fl / a / 1e6:6.0f} TF   w4 {c:8.1f} us {fl / c / 1e6:6.0f} TF", flush=True)
+    print(f"B{b} H{heads} Lq{L} Lk{lkv}: w8 {a:8.1f} us {fl / a / 1e6:6.0f} TF   w4 {c:8.1f} us {fl / c / 1e6:6.0f} TF", flush=True)
