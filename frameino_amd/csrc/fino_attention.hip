@@ -193,14 +193,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
         const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false); \
         MX_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                       \
     }
-    // deferred rescale (T13): move the running max only when it grew by more than kRescaleThr (log2 units).  O, l
+    // deferred rescale (T13): move the running max only when it grew by more than rescale_thr<T>() (log2 units).  O, l
     // and m move together and only BETWEEN tiles (all of the previous tile's P.V is in O, no P of the next exists).
     // Rows beyond lk in a ragged last tile are clamped copies of key lk-1, so the max over the padded tile is the
     // max over the valid keys.
 #define MAYBE_RESCALE(MX_)                                                                                   \
     {                                                                                                        \
         const float m_cand_ = fmaxf(m_run, (MX_) * c2);                                                      \
-        if (__any((m_cand_ - m_run) > kRescaleThr)) {                                                        \
+        if (__any((m_cand_ - m_run) > rescale_thr<T>())) {                                                        \
             const float alpha_ = __builtin_amdgcn_exp2f(m_run - m_cand_);                                    \
             m_run = m_cand_;                                                                                 \
             l_run *= alpha_;                                                                                 \
@@ -550,10 +550,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         if (w >= 1) { PP_WRITE(w) }
         ASTAMP(tsa)
         {
-            // deferred rescale (threshold kRescaleThr): O, l and m move together, between tiles.  mx_next = row max of
+            // deferred rescale (threshold rescale_thr<T>()): O, l and m move together, between tiles.  mx_next = row max of
             // this tile's S, computed in the shadow of the previous matrix phase's P.V MFMAs.
             const float m_cand = fmaxf(m_run, mx_next * c2);
-            if (__any((m_cand - m_run) > kRescaleThr)) {
+            if (__any((m_cand - m_run) > rescale_thr<T>())) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
                 m_run = m_cand;
                 l_run *= alpha;
@@ -949,7 +949,8 @@ static int attn_common(const void* q, const void* k, const void* v, void* o, int
                    k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 &&
                    v_hs % 8 == 0 && o_hs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0,
                FINO_ERR_ARG, "fino_attn_fwd: pointers and strides must be 16-byte aligned");
-    FINO_CHECK(scale > 0.f, FINO_ERR_ARG, "fino_attn_fwd: scale must be > 0");
+    FINO_CHECK(scale > 0.f || scale == FINO_ATTN_SCALE_FOLDED, FINO_ERR_ARG,
+               "fino_attn_fwd: scale must be > 0 (or FINO_ATTN_SCALE_FOLDED)");
     // the kernels address the K/V rows of one (batch, head) through a buffer resource: 32-bit byte count and offsets
     {
         const int64_t kmax = k_rs > v_rs ? k_rs : v_rs;
@@ -963,7 +964,7 @@ static int attn_common(const void* q, const void* k, const void* v, void* o, int
     p.batch = batch; p.heads = heads; p.lq = (int)lq; p.lk = (int)lk;
     p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs;
     p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs; p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = o_hs;
-    p.scale_log2 = scale * 1.4426950408889634f;
+    p.scale_log2 = scale == FINO_ATTN_SCALE_FOLDED ? 1.0f : scale * 1.4426950408889634f;
     p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
     p.ws = (workspace && workspace_bytes > 0) ? (float*)workspace : nullptr;
     p.all_partial = all_partial;

@@ -45,7 +45,13 @@ constexpr int kQRowsPerWave = 32;
 constexpr int kWaves = FINO_ATTN_WAVES;   // waves (32 query rows each) per workgroup
 constexpr int kQBlock = kQRowsPerWave * kWaves;  // 256
 constexpr int kKV = 64;
-constexpr float kRescaleThr = 8.0f;  // log2 units: P <= 256 between rescales
+// Deferred rescale: the running maximum m moves only when a row maximum exceeds it by more than this (log2 units), so
+// between rescales P = exp2(s - m) <= 2^thr.  P is rounded to the operand type for the P.V product: fp16 tops out at
+// 65504 = 2^16 - 32, bf16 has fp32's exponent; l and O are fp32 sums of at most Lk terms (2^14 * 2^40 << 2^127).  Every
+// quantity of a row scales by the same 2^(stale m), so the result does not depend on the threshold; 8 (r01) made peaky
+// logits rescale every few tiles, which costs the 4-wave kernel an AGPR round trip of O.
+template <typename T>
+constexpr float rescale_thr() { return T::kId == FINO_BF16 ? 40.0f : 14.0f; }
 
 // Byte offset of 16-byte chunk `ch` of row `row` inside a [kKV][D] tile.
 //  D=128 (256-B rows): ch ^ (((row&3)<<2) | ((row>>2)&3))

@@ -68,6 +68,14 @@ __device__ __forceinline__ void w4_mfma_qk0(f32x16_t& d, const u32x4_t& a, const
     else
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));
 }
+// d = a . b (both operands in VGPRs): the "ones x (-m)" product that opens every S accumulator
+template <typename T>
+__device__ __forceinline__ void w4_mfma_vv0(f32x16_t& d, const u32x4_t& a, const u32x4_t& b) {
+    if constexpr (T::kId == FINO_BF16)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
 template <typename T>
 __device__ __forceinline__ void w4_mfma_qk(f32x16_t& d, const u32x4_t& a, const u32x4_t& bq) {
     if constexpr (T::kId == FINO_BF16)
@@ -77,7 +85,9 @@ __device__ __forceinline__ void w4_mfma_qk(f32x16_t& d, const u32x4_t& a, const 
 }
 
 
-template <typename T, int VAR>
+// FOLD: q arrives pre-multiplied by softmax_scale * log2(e) (p.scale_log2 == 1): -m is folded into the S accumulators by
+// one more MFMA product and the softmax is a bare exp2 (see the prologue).
+template <typename T, int VAR, bool FOLD>
 __global__ __attribute__((amdgpu_flat_work_group_size(kW4Threads, kW4Threads), amdgpu_waves_per_eu(1, 1)))
 void attn_w4_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,6 +157,7 @@ void attn_w4_kernel(const AttnParams p) {
         for (int ks = 0; ks < kKS; ++ks) {
             const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qc * p.q_rs + 16 * ks + 8 * h);
             qf[qs][ks] = u32x4_t{u.x, u.y, u.z, u.w};
+            asm volatile("" : "+a"(qf[qs][ks]));        // lives in AGPRs from here on (else: copied there before every MFMA)
         }
     }
 
@@ -195,8 +206,8 @@ void attn_w4_kernel(const AttnParams p) {
 
     w4_o_zero();                   // O^T: a128..a255, touched only through fino_attention_w4_regs.h
     float m_run[2] = {-INFINITY, -INFINITY};
+    const float c2 = p.scale_log2;           // FOLD: 1 (unused)
     float l_run[2] = {0.f, 0.f};
-    const float c2 = p.scale_log2;
 
     // row max of 8 accumulator registers
 #define W4_MAX8(S_, O_) fmx(fmx3(fmx3(S_[O_], S_[O_ + 1], S_[O_ + 2]), fmx3(S_[O_ + 3], S_[O_ + 4], S_[O_ + 5]), \
@@ -245,19 +256,34 @@ void attn_w4_kernel(const AttnParams p) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA results -> vector reads
     W4_MASK(sa, 0)
     float psum0 = 0.f;             // row sum of sub-block 0's P of the tile in flight (added to l_run in phase 1)
+    // The running maximum is kept as a value of the operand type T: -m then rides into every later S accumulator as
+    // one more product ("ones" x (-m), exact in the fp32 accumulate), and the softmax is exp2(S) with no per-element
+    // scale-and-subtract.  ones: A[key][k = 0] = 1;  mneg[qs]: B[k = 0][q] = -m[q]  (k = 0 lives in the h = 0 lanes).
+    const u32x4_t ones = {h == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u};
+    u32x4_t mneg[2];
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const float mx = fmx(fmx3(W4_MAX8(sa[qs][0], 0), W4_MAX8(sa[qs][0], 8), W4_MAX8(sa[qs][1], 0)),
                              W4_MAX8(sa[qs][1], 8));
         float mxx;
         W4_SWAPMAX(mx, mxx)
-        m_run[qs] = mxx * c2;
+        if constexpr (FOLD) {
+            m_run[qs] = T::to_f32(T::from_f32(mxx));
+            mneg[qs] = u32x4_t{h == 0 ? (uint32_t)T::from_f32(-m_run[qs]) : 0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sa[qs][kh][j] -= m_run[qs];
+        } else {
+            m_run[qs] = mxx * c2;
+            mneg[qs] = u32x4_t{0u, 0u, 0u, 0u};
+        }
     }
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            sa[0][kh][j] = __builtin_amdgcn_exp2f(sa[0][kh][j] * c2 - m_run[0]);
+            sa[0][kh][j] = FOLD ? __builtin_amdgcn_exp2f(sa[0][kh][j]) : __builtin_amdgcn_exp2f(sa[0][kh][j] * c2 - m_run[0]);
             psum0 += sa[0][kh][j];
         }
 
@@ -280,6 +306,7 @@ void attn_w4_kernel(const AttnParams p) {
         vh_addr[dt] = (vh_base - 2 * kW4TileBytes) ^ (dt << 6);
     }
 
+    // ---- FOLD = false (any softmax scale): scale-and-subtract per element ----
     // softmax pieces.  W4_FMA: y = c.s - m of element E_ (e = 16 * key half + j), one slice AHEAD of its exp2 so that the
     // transcendental never waits for its operand; W4_EXPY: x = exp2(y), and the row sum takes the PREVIOUS x (a
     // transcendental's result is not ready for the next issue).  The empty asm pins each piece to its slice: pure
@@ -291,6 +318,17 @@ void attn_w4_kernel(const AttnParams p) {
         float x_;                                                                                              \
         W4_SEP                                                                                                 \
         asm volatile("v_exp_f32 %0, %2\n\tv_add_f32 %1, %1, %3" : "=&v"(x_), "+v"(SUM_) : "v"(Y_), "v"(PEND_));  \
+        S_[QS_][(E_) >> 4][(E_) & 15] = x_;                                                                    \
+        PEND_ = x_;                                                                                            \
+    }
+    // ---- FOLD = true ----
+    // one softmax element (e = 16 * key half + j): x = exp2(S), and the row sum takes the PREVIOUS x (a transcendental's
+    // result is not ready for the next issue).  asm: the placement in its slice is the schedule.
+#define W4_EXP1(S_, QS_, E_, SUM_, PEND_)                                                                      \
+    {                                                                                                          \
+        float x_;                                                                                              \
+        asm volatile("v_exp_f32 %0, %2\n\tv_add_f32 %1, %1, %3" : "=&v"(x_), "+v"(SUM_)                        \
+                     : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(PEND_));                                        \
         S_[QS_][(E_) >> 4][(E_) & 15] = x_;                                                                    \
         PEND_ = x_;                                                                                            \
     }
@@ -316,7 +354,133 @@ void attn_w4_kernel(const AttnParams p) {
     // ---- one key tile t of parity PAR_ (literal): SC_ = S(t) (sub-block 0 already exp2'ed, its row sum in psum0),
     //      SN_ = S(t+1).  Ring slots: K(t+1) is read from K slot 1 - PAR_, V(t) from V slot PAR_; the DMA of K(t+2)
     //      goes to K slot PAR_ and that of V(t+1) to V slot 1 - PAR_ (both free since the barrier). ----
-#define W4_TILE(SC_, SN_, TT_, PAR_, HN_)                                                                      \
+#define W4_TILE_F(SC_, SN_, TT_, PAR_, HN_)                                                                      \
+    {                                                                                                          \
+        const int t_ = (TT_);                                                                                  \
+        constexpr bool has_next_ = (HN_);                                                                      \
+        constexpr int ks_off_ = (1 - (PAR_)) * kW4TileBytes;                  /* K slot read in phase 1 */     \
+        constexpr int vs_off_ = (2 + (PAR_)) * kW4TileBytes;                  /* V slot read in phase 2 */     \
+        W4_STAMP(ts0)                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        W4_STAMP(ts1)                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        W4_FENCE                                                                                               \
+        W4_STAMP(ts2)                                                                                          \
+        const bool dma_k_ = t_ + 2 < nt;     /* the 8 LDS-DMA pieces go out one per k-step of phase 1 */       \
+        W4_STAMP(ts3)                                                                                          \
+        /* ================= phase 1: S(t+1) = ones.(-m) + K(t+1).Q~^T  ||  exp2 of sub-block 1 of S(t), packing === */ \
+        /* 36 MFMA slices: 4 opening products (they also cover the first K fragment's LDS latency), then 8 k-steps x 4. \
+           Slice s carries exp2 of element s of sub-block 1 (s < 32) and one packed pair: pairs 0..15 = sub-block 0   \
+           (exp2'ed a phase ago) in slices 0..15, pair p >= 16 = sub-block 1 elements 2(p-16), +1 in slice p + 4.     */ \
+        float psum1_ = 0.f, pend1_ = 0.f;                                                                      \
+        u32x4_t ka_[2][2];                                                                                     \
+        u32x2_t vlo_[4], vhi_[4];                                                                              \
+        if (has_next_) {                                                                                       \
+            W4_LD128(ka_[0][0], ka_addr[0], ks_off_)                                                           \
+            W4_LD128(ka_[0][1], ka_addr[0], ks_off_ + 32 * D * 2)                                              \
+        }                                                                                                      \
+        /* ones / mneg are vector-written registers (re-assembled by the compiler at will): a VALU write straight  \
+           in front of an MFMA that reads it is a hazard the recogniser cannot see through the asm */          \
+        asm volatile("s_nop 3" : "+v"(mneg[0]), "+v"(mneg[1]) : "v"(ones));                                    \
+        W4_FENCE                                                                                               \
+        _Pragma("unroll") for (int s_ = 0; s_ < 36; ++s_) {                                                    \
+            const int ks_ = (s_ - 4) >> 2, i_ = s_ & 3;               /* k-step / MFMA of the k-step (s >= 4) */ \
+            const int qs_ = i_ & 1, kh_ = i_ >> 1;                                                             \
+            if (s_ >= 4 && i_ == 0) {                                                                          \
+                if (has_next_ && ks_ + 1 < kKS) {                                                              \
+                    W4_LD128(ka_[(ks_ + 1) & 1][0], ka_addr[ks_ + 1], ks_off_)                                 \
+                    W4_LD128(ka_[(ks_ + 1) & 1][1], ka_addr[ks_ + 1], ks_off_ + 32 * D * 2)                    \
+                }                                                                                              \
+                if (ks_ == kKS - 2) { W4_LOADV(0, vs_off_) }                                                   \
+                if (ks_ == kKS - 1) { W4_LOADV(1, vs_off_) }                                                   \
+                /* K(ks) landed: behind it are K(ks+1) (2 reads), at ks = 6 also V pair 0, at ks = 7 V pairs 0, 1 */ \
+                if (has_next_) {                                                                               \
+                    if (ks_ < kKS - 2) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(4) }                            \
+                }                                                                                              \
+            }                                                                                                  \
+            if (has_next_) {                                                                                   \
+                if (s_ < 4) w4_mfma_vv0<T>(SN_[qs_][kh_], ones, mneg[qs_]);                                    \
+                else w4_mfma_qk<T>(SN_[qs_][kh_], ka_[ks_ & 1][kh_], qf[qs_][ks_]);                            \
+            }                                                                                                  \
+            if (s_ >= 4 && i_ == 1) {                                                                          \
+                if (ks_ < 4) { if (dma_k_) { W4_DMA_K1(t_ + 2, PAR_, ks_) } }                                  \
+                else if (has_next_) { W4_DMA_V1(t_ + 1, 1 - (PAR_), ks_ - 4) }                                 \
+            }                                                                                                  \
+            if (s_ < 32) { W4_EXP1(SC_, 1, s_, psum1_, pend1_) }                                               \
+            if (s_ < 16) { W4_PACK2(SC_, 0, 2 * s_) }                                                          \
+            else if (s_ >= 20) { W4_PACK2(SC_, 1, 2 * (s_ - 20)) }                                             \
+            W4_FENCE                                                                                           \
+        }                                                                                                      \
+        l_run[0] += psum0;                                                                                     \
+        l_run[1] += psum1_ + pend1_;                                                                           \
+        W4_FENCE                                                                                               \
+        W4_STAMP(ts4)                                                                                          \
+        /* ================= phase 2: O^T += V(t)^T.P(t)^T  ||  row max of S(t+1), exp2 of its sub-block 0 == */ \
+        if (has_next_) { W4_MASK(SN_, t_ + 1) }                                                                \
+        float mxp_[2] = {-INFINITY, -INFINITY}, dm_[2] = {0.f, 0.f};                                           \
+        bool resc_ = false;                                                                                    \
+        float psn_ = 0.f, pendn_ = 0.f;                                                                        \
+        _Pragma("unroll") for (int n_ = 0; n_ < 4 * kDT; ++n_) {                                               \
+            if (n_ + 2 < 4 * kDT) { W4_LOADV(n_ + 2, vs_off_) }                                                \
+            /* pair n landed: behind it are pairs n+1, n+2 (2 reads each) */                                   \
+            if (n_ + 2 < 4 * kDT) { W4_WAIT_LGKM(4) } else if (n_ + 1 < 4 * kDT) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(0) } \
+            const u32x4_t va_ = {vlo_[n_ & 3][0], vlo_[n_ & 3][1], vhi_[n_ & 3][0], vhi_[n_ & 3][1]};          \
+            _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) {                                              \
+                const int s_ = 2 * n_ + qs_;                             /* slice 0..31 */                     \
+                w4_o_mfma<T>(4 * qs_ + (n_ & 3), va_, pb[qs_][n_ >> 2]);                                       \
+                if (has_next_) {                                                                               \
+                    if (s_ < 4) {               /* a quarter of both sub-blocks' row maxima: two independent chains */ \
+                        const int kh_ = s_ >> 1, o_ = 8 * (s_ & 1);                                            \
+                        mxp_[0] = fmx(mxp_[0], W4_MAX8(SN_[0][kh_], o_));                                      \
+                        mxp_[1] = fmx(mxp_[1], W4_MAX8(SN_[1][kh_], o_));                                      \
+                        asm volatile("" : "+v"(mxp_[0]), "+v"(mxp_[1]));                                       \
+                    } else if (s_ == 4) {                                                                      \
+                        /* S(t+1) is relative to m_run already: its row max IS the excess over the running maximum. \
+                           Deferred rescale: only past rescale_thr<T>() (then all lanes move, each to its own maximum). */ \
+                        float mx0_, mx1_;                                                                      \
+                        W4_SWAPMAX(mxp_[0], mx0_)                                                              \
+                        W4_SWAPMAX(mxp_[1], mx1_)                                                              \
+                        resc_ = __any(fmx(mx0_, mx1_) > rescale_thr<T>());                                          \
+                        if (__builtin_expect(resc_, 0)) {                                                      \
+                            const float mx_[2] = {mx0_, mx1_};                                                 \
+                            _Pragma("unroll") for (int q2_ = 0; q2_ < 2; ++q2_) {                              \
+                                const float mn_ = T::to_f32(T::from_f32(m_run[q2_] + fmx(mx_[q2_], 0.f)));     \
+                                dm_[q2_] = mn_ - m_run[q2_];                                                   \
+                                m_run[q2_] = mn_;                                                              \
+                                mneg[q2_][0] = h == 0 ? (uint32_t)T::from_f32(-mn_) : 0u;                      \
+                                _Pragma("unroll") for (int kh_ = 0; kh_ < 2; ++kh_)                            \
+                                    _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) SN_[q2_][kh_][j_] -= dm_[q2_]; \
+                            }                                                                                  \
+                        }                                                                                      \
+                    } else if (s_ < 10) {       /* 32 exp2 of sub-block 0 over slices 5..31: two in 5..9, then one */ \
+                        W4_EXP1(SN_, 0, 2 * (s_ - 5), psn_, pendn_)                                            \
+                        W4_EXP1(SN_, 0, 2 * (s_ - 5) + 1, psn_, pendn_)                                        \
+                    } else {                                                                                   \
+                        W4_EXP1(SN_, 0, s_, psn_, pendn_)                                                      \
+                    }                                                                                          \
+                }                                                                                              \
+                W4_FENCE                                                                                       \
+            }                                                                                                  \
+        }                                                                                                      \
+        /* the O / l side of a rescale, between tiles (after the last P(t).V(t) product) */                    \
+        if (has_next_) {                                                                                       \
+            if (__builtin_expect(resc_, 0)) {                                                                  \
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       /* MFMA writes of O -> vector reads */ \
+                _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) {                                          \
+                    const float alpha_ = __builtin_amdgcn_exp2f(-dm_[qs_]);                                    \
+                    l_run[qs_] *= alpha_;                                                                      \
+                    w4_o_scale(qs_, alpha_);                                                                   \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        psum0 = psn_ + pendn_;                                                                                 \
+        W4_FENCE                                                                                               \
+        W4_STAMP(ts5)                                                                                          \
+        W4_STAMP_ACC                                                                                           \
+    }
+
+    // ---- the same tile without the fold (FOLD = false): 32 + 32 MFMA slices, c.s - m by v_fma one slice ahead ----
+#define W4_TILE_N(SC_, SN_, TT_, PAR_, HN_)                                                                      \
     {                                                                                                          \
         const int t_ = (TT_);                                                                                  \
         constexpr bool has_next_ = (HN_);                                                                      \
@@ -404,7 +568,7 @@ void attn_w4_kernel(const AttnParams p) {
                         W4_SWAPMAX(mxp_[1], mx1_)                                                              \
                         m_new_[0] = fmx(m_run[0], mx0_ * c2);                                                  \
                         m_new_[1] = fmx(m_run[1], mx1_ * c2);                                                  \
-                        if (!__any(fmx(m_new_[0] - m_run[0], m_new_[1] - m_run[1]) > kRescaleThr)) {           \
+                        if (!__any(fmx(m_new_[0] - m_run[0], m_new_[1] - m_run[1]) > rescale_thr<T>())) {           \
                             m_new_[0] = m_run[0];                                                              \
                             m_new_[1] = m_run[1];                                                              \
                         }                                                                                      \
@@ -448,6 +612,7 @@ void attn_w4_kernel(const AttnParams p) {
 #define W4_STAMP_ACC
 #endif
     // tiles 0 .. nt-2 have a successor (two per trip: the S buffers and the ring slots swap roles); the last one does not
+#define W4_TILE(A_, B_, T_, P_, H_) if constexpr (FOLD) { W4_TILE_F(A_, B_, T_, P_, H_) } else { W4_TILE_N(A_, B_, T_, P_, H_) }
     int t = 0;
     for (; t + 2 < nt; t += 2) {
         W4_TILE(sa, sb, t, 0, true)
@@ -507,16 +672,16 @@ void attn_w4_kernel(const AttnParams p) {
   }   // piece
 }
 
-template <typename T>
+template <typename T, bool FOLD>
 int launch_w4(const AttnParams& p, hipStream_t st) {
     static FinoPerDeviceOnce once_a, once_b;
-    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_w4_kernel<T, 0>), kW4Smem, "fino_attn_fwd")) return rc;
-    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_w4_kernel<T, 1>), kW4Smem, "fino_attn_fwd")) return rc;
+    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_w4_kernel<T, 0, FOLD>), kW4Smem, "fino_attn_fwd")) return rc;
+    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_w4_kernel<T, 1, FOLD>), kW4Smem, "fino_attn_fwd")) return rc;
     const dim3 grid((unsigned)(8 * (p.full_x + p.nwg)));
     if (p.lk > 1024)
-        attn_w4_kernel<T, 0><<<grid, kW4Threads, kW4Smem, st>>>(p);
+        attn_w4_kernel<T, 0, FOLD><<<grid, kW4Threads, kW4Smem, st>>>(p);
     else
-        attn_w4_kernel<T, 1><<<grid, kW4Threads, kW4Smem, st>>>(p);
+        attn_w4_kernel<T, 1, FOLD><<<grid, kW4Threads, kW4Smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -525,5 +690,7 @@ int launch_w4(const AttnParams& p, hipStream_t st) {
 
 // the main launch only: p carries the tail-split plan (full_x, rem_x, nwg, per) / all_partial; the caller runs the combine
 int fino_attn_launch_w4(const AttnParams& p, int dtype, hipStream_t st) {
-    return dtype == FINO_BF16 ? launch_w4<BF16>(p, st) : launch_w4<F16>(p, st);
+    // scale * log2(e) == 1 exactly <=> the caller said FINO_ATTN_SCALE_FOLDED: q carries the softmax scale already
+    if (p.scale_log2 == 1.0f) return dtype == FINO_BF16 ? launch_w4<BF16, true>(p, st) : launch_w4<F16, true>(p, st);
+    return dtype == FINO_BF16 ? launch_w4<BF16, false>(p, st) : launch_w4<F16, false>(p, st);
 }

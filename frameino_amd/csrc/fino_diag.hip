@@ -1,0 +1,75 @@
+// Diagnostics (never on the product path): what the chip sustains when NOTHING but the matrix pipe works.
+// fino_diag_mfma_peak: every wave issues `iters` x 16 independent v_mfma_f32_32x32x16_bf16 (or 16x16x32) from registers,
+// 1 or 2 waves per SIMD on every CU -- the dense MFMA rate under the board's power cap, i.e. the ceiling any
+// MFMA-bound kernel of this library can be compared with (tools/mfma_peak.py).
+#include "fino_common.h"
+
+namespace {
+
+template <int KIND>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+    // operands from the caller's buffer (zeros, small integers or gaussian noise: the power drawn -- and under the cap
+    // the clock -- depends on how many operand bits toggle)
+    bf16x8_t a, b;
+    {
+        const uint4 ua = reinterpret_cast<const uint4*>(out)[16 + threadIdx.x];
+        const uint4 ub = reinterpret_cast<const uint4*>(out)[16 + 256 + threadIdx.x];
+        a = __builtin_bit_cast(bf16x8_t, ua);
+        b = __builtin_bit_cast(bf16x8_t, ub);
+    }
+    float s = 0.f;
+    if constexpr (KIND == 0) {
+        f32x16_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += acc[t][j];
+    } else {
+        f32x4_t acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[t][j];
+    }
+    if (s == 12345.678f) out[0] = s;          // keep the accumulators alive
+}
+
+}  // namespace
+
+// kind 0: 32x32x16 (16 per iteration), kind 1: 16x16x32 (32 per iteration); both = 524288 FLOP per wave-iteration.
+// scratch: >= 256 B + 2 x 256 x 16 B; bytes 256.. hold the A and B operands of the 256 lanes (caller-filled).
+// blocks of 256 threads (one wave per SIMD); waves_per_simd in {1, 2} -> blocks = CUs * waves_per_simd.  Returns the FLOPs
+// launched in *flops.
+extern "C" int fino_diag_mfma_peak(int kind, int waves_per_simd, int iters, void* scratch, double* flops, void* stream) {
+    FINO_CHECK((kind == 0 || kind == 1) && (waves_per_simd == 1 || waves_per_simd == 2) && iters > 0 && scratch && flops,
+               FINO_ERR_ARG, "fino_diag_mfma_peak: bad arguments");
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fino_current_device()) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int blocks = cus * waves_per_simd;
+    if (kind == 0)
+        mfma_peak_kernel<0><<<blocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
+    else
+        mfma_peak_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
+    FINO_LAUNCH_CHECK();
+    *flops = (double)blocks * 4.0 * (double)iters * 524288.0;
+    return FINO_OK;
+}

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint1
                                                                            const uint16_t* __restrict__ w, float eps,
                                                                            const float* __restrict__ cos_t,
                                                                            const float* __restrict__ sin_t,
-                                                                           int head_dim) {
+                                                                           int head_dim, float out_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -209,6 +209,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint1
                 o[2 * j + 1] = x1 * ss[j] + x2 * cc[j];
             }
         }
+        // fino_rmsnorm_rope_scaled: the fp32 result times out_scale, rounded ONCE (1.0f: the plain op, bit for bit)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= out_scale;
         EW_STORE(x + row * ldx + c, pack8<T>(o));
     }
 }
@@ -590,10 +593,12 @@ static int gated_residual_impl(const void* x, const void* y, void* out, int64_t 
     return FINO_OK;
 }
 
-extern "C" int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
-                                 const float* cos_t, const float* sin_t, int head_dim, int dtype, void* stream) {
+extern "C" int fino_rmsnorm_rope_scaled(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                                        const float* cos_t, const float* sin_t, int head_dim, float out_scale, int dtype,
+                                        void* stream) {
     CHECK_ROWS_DIM("fino_rmsnorm_rope");
     FINO_CHECK(x, FINO_ERR_ARG, "fino_rmsnorm_rope: null pointer");
+    FINO_CHECK(out_scale > 0.f, FINO_ERR_ARG, "fino_rmsnorm_rope_scaled: out_scale must be > 0");
     FINO_CHECK((cos_t == nullptr) == (sin_t == nullptr), FINO_ERR_ARG, "fino_rmsnorm_rope: cos/sin must both be set");
     FINO_CHECK(!cos_t || (head_dim > 0 && head_dim % 8 == 0 && dim % head_dim == 0), FINO_ERR_ARG,
                "fino_rmsnorm_rope: head_dim=%d must divide dim=%d and be a multiple of 8", head_dim, dim);
@@ -606,14 +611,21 @@ extern "C" int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, co
         constexpr int NP = decltype(np)::value;
         if (dtype == FINO_BF16)
             rmsnorm_rope_kernel<BF16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx,
-                                                                  (const uint16_t*)weight, eps, cos_t, sin_t, head_dim);
+                                                                  (const uint16_t*)weight, eps, cos_t, sin_t, head_dim,
+                                                                  out_scale);
         else
             rmsnorm_rope_kernel<F16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx,
-                                                                 (const uint16_t*)weight, eps, cos_t, sin_t, head_dim);
+                                                                 (const uint16_t*)weight, eps, cos_t, sin_t, head_dim,
+                                                                  out_scale);
     });
     FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "fino_rmsnorm_rope: dim %d > %d unsupported", dim, kMaxPasses * 512);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
+}
+
+extern "C" int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                                 const float* cos_t, const float* sin_t, int head_dim, int dtype, void* stream) {
+    return fino_rmsnorm_rope_scaled(x, rows, dim, ldx, weight, eps, cos_t, sin_t, head_dim, 1.0f, dtype, stream);
 }
 
 extern "C" int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx,

@@ -134,14 +134,19 @@ def gated_residual(x, y, gate=None, sel=None, out=None, staged=False):
     return out.view(x.shape) if out.shape != x.shape and out.numel() == x.numel() else out
 
 
-def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0):
-    """In place on the row-strided view x [rows, D] (e.g. the q or k column block of a fused QKV buffer)."""
+SCALE_FOLDED = -1.0     # FINO_ATTN_SCALE_FOLDED: q already carries softmax_scale * log2(e) (rmsnorm_rope_(out_scale=...))
+LOG2E = 1.4426950408889634
+
+
+def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0, out_scale=1.0):
+    """In place on the row-strided view x [rows, D] (e.g. the q or k column block of a fused QKV buffer).
+    out_scale: multiplies the fp32 result before its one rounding (q for attention(scale=SCALE_FOLDED))."""
     x2, rows, dim, ldx = _rows2d(x)
     if cos is not None:
         assert cos.dtype == torch.float32 and cos.is_contiguous() and cos.shape == (rows, head_dim // 2)
         assert sin.dtype == torch.float32 and sin.is_contiguous() and sin.shape == cos.shape
-    _lib.check(_lib.lib().fino_rmsnorm_rope(_p(x2), rows, dim, ldx, _p(weight), eps, _p(cos), _p(sin), head_dim,
-                                           _dt(x), _stream()), "fino_rmsnorm_rope")
+    _lib.check(_lib.lib().fino_rmsnorm_rope_scaled(_p(x2), rows, dim, ldx, _p(weight), eps, _p(cos), _p(sin), head_dim,
+                                                  float(out_scale), _dt(x), _stream()), "fino_rmsnorm_rope")
     return x
 
 

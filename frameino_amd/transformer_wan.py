@@ -141,6 +141,10 @@ class WanTransformer3DModel(nn.Module):
         self.parallel = None      # frameino_amd.parallel.TokenShard or None
         self._fp8 = {}            # (layer, linear) -> (e4m3 weight bytes, MX scales); see enable_mxfp8_linears
         self.dedup_shared_prefix = True   # A/B knob: CFG-batched call computes the branch-invariant prefix once
+        # q of the self-attention leaves its norm + RoPE kernel already multiplied by head_dim**-0.5 * log2(e) (fp32, one
+        # rounding) and the attention kernels take q.k as the exp2 argument (FINO_ATTN_SCALE_FOLDED): no per-logit
+        # scale-and-subtract in the softmax.  False: q as the reference rounds it, scale applied to the logits.
+        self.fold_softmax_scale = True
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -431,6 +435,9 @@ class WanTransformer3DModel(nn.Module):
         x = ws.x[:nr]
         o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=x[:n] if shared else x)
         nrm, att, q2, ff = ws.n[:nr], ws.att[:nr], ws.q2[:nr], ws.ff[:nr]
+        fold = self.fold_softmax_scale and hasattr(o, "SCALE_FOLDED")
+        qfold = {"out_scale": dh ** -0.5 * o.LOG2E} if fold else {}
+        afold = {"scale": o.SCALE_FOLDED} if fold else {}
         yield
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
@@ -449,10 +456,10 @@ class WanTransformer3DModel(nn.Module):
                 n1, q1, sel1 = nrm[:n], ws.qkv[:n], (None if sel is None else sel[:n])
                 o.adaln_modulate(x[:n], m[:, 0], m[:, 1], sel1, cfg.eps, out=n1)
                 self._lin(li, "qkv", n1, e.wqkv, e.bqkv, out=q1)
-                o.rmsnorm_rope_(q1[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos1, sin1, dh)
+                o.rmsnorm_rope_(q1[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos1, sin1, dh, **qfold)
                 o.rmsnorm_rope_(q1[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos1, sin1, dh)
                 q3 = q1.view(1, n, 3 * d)
-                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att[:n].view(1, n, d))
+                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att[:n].view(1, n, d), **afold)
                 self._lin(li, "out", att[:n], blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x[:n], gate=m[:, 2], sel=sel1, out=x[:n])
                 for bi in range(1, b):
@@ -460,10 +467,10 @@ class WanTransformer3DModel(nn.Module):
             elif sh is None:
                 qkv = ws.qkv[:nr]
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
-                o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
+                o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
                 o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                 q3 = qkv.view(b, n, 3 * d)
-                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d))
+                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
             else:
                 # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
@@ -471,27 +478,27 @@ class WanTransformer3DModel(nn.Module):
                 o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                 kv_all, work = sh.all_gather_kv(kv_loc)
                 self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
-                o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh)
+                o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
                 if getattr(sh, "overlap_local", False):
                     # local keys first -- nothing of it waits for the wire -- then what the gather delivered before /
                     # after the own chunk; the (O, m, l) partials are merged (same softmax up to fp32 summation order)
                     qv = q2.view(1, n, d)
                     pf = o.attention_partial_floats(1, heads, n, dh) if hasattr(o, "attention_partial_floats") else 0
                     parts = [o.attention_partial(qv, kv_loc[:n, :d][None], kv_loc[:n, d:][None], heads,
-                                                 out=sh.partial_buf(0, pf, dev))]
+                                                 out=sh.partial_buf(0, pf, dev), **afold)]
                     if work is not None:
                         work.wait()
                     kv3 = kv_all.view(1, -1, 2 * d)
                     for pi, (k0, k1) in enumerate(((0, lo), (lo + lpad, L))):
                         if k1 > k0:
                             parts.append(o.attention_partial(qv, kv3[:, k0:k1, :d], kv3[:, k0:k1, d:], heads,
-                                                             out=sh.partial_buf(1 + pi, pf, dev)))
+                                                             out=sh.partial_buf(1 + pi, pf, dev), **afold))
                     o.attention_merge(parts, 1, n, heads, dh, dt, out=att.view(1, n, d))
                 else:
                     if work is not None:
                         work.wait()
                     kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
-                    o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d))
+                    o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d), **afold)
             if default_procs and not once:
                 self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x, gate=m[:, 2], sel=sel, out=x)

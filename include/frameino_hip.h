@@ -82,6 +82,11 @@ int fino_layernorm_zero(const void* x, void* y, int64_t rows, int dim, int64_t l
  * weight == NULL skips the norm (RoPE only). */
 int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
                       const float* cos_t, const float* sin_t, int head_dim, int dtype, void* stream);
+/* The same with the fp32 result multiplied by out_scale before its ONE rounding to T: q prepared with
+ * out_scale = softmax_scale * log2(e) goes to the attention kernels with scale = FINO_ATTN_SCALE_FOLDED. */
+int fino_rmsnorm_rope_scaled(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                             const float* cos_t, const float* sin_t, int head_dim, float out_scale, int dtype,
+                             void* stream);
 
 /* Per-head LayerNorm(head_dim, affine) + RoPE on rows >= rope_row0 of every batch element (CogVideoX):
  * architecture/attention_processor.py:2851-2860.  x is [batch, rows, heads*head_dim] with row stride ldx.
@@ -96,7 +101,11 @@ int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim
  * Element (b, row, h, d) of X lives at X + b*x_bs + row*x_rs + h*x_hs + d  (strides in ELEMENTS; d contiguous),
  * so q/k/v can be column slices of one fused-QKV GEMM output and o is written token-major [L, H*Dh].
  * head_dim in {64, 128}.  Replaces F.scaled_dot_product_attention at transformer_wan.py:108,
- * attention_processor.py:2863, :2934. */
+ * attention_processor.py:2863, :2934.
+ * scale = FINO_ATTN_SCALE_FOLDED (in every fino_attn_* entry point): q already carries softmax_scale * log2(e)
+ * (fino_rmsnorm_rope_scaled writes it that way, one rounding instead of two), so the kernels take q.k as the exp2
+ * argument as it is -- and the head_dim-128 4-wave kernel folds the running maximum into its MFMAs. */
+#define FINO_ATTN_SCALE_FOLDED (-1.0f)
 int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
                   int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs,
                   int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs,
@@ -306,6 +315,13 @@ int fino_avg_pool_time2(const void* x, void* y, int t_in, int h, int w, int c_pa
 int fino_resize_area_pad_u8(const void* src, void* dst, int src_h, int src_w, int region_h, int region_w, int out_h,
                             int out_w, int off_y, int off_x, int fill, void* stream);
 int fino_u8_hwc_to_chw_unit(const void* src, float* dst, int height, int width, void* stream);
+
+/* ---- diagnostics (tools/ only) --------------------------------------------------------------------------------
+ * Dense MFMA rate with nothing else running: `iters` x 16 independent 32x32x16 (kind 0) / 32 independent 16x16x32
+ * (kind 1) bf16 MFMAs per wave from registers, waves_per_simd in {1, 2} on every SIMD of the device.  *flops = FLOPs
+ * launched; time it with events.  What the board sustains under its power cap -- the ceiling of every MFMA-bound
+ * kernel here. */
+int fino_diag_mfma_peak(int kind, int waves_per_simd, int iters, void* scratch, double* flops, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,8 @@
 collective logic of frameino_amd/parallel.py where no GPU exists.  Each function restates the operator contract
 of include/frameino_hip.h in plain torch (same semantics as the references in tests/test_kernels_gpu.py).
 It is test infrastructure: the product never imports it."""
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -32,7 +34,11 @@ def gated_residual(x, y, gate=None, sel=None, out=None):
     return r if out is None else out.copy_(r)
 
 
-def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0):
+SCALE_FOLDED = -1.0
+LOG2E = 1.4426950408889634
+
+
+def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0, out_scale=1.0):
     y = x
     if weight is not None:
         var = x.float().pow(2).mean(-1, keepdim=True)
@@ -49,7 +55,7 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0):
         o[..., 0] = x1 * c - x2 * s
         o[..., 1] = x1 * s + x2 * c
         y = o.reshape(rows, dim)
-    x.copy_(y.to(x.dtype))
+    x.copy_((y * out_scale).to(x.dtype) if out_scale != 1.0 else y.to(x.dtype))
     return x
 
 
@@ -57,7 +63,9 @@ def attention(q, k, v, heads, out=None, scale=None):
     b, lq, hd = q.shape
     dh = hd // heads
     f = lambda t: t.reshape(b, -1, heads, dh).transpose(1, 2)      # noqa: E731
-    o = F.scaled_dot_product_attention(f(q), f(k), f(v)).transpose(1, 2).reshape(b, lq, hd).to(q.dtype)
+    # SCALE_FOLDED: q carries softmax_scale * log2(e); softmax(ln2 * q.k) = 2^(q.k) normalised
+    sc = math.log(2.0) if scale == SCALE_FOLDED else scale
+    o = F.scaled_dot_product_attention(f(q), f(k), f(v), scale=sc).transpose(1, 2).reshape(b, lq, hd).to(q.dtype)
     return o if out is None else out.copy_(o)
 
 
@@ -66,7 +74,7 @@ def attention_partial(q, k, v, heads, out=None, scale=None):
     b, lq, hd = q.shape
     dh = hd // heads
     f = lambda t: t.reshape(b, -1, heads, dh).transpose(1, 2).float()      # noqa: E731
-    s_ = f(q) @ f(k).transpose(2, 3) * (dh ** -0.5 if scale is None else scale)
+    s_ = f(q) @ f(k).transpose(2, 3) * (dh ** -0.5 if scale is None else math.log(2.0) if scale == SCALE_FOLDED else scale)
     m = s_.amax(dim=-1, keepdim=True)
     p_ = torch.exp(s_ - m)
     return p_ @ f(v), m, p_.sum(dim=-1, keepdim=True)

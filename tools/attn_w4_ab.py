@@ -25,15 +25,17 @@ def ref(q, k, v, heads):
 for (b, heads, lq, lk, qscale) in [(1, 2, 64, 64, 1.0), (1, 2, 300, 500, 1.0), (2, 3, 257, 129, 1.0), (1, 8, 1000, 77, 1.0),
                                    (1, 2, 513, 2000, 8.0), (2, 24, 1024, 1024, 1.0)]:
     d = heads * 128
-    q = (torch.randn(b, lq, d, device=dev, generator=g) * qscale).bfloat16()
+    qf = torch.randn(b, lq, d, device=dev, generator=g) * qscale          # "fp32 q" as the norm + RoPE kernel holds it
+    q = qf.bfloat16()
+    qs = (qf * (128 ** -0.5 * ops.LOG2E)).bfloat16()                        # what rmsnorm_rope_(out_scale=...) writes
     kv = torch.randn(b, lk, 2 * d, device=dev, generator=g).bfloat16()
     k, v = kv[:, :, :d], kv[:, :, d:]
-    lib.fino_tune_set(KEY, 1); o1 = ops.attention(q, k, v, heads)
-    lib.fino_tune_set(KEY, 2); o2 = ops.attention(q, k, v, heads)
+    lib.fino_tune_set(KEY, 1); o1 = ops.attention(q, k, v, heads); o1f = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
+    lib.fino_tune_set(KEY, 2); o2 = ops.attention(q, k, v, heads); o2f = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
     lib.fino_tune_set(KEY, 0)
-    r = ref(q, k, v, heads)
-    print(f"B{b} H{heads} Lq{lq} Lk{lk} qx{qscale}: w8 vs fp32 {rel(o1, r):.5f}  w4 vs fp32 {rel(o2, r):.5f}  w4 vs w8 {rel(o2, o1):.5f}"
-          f"  finite {bool(torch.isfinite(o2.float()).all())}", flush=True)
+    r = ref(qf, k, v, heads)
+    print(f"B{b} H{heads} Lq{lq} Lk{lk} qx{qscale} vs SDPA(fp32 q): w8 {rel(o1, r):.5f}  w8 folded-scale {rel(o1f, r):.5f}  "
+          f"w4 {rel(o2, r):.5f}  w4 folded-scale (MFMA fold) {rel(o2f, r):.5f}  finite {bool(torch.isfinite(o2f.float()).all())}", flush=True)
 
 # partials over key ranges + merge through the 4-wave kernel
 for (b, heads, lq, splits) in [(2, 3, 300, (0, 64, 500)), (1, 24, 3080, (0, 3080, 6160, 12320))]:
@@ -55,17 +57,20 @@ for (b, heads, L, lkv) in [(2, 24, 12288, 0), (2, 24, 12320, 0), (1, 24, 12320, 
     qkv = torch.randn(b, max(L, lkv), 3 * d, device=dev, generator=g).bfloat16()
     q, k, v = qkv[:, :L, :d], qkv[:, :lkv, d:2 * d], qkv[:, :lkv, 2 * d:]
     out = torch.empty(b, L, d, device=dev, dtype=torch.bfloat16)
-    t = {1: [], 2: []}
-    for kk in (1, 2):
-        lib.fino_tune_set(KEY, kk); ops.attention(q, k, v, heads, out=out)
+    qsc = (q.float() * (128 ** -0.5 * ops.LOG2E)).bfloat16()      # the folded-scale runs get q pre-multiplied, as the model does
+    t = {1: [], 2: [], 3: []}
+    runs = {1: (1, None), 2: (2, None), 3: (2, ops.SCALE_FOLDED)}
+    for kk, (tk, sc) in runs.items():
+        lib.fino_tune_set(KEY, tk); ops.attention(q if sc is None else qsc, k, v, heads, out=out, scale=sc)
     for _ in range(5):
-        for kk in (1, 2):
-            lib.fino_tune_set(KEY, kk)
+        for kk, (tk, sc) in runs.items():
+            lib.fino_tune_set(KEY, tk)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            for _ in range(3): ops.attention(q, k, v, heads, out=out)
+            for _ in range(3): ops.attention(q if sc is None else qsc, k, v, heads, out=out, scale=sc)
             e.record(); torch.cuda.synchronize(); t[kk].append(s.elapsed_time(e) / 3 * 1e3)
     lib.fino_tune_set(KEY, 0)
     fl = 4.0 * b * heads * L * lkv * 128
-    a, c = statistics.median(t[1]), statistics.median(t[2])
-    print(f"B{b} H{heads} Lq{L} Lk{lkv}: w8 {a:8.1f} us {fl / a / 1e6:6.0f} TF   w4 {c:8.1f} us {fl / c / 1e6:6.0f} TF", flush=True)
+    a, c, f3 = statistics.median(t[1]), statistics.median(t[2]), statistics.median(t[3])
+    print(f"B{b} H{heads} Lq{L} Lk{lkv}: w8 {a:8.1f} us {fl / a / 1e6:6.0f} TF   w4 {c:8.1f} us {fl / c / 1e6:6.0f} TF   "
+          f"w4 folded scale {f3:8.1f} us {fl / f3 / 1e6:6.0f} TF", flush=True)

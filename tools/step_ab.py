@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of whole denoise steps (the bench workload) under switches that do not change results:
-GEMM raster group height (r01's fixed 4 vs the per-shape default) and the branch-invariant prefix computed once.
+GEMM raster group height (r01's fixed 4 vs the per-shape default), the branch-invariant prefix computed once, the 4-wave
+attention kernel and the softmax scale folded into q.
 Interleaved rounds in one process, median ms/step.  GPU box only."""
 import os
 import statistics
@@ -11,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from frameino_amd import _lib  # noqa: E402
+from frameino_amd import _lib, ops  # noqa: E402
 from frameino_amd.configs import WAN22_5B_CFG  # noqa: E402
 from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline  # noqa: E402
 from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler  # noqa: E402
@@ -34,26 +35,39 @@ st = pipe.make_state(lat, cond, traj, idl, mask, pe, ne, 5.0)
 st.t_rows[1:2].copy_(pipe.scheduler.timesteps[10:11].float())
 st.dt.copy_(pipe.scheduler.dts[10:11])
 lib = _lib.lib()
-settings = {"r01 (group_m 4, no dedup)": (4, False), "group_m per shape": (0, False), "+ shared prefix once": (0, True)}
+# (GEMM group_m, shared prefix once, attention kernel tune [1 = 8-wave, 0 = policy: 4-wave at this shape], folded scale)
+settings = {"r01 (group_m 4, no dedup, 8-wave attention)": (4, False, 1, False),
+            "group_m per shape": (0, False, 1, False), "+ shared prefix once": (0, True, 1, False),
+            "+ 4-wave attention kernel": (0, True, 0, False), "+ softmax scale folded into q (MFMA fold)": (0, True, 0, True)}
 res = {k: [] for k in settings}
 
 
-def run(gm, dedup, steps):
+attn = {}
+
+
+def run(gm, dedup, attn_k, fold, steps):
     lib.fino_tune_set(0, gm)
+    lib.fino_tune_set(4, attn_k)
+    model.fold_softmax_scale = fold
     model.dedup_shared_prefix = dedup
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    with torch.no_grad():
+    with torch.no_grad(), ops.KernelTimer({"attn_self"}) as kt:
         for _ in range(steps):
             pipe._step(st)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    attn.setdefault((gm, dedup, attn_k, fold), []).append(kt.summary()["attn_self"]["total_ms"] / steps)
+    return ms
 
 
-for k, (gm, dd) in settings.items():
-    run(gm, dd, 2)
+for k, a in settings.items():
+    run(*a, 2)
 for rnd in range(5):
-    for k, (gm, dd) in settings.items():
-        res[k].append(run(gm, dd, 3))
+    for k, a in settings.items():
+        res[k].append(run(*a, 3))
 lib.fino_tune_set(0, 0)
+lib.fino_tune_set(4, 0)
 for k, v in res.items():
-    print(f"{k:32s} median {statistics.median(v):7.2f} ms/step  (min {min(v):.2f}, max {max(v):.2f})")
+    a_ms = statistics.median(attn[settings[k]][1:])
+    print(f"    self-attention launches {a_ms:7.2f} ms/step, everything else {statistics.median(v) - a_ms:7.2f}")
+    print(f"{k:44s} median {statistics.median(v):7.2f} ms/step  (min {min(v):.2f}, max {max(v):.2f})")
