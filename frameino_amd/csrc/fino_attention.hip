@@ -887,10 +887,14 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     if (p.all_partial) sp = SplitPlan{groups * p.nqb, 0, 0, 1};       // no tail split: every block is a partial anyway
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
-    // head_dim 128: the 4-wave kernel wins on long rows of many blocks (its block prologue is the heavier one: Lq 3080 x
-    // Lk 12320 on 312 blocks 967 vs 1008 TFLOP/s, text cross-attention Lk 512 570 vs 650; 12320^2 x 48 heads 1158 vs 1131)
-    const int tune_k = fino_tune_get(FINO_TUNE_ATTN_KERNEL);                 // A/B: 1 = 8-wave, 2 = 4-wave
-    const bool w4 = D == 128 && (tune_k == 2 || (tune_k == 0 && p.lk >= 4096 && (int64_t)groups * p.nqb * 8 >= 3 * device_cus()));
+    // head_dim 128 has two kernels.  Standalone the 4-wave one is the faster on long rows of many blocks (B = 2, 24 heads,
+    // 12320^2: 1169 vs 1150 TFLOP/s, 1212 with the MFMA fold; tools/attn_w4_ab.py) and the slower on short ones (its block
+    // prologue is the heavier: Lq 3080 x Lk 12320 967 vs 1008, text cross-attention 570 vs 650).  INSIDE the denoise step,
+    // which runs at the board's power cap from first to last kernel (tools/power_probe.py), the two tie within noise
+    // (self-attention launches 97.1 vs 97.1 ms per step, tools/step_ab.py): the default stays the 8-wave kernel, the
+    // 4-wave one is FINO_TUNE_ATTN_KERNEL = 2.
+    const int tune_k = fino_tune_get(FINO_TUNE_ATTN_KERNEL);
+    const bool w4 = D == 128 && tune_k == 2;
     if (w4) {
         if (int rc = fino_attn_launch_w4(p, T::kId, st)) return rc;
     } else if (pingpong)

@@ -141,10 +141,11 @@ class WanTransformer3DModel(nn.Module):
         self.parallel = None      # frameino_amd.parallel.TokenShard or None
         self._fp8 = {}            # (layer, linear) -> (e4m3 weight bytes, MX scales); see enable_mxfp8_linears
         self.dedup_shared_prefix = True   # A/B knob: CFG-batched call computes the branch-invariant prefix once
-        # q of the self-attention leaves its norm + RoPE kernel already multiplied by head_dim**-0.5 * log2(e) (fp32, one
-        # rounding) and the attention kernels take q.k as the exp2 argument (FINO_ATTN_SCALE_FOLDED): no per-logit
-        # scale-and-subtract in the softmax.  False: q as the reference rounds it, scale applied to the logits.
-        self.fold_softmax_scale = True
+        # True: q of the self-attention leaves its norm + RoPE kernel already multiplied by head_dim**-0.5 * log2(e) (fp32,
+        # one rounding) and the attention kernels take q.k as the exp2 argument (FINO_ATTN_SCALE_FOLDED), which lets the
+        # 4-wave kernel fold the running maximum into its MFMAs.  False (default): q rounded where the reference rounds it,
+        # scale applied to the logits -- inside the power-capped step the fold buys nothing.
+        self.fold_softmax_scale = False
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property

@@ -38,7 +38,7 @@ const char* fino_last_error(void);
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
  * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
  * ping-pong one.  FINO_TUNE_GEMM_STREAM_K: 1 = never use the stream-K tail of fino_gemm_ws, 2 = whenever legal.
- * FINO_TUNE_ATTN_KERNEL (head_dim 128): 1 = the 8-wave ping-pong kernel, 2 = the 4-wave one-wave-per-SIMD kernel. */
+ * FINO_TUNE_ATTN_KERNEL (head_dim 128): 2 = the 4-wave one-wave-per-SIMD kernel instead of the 8-wave ping-pong one. */
 enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_STREAM_K = 3,
        FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);

@@ -429,3 +429,95 @@ def test_attention_partials_over_key_ranges_merge_to_the_full_attention(heads, d
     assert rel_rms(merged, full.float()) < 2.0 ** -8, rel_rms(merged, full.float())
     one = ops.attention_merge([ops.attention_partial(q, k, v, heads)], 2, lq, heads, dh, q.dtype)
     assert rel_rms(one, full.float()) < 2.0 ** -9
+
+
+def _sdpa_f32(q, k, v, heads, scale=None):
+    b, lq, d = q.shape
+    dh = d // heads
+    f = lambda t: t.view(b, -1, heads, dh).transpose(1, 2).float()      # noqa: E731
+    return torch.nn.functional.scaled_dot_product_attention(f(q), f(k), f(v), scale=scale).transpose(1, 2).reshape(b, lq, d)
+
+
+@pytest.mark.parametrize("b,heads,lq,lk", [(1, 2, 64, 64), (2, 3, 257, 129), (1, 2, 300, 500), (1, 8, 1000, 77),
+                                           (2, 24, 1024, 1024), (1, 24, 2000, 4500)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_four_wave_attention_kernel_and_folded_scale(b, heads, lq, lk, dtype):
+    """FINO_TUNE_ATTN_KERNEL = 2 (fino_attention_w4.hip): whole blocks, ragged last tile, tail split, and the
+    FINO_ATTN_SCALE_FOLDED path (q pre-multiplied by scale * log2(e), running maximum folded into the MFMAs), each against
+    fp32 SDPA on the q it was given (tolerance 2^-8 relative RMS); the folded q is ONE rounding of the fp32 q like the plain
+    one, so both are equally far from SDPA on the un-rounded q."""
+    from frameino_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    d = heads * 128
+    qf = torch.randn(b, lq, d, device=DEV, generator=g) * 2.0
+    kv = torch.randn(b, lk, 2 * d, device=DEV, generator=g).to(dtype)
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    c = 128 ** -0.5 * ops.LOG2E
+    q, qs = qf.to(dtype), (qf * c).to(dtype)                 # as rmsnorm_rope_ writes q without / with out_scale
+    ref, ref_s = _sdpa_f32(q, k, v, heads), _sdpa_f32(qs.float() / c, k, v, heads)
+    lib = _lib.lib()
+    try:
+        lib.fino_tune_set(4, 2)
+        plain = ops.attention(q, k, v, heads)
+        folded = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
+        lib.fino_tune_set(4, 0)
+        folded8 = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
+    finally:
+        lib.fino_tune_set(4, 0)
+    for name, out, want in (("4-wave", plain, ref), ("4-wave folded", folded, ref_s), ("8-wave folded", folded8, ref_s)):
+        assert torch.isfinite(out.float()).all(), name
+        assert rel_rms(out, want) < 2.0 ** -8, (name, rel_rms(out, want))
+    # and both roundings of q are equally far from the un-rounded one
+    truth = _sdpa_f32(qf, k, v, heads)
+    assert rel_rms(folded, truth) < 1.25 * rel_rms(plain, truth) + 1e-4
+
+
+def test_four_wave_partials_merge_and_peaky_rows():
+    """the 4-wave kernel's (O, m, l) partials are in the 8-wave layout: merged key ranges == one pass; and rows whose
+    maximum keeps growing by far more than the deferred-rescale threshold (keys sorted by logit) stay exact"""
+    from frameino_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    heads, lq, lk = 3, 300, 1500
+    d = heads * 128
+    q = (torch.randn(1, lq, d, device=DEV, generator=g) * 6.0).bfloat16()
+    kv = torch.randn(1, lk, 2 * d, device=DEV, generator=g).bfloat16()
+    # order the keys by their logit against query 0 of head 0: the running maximum of that row rises all the way
+    order = (kv[0, :, :128].float() @ q[0, 0, :128].float()).argsort()
+    kv = kv[:, order].contiguous()
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    ref = _sdpa_f32(q, k, v, heads)
+    lib = _lib.lib()
+    try:
+        lib.fino_tune_set(4, 2)
+        one = ops.attention(q, k, v, heads)
+        qs = (q.float() * (128 ** -0.5 * ops.LOG2E)).bfloat16()
+        fold = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
+        parts = [ops.attention_partial(q, k[:, a:c], v[:, a:c], heads) for a, c in ((0, 700), (700, 701), (701, lk))]
+        merged = ops.attention_merge(parts, 1, lq, heads, 128, q.dtype)
+    finally:
+        lib.fino_tune_set(4, 0)
+    assert rel_rms(one, ref) < 2.0 ** -8 and rel_rms(merged, ref) < 2.0 ** -8, (rel_rms(one, ref), rel_rms(merged, ref))
+    assert rel_rms(fold, _sdpa_f32(qs.float() / (128 ** -0.5 * ops.LOG2E), k, v, heads)) < 2.0 ** -8
+
+
+def test_rmsnorm_rope_out_scale_is_one_rounding():
+    from frameino_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(9)
+    rows, heads, dh = 333, 4, 128
+    d = heads * dh
+    x = torch.randn(rows, d, device=DEV, generator=g).bfloat16()
+    w = (1 + 0.1 * torch.randn(d, device=DEV, generator=g)).bfloat16()
+    ang = torch.rand(rows, dh // 2, device=DEV, generator=g) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    c = dh ** -0.5 * ops.LOG2E
+    plain = ops.rmsnorm_rope_(x.clone(), w, 1e-6, cos, sin, dh)
+    scaled = ops.rmsnorm_rope_(x.clone(), w, 1e-6, cos, sin, dh, out_scale=c)
+    # fp32 restatement of the kernel's arithmetic (same rounding points up to the RoPE, then x c, one rounding)
+    xf = x.float()
+    y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).bfloat16().float() * w.float()
+    y = y.bfloat16().float().view(rows, heads, dh // 2, 2)
+    o = torch.stack((y[..., 0] * cos[:, None] - y[..., 1] * sin[:, None], y[..., 0] * sin[:, None] + y[..., 1] * cos[:, None]), -1)
+    want = (o.reshape(rows, d) * c).bfloat16()
+    assert (scaled.float() - want.float()).abs().max() <= 2.0 ** -8 * want.float().abs().max()
+    assert (scaled != want).float().mean() < 0.02                     # a few 1-ulp flips from rsqrt / fma contraction
+    assert rel_rms(scaled.float() / c, plain.float()) < 2.0 ** -8     # and it is the plain result, scaled

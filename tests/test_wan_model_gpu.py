@@ -58,6 +58,18 @@ def test_midsize_model_vs_oracle(per_token):
     r32, rb, rr = rel_rms(out, ref32), rel_rms(out, refb), rel_rms(refb, ref32)
     print(f"hip-vs-fp32 {r32:.4f}  hip-vs-bf16-oracle {rb:.4f}  bf16-oracle-vs-fp32 {rr:.4f}")
     assert r32 < 3e-2 and rb < 1.5e-2
+    # softmax scale folded into q (one rounding of q.c instead of q; 4-wave attention kernel with the MFMA fold): as close
+    # to the fp32 oracle as the reference's rounding points are
+    from frameino_amd import _lib
+    m.fold_softmax_scale = True
+    try:
+        _lib.lib().fino_tune_set(4, 2)
+        outf = m(x.to(DEV).bfloat16(), ts.to(DEV), txt.to(DEV).bfloat16(), return_dict=False)[0]
+    finally:
+        _lib.lib().fino_tune_set(4, 0)
+    rf = rel_rms(outf, ref32)
+    print(f"folded softmax scale: hip-vs-fp32 {rf:.4f}")
+    assert rf < 3e-2 and rf < 1.3 * r32 + 2e-3
 
 
 def test_processor_plugin_standalone_and_custom_processor(golden):
