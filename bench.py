@@ -420,6 +420,9 @@ def main():
         alg_bytes = batch * 4 * L * heads * dh * 2           # Q, K, V read + O written, bf16
         roofline = {"bound": "mfma", "kernel": "attn_pp_kernel<BF16,128,0> (3D self-attention)",
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                    # what the matrix pipe ALONE sustains on gaussian operands before the board's power cap takes the
+                    # clock down (tools/mfma_peak.py, profiles/r02_mfma_peak.txt); the step runs at that cap throughout
+                    "power_capped_peak": 1870.0, "frac_of_power_capped_peak": ach / 1870.0,
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "algorithmic_bytes": alg_bytes,
                     "traffic_over_algorithmic": None if traffic is None else traffic / alg_bytes,
