@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
     vec8 qf[kKS];
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) {
-        const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);      // rows past Lq are never stored: zero operands draw the least power
         qf[ks] = __builtin_bit_cast(vec8, u);
     }
 
@@ -412,7 +413,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     vec8 qf[kKS];
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) {
-        const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);      // rows past Lq are never stored: zero operands draw the least power
         qf[ks] = __builtin_bit_cast(vec8, u);
     }
 

@@ -155,7 +155,8 @@ void attn_w4_kernel(const AttnParams p) {
         const int qc = qrow[qs] < p.lq ? qrow[qs] : p.lq - 1;
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
-            const uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qc * p.q_rs + 16 * ks + 8 * h);
+            uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qc * p.q_rs + 16 * ks + 8 * h);
+            if (qrow[qs] >= p.lq) u = make_uint4(0, 0, 0, 0);   // rows past Lq are never stored: zero operands draw the least power
             qf[qs][ks] = u32x4_t{u.x, u.y, u.z, u.w};
             asm volatile("" : "+a"(qf[qs][ks]));        // lives in AGPRs from here on (else: copied there before every MFMA)
         }
