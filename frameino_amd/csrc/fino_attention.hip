@@ -889,12 +889,10 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     if (p.all_partial) sp = SplitPlan{groups * p.nqb, 0, 0, 1};       // no tail split: every block is a partial anyway
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
-    // head_dim 128 has two kernels.  Standalone the 4-wave one is the faster on long rows of many blocks (B = 2, 24 heads,
-    // 12320^2: 1169 vs 1150 TFLOP/s, 1212 with the MFMA fold; tools/attn_w4_ab.py) and the slower on short ones (its block
-    // prologue is the heavier: Lq 3080 x Lk 12320 967 vs 1008, text cross-attention 570 vs 650).  INSIDE the denoise step,
-    // which runs at the board's power cap from first to last kernel (tools/power_probe.py), the two tie within noise
-    // (self-attention launches 97.1 vs 97.1 ms per step, tools/step_ab.py): the default stays the 8-wave kernel, the
-    // 4-wave one is FINO_TUNE_ATTN_KERNEL = 2.
+    // head_dim 128 has two kernels.  On gaussian operands the 4-wave one is the faster standalone (B = 2, 24 heads, 12320^2:
+    // 1186 vs 1166 TFLOP/s, 1253 with the MFMA fold; tools/attn_w4_ab.py).  Inside the denoise step, on the bench's own
+    // activations, rocprof says 3237 / 3070 (fold) vs 3114 us per launch for the 8-wave kernel and tools/step_ab.py a tie
+    // per step: the default stays the 8-wave kernel, the 4-wave one is FINO_TUNE_ATTN_KERNEL = 2.
     const int tune_k = fino_tune_get(FINO_TUNE_ATTN_KERNEL);
     const bool w4 = D == 128 && tune_k == 2;
     if (w4) {

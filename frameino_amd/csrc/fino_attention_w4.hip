@@ -641,7 +641,8 @@ void attn_w4_kernel(const AttnParams p) {
         if (part >= 0) {
             // same layout as the 8-wave kernel's partials: its wave 2w + qs owns these 32 query rows
             float* w = p.ws + (int64_t)part * partial_floats<D>();
-            const int tid8 = (2 * wave + qs) * 64 + lane;
+            int tid8 = (2 * wave + qs) * 64 + lane;
+            asm volatile("" : "+v"(tid8));   // opaque: or the 64 store offsets are computed before the piece loop and spilled
 #pragma unroll
             for (int dt = 0; dt < kDT; ++dt) {
                 float f[16];
