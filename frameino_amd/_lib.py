@@ -35,6 +35,8 @@ SIGNATURES = {
     "fino_diag_mfma_peak": [c_int, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_void_p],
     "fino_headnorm_rope": [c_void_p, c_int, c_i64, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p, c_float,
                            c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "fino_headnorm_rope_scaled": [c_void_p, c_int, c_i64, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p, c_float,
+                                  c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p],
     "fino_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 12 + [c_float, c_int, c_void_p],
     "fino_attn_fwd_ws": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 12 +
                         [c_float, c_int, c_void_p, c_i64, c_void_p],

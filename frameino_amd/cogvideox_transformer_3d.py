@@ -122,6 +122,11 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._fp8 = {}
+        # q leaves its LayerNorm + RoPE kernel multiplied by head_dim**-0.5 * log2(e) and the attention kernels take q.k as
+        # the exp2 argument (FINO_ATTN_SCALE_FOLDED): at head_dim 64 that selects the 4-wave kernel with the running maximum
+        # folded into its MFMAs (-5 % per step).  Video rows: one rounding of q.c instead of q; the 226 text rows (LayerNorm
+        # only, already rounded) are rounded twice.  False: q as the reference rounds it, scale applied to the logits.
+        self.fold_softmax_scale = True
         self.original_attn_processors = None
 
     # ---- reference surface (:346-444) ----
@@ -324,6 +329,9 @@ class CogVideoXTransformer3DModel(nn.Module):
         if image_rotary_emb is not None:
             cos, sin = (t.to(dev).float().contiguous() for t in image_rotary_emb)
 
+        fold = self.fold_softmax_scale and hasattr(ops, "SCALE_FOLDED")
+        qfold = {"out_scale": dh ** -0.5 * ops.LOG2E} if fold else {}
+        afold = {"scale": ops.SCALE_FOLDED} if fold else {}
         # 3. blocks (:503-529)
         for li, (blk, e) in enumerate(zip(self.transformer_blocks, pk.layers)):
             t1, t2 = tables[2 * li], tables[2 * li + 1]                              # [2B, 3, D]
@@ -331,9 +339,9 @@ class CogVideoXTransformer3DModel(nn.Module):
             if default_procs:
                 qkv = self._lin(li, "qkv", n, e.wqkv, e.bqkv).view(b, L, 3 * d)
                 nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
-                ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt)
+                ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt, **qfold)
                 ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
-                att = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads)
+                att = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads, **afold)
                 self._lin(li, "out", att.view(b * L, d), blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
                           ops.EPI_GATED_RESIDUAL_STAGED, residual=x2, gate=t1[:, 2], sel=sel, out=x2)
             else:

@@ -894,9 +894,13 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     // activations, rocprof says 3237 / 3070 (fold) vs 3114 us per launch for the 8-wave kernel and tools/step_ab.py a tie
     // per step: the default stays the 8-wave kernel, the 4-wave one is FINO_TUNE_ATTN_KERNEL = 2.
     const int tune_k = fino_tune_get(FINO_TUNE_ATTN_KERNEL);
-    const bool w4 = D == 128 && tune_k == 2;
+    // head_dim 64 (CogVideoX) is bound by the softmax's vector work, not by power: there the 4-wave kernel with the folded
+    // scale wins inside the step too (B = 2, 48 heads, L = 19126: 952 vs 858 TFLOP/s; the CogVideoX-5B step 782 -> 741 ms
+    // in bf16, 659 -> 619 with MXFP8 linears) and is the default whenever the caller folds the scale into q.
+    const bool w4 = fino_attn_w4_supports(D, p.scale_log2) &&
+                    (tune_k == 2 || (tune_k == 0 && D == 64 && p.scale_log2 == 1.0f && p.lk >= 2048));
     if (w4) {
-        if (int rc = fino_attn_launch_w4(p, T::kId, st)) return rc;
+        if (int rc = fino_attn_launch_w4(p, T::kId, D, st)) return rc;
     } else if (pingpong)
         attn_pp_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     else

@@ -68,5 +68,6 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 
 }  // namespace fino_attn_ns
 
-// 4-wave kernel (head_dim 128, whole blocks, no partials): defined in fino_attention_w4.hip
-int fino_attn_launch_w4(const fino_attn_ns::AttnParams& p, int dtype, hipStream_t st);
+// 4-wave kernel: defined in fino_attention_w4.hip (head_dim 128; head_dim 64 with the folded softmax scale only)
+bool fino_attn_w4_supports(int head_dim, float scale_log2);
+int fino_attn_launch_w4(const fino_attn_ns::AttnParams& p, int dtype, int head_dim, hipStream_t st);

@@ -33,9 +33,11 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kW4Waves = 4;
 constexpr int kW4Threads = kW4Waves * 64;
-constexpr int kW4D = 128;
-constexpr int kW4TileBytes = kKV * kW4D * 2;     // 16 KiB
-constexpr int kW4Smem = 4 * kW4TileBytes;        // K ring (2) + V ring (2)
+// slice schedules of the fold loop (phase 1 has S1 = 4 + 4 * D/16 MFMA slices, phase 2 S2 = 8 * D/32):
+constexpr int w4_s1(int d) { return 4 + 4 * (d / 16); }
+constexpr int w4_s2(int d) { return 8 * (d / 32); }
+// 32 items dealt over `n` slices in order, item e in slice e * n / 32: slice s holds items [w4_lo(s, n), w4_lo(s + 1, n))
+constexpr int w4_lo(int s, int n) { return s <= 0 ? 0 : (s >= n ? 32 : (32 * s + n - 1) / n); }
 
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
 // Between two inline-asm statements of which the second reads a register the first one writes, the hazard recogniser
@@ -85,15 +87,18 @@ __device__ __forceinline__ void w4_mfma_qk(f32x16_t& d, const u32x4_t& a, const 
 }
 
 
+// D = 128 (Wan) or 64 (CogVideoX; FOLD only).
 // FOLD: q arrives pre-multiplied by softmax_scale * log2(e) (p.scale_log2 == 1): -m is folded into the S accumulators by
 // one more MFMA product and the softmax is a bare exp2 (see the prologue).
-template <typename T, int VAR, bool FOLD>
+template <typename T, int D, int VAR, bool FOLD>
 __global__ __attribute__((amdgpu_flat_work_group_size(kW4Threads, kW4Threads), amdgpu_waves_per_eu(1, 1)))
 void attn_w4_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = kW4D;
-    constexpr int kKS = D / 16;   // 8 k-steps of QK^T
-    constexpr int kDT = D / 32;   // 4 d-tiles of O^T
+    constexpr int kKS = D / 16;   // k-steps of QK^T (8 / 4)
+    constexpr int kDT = D / 32;   // d-tiles of O^T (4 / 2)
+    constexpr int kW4TileBytes = kKV * D * 2;            // 16 / 8 KiB; LDS: K ring (2) + V ring (2)
+    constexpr int kNPW = kW4TileBytes / 1024 / kW4Waves;   // 1-KiB LDS-DMA pieces per wave and tile (4 / 2)
+    static_assert(FOLD || D == 128, "head_dim 64 is built for the folded-scale path only");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -169,31 +174,34 @@ void attn_w4_kernel(const AttnParams p) {
         (void*)kp, 0, (int)((((int64_t)lk - 1) * p.k_rs + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)vp, 0, (int)((((int64_t)lk - 1) * p.v_rs + D) * 2), 0x00020000);
-    uint32_t kvo[4], vvo[4];
+    // a piece = 1 KiB of the LDS image = 4 rows x 16 chunks (D = 128) or 8 rows x 8 chunks (D = 64); lane l lands at row
+    // l / chunks-per-row, physical chunk l % chunks-per-row and fetches the logical chunk phys ^ swizzle(row)
+    uint32_t kvo[4], vvo[4];       // (kNPW used; a template-dependent array size here silently drops the HOST instantiation)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 16 * wave + 4 * j + (lane >> 4);
-        const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | j);
+    for (int j = 0; j < kNPW; ++j) {
+        constexpr int cpr = D / 8, rpp = 1024 / (D * 2);
+        const int row = 16 * wave + rpp * j + lane / cpr;
+        const int ch = ((lds_off<D>(row, lane % cpr) - row * (D * 2)) >> 4);       // = (lane % cpr) ^ swizzle(row)
         kvo[j] = (uint32_t)((row * p.k_rs + ch * 8) * 2);
         vvo[j] = (uint32_t)((row * p.v_rs + ch * 8) * 2);
     }
     const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
     // K(t) -> slot t & 1 (bytes 0 / 16 K), V(t) -> slot 2 + (t & 1)
 #define W4_DMA_K(T_)                                                                                           \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) __builtin_amdgcn_raw_ptr_buffer_load_lds(                 \
-        k_rsrc, (FINO_LDS void*)(smem + ((T_) & 1) * kW4TileBytes + (4 * wave + j_) * 1024), 16, kvo[j_],      \
+    _Pragma("unroll") for (int j_ = 0; j_ < kNPW; ++j_) __builtin_amdgcn_raw_ptr_buffer_load_lds(              \
+        k_rsrc, (FINO_LDS void*)(smem + ((T_) & 1) * kW4TileBytes + (kNPW * wave + j_) * 1024), 16, kvo[j_],   \
         (T_) * k_tile_bytes, 0, 0);
 #define W4_DMA_K1(T_, SLOT_, J_)                                                                               \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
-        k_rsrc, (FINO_LDS void*)(smem + (SLOT_) * kW4TileBytes + (4 * wave + (J_)) * 1024), 16, kvo[J_],       \
+        k_rsrc, (FINO_LDS void*)(smem + (SLOT_) * kW4TileBytes + (kNPW * wave + (J_)) * 1024), 16, kvo[J_],    \
         (T_) * k_tile_bytes, 0, 0);
 #define W4_DMA_V1(T_, SLOT_, J_)                                                                               \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
-        v_rsrc, (FINO_LDS void*)(smem + (2 + (SLOT_)) * kW4TileBytes + (4 * wave + (J_)) * 1024), 16, vvo[J_], \
+        v_rsrc, (FINO_LDS void*)(smem + (2 + (SLOT_)) * kW4TileBytes + (kNPW * wave + (J_)) * 1024), 16, vvo[J_], \
         (T_) * v_tile_bytes, 0, 0);
 #define W4_DMA_V(T_)                                                                                           \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) __builtin_amdgcn_raw_ptr_buffer_load_lds(                 \
-        v_rsrc, (FINO_LDS void*)(smem + (2 + ((T_) & 1)) * kW4TileBytes + (4 * wave + j_) * 1024), 16, vvo[j_], \
+    _Pragma("unroll") for (int j_ = 0; j_ < kNPW; ++j_) __builtin_amdgcn_raw_ptr_buffer_load_lds(              \
+        v_rsrc, (FINO_LDS void*)(smem + (2 + ((T_) & 1)) * kW4TileBytes + (kNPW * wave + j_) * 1024), 16, vvo[j_], \
         (T_) * v_tile_bytes, 0, 0);
 
     // ---- per-lane LDS fragment addresses (raw: the dynamic segment is the kernel's only LDS and starts at 0) ----
@@ -333,6 +341,7 @@ void attn_w4_kernel(const AttnParams p) {
         S_[QS_][(E_) >> 4][(E_) & 15] = x_;                                                                    \
         PEND_ = x_;                                                                                            \
     }
+#define W4_EL(S_, QS_, E_) S_[QS_][(E_) >> 4][(E_) & 15]
     // pack elements (E_, E_ + 1) of sub-block QS_ (E_ even) into P's B-operand registers
 #define W4_PACK2(S_, QS_, E_)                                                                                  \
     {                                                                                                          \
@@ -345,17 +354,126 @@ void attn_w4_kernel(const AttnParams p) {
                          : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]));      \
         pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
     }
-    // V^T fragment pair n (= 4 * key step + d-tile) of the V slot at byte VS_ -> ring entry n & 3 (two 64-bit halves)
+    // V^T fragment pair n (= kDT * key step + d-tile) of the V slot at byte VS_ -> ring entry n & 3 (two 64-bit halves)
 #define W4_LOADV(N_, VS_)                                                                                      \
     {                                                                                                          \
-        W4_LDTR(vlo_[(N_) & 3], vl_addr[(N_) & 3], (VS_) + ((N_) >> 2) * 16 * D * 2)                           \
-        W4_LDTR(vhi_[(N_) & 3], vh_addr[(N_) & 3], (VS_) + ((N_) >> 2) * 16 * D * 2)                           \
+        W4_LDTR(vlo_[(N_) & 3], vl_addr[(N_) % kDT], (VS_) + ((N_) / kDT) * 16 * D * 2)                        \
+        W4_LDTR(vhi_[(N_) & 3], vh_addr[(N_) % kDT], (VS_) + ((N_) / kDT) * 16 * D * 2)                        \
     }
+
+    // exp2 of elements [LO_, LO_ + N_) of a sub-block and the row-sum adds of the elements BEFORE each of them (PREV_ =
+    // element LO_ - 1, or zero), as ONE asm statement (between two statements the hazard recogniser pads with s_nop).
+    // LO_, N_ are constant expressions (the slices are spelled out by literal index below).
+#define W4_EXPADD(S_, QS_, LO_, N_, PREV_, SUM_)                                                               \
+    {                                                                                                          \
+        if constexpr ((N_) == 1)                                                                               \
+            asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %2" : "+v"(W4_EL(S_, QS_, LO_)), "+v"(SUM_) : "v"(PREV_)); \
+        else if constexpr ((N_) == 2)                                                                          \
+            asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_add_f32 %2, %2, %3\n\tv_add_f32 %2, %2, %0"  \
+                         : "+v"(W4_EL(S_, QS_, LO_)), "+v"(W4_EL(S_, QS_, (LO_) + 1)), "+v"(SUM_) : "v"(PREV_)); \
+        else if constexpr ((N_) == 3)                                                                          \
+            asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_add_f32 %3, %3, %4\n\t"   \
+                         "v_add_f32 %3, %3, %0\n\tv_add_f32 %3, %3, %1"                                        \
+                         : "+v"(W4_EL(S_, QS_, LO_)), "+v"(W4_EL(S_, QS_, (LO_) + 1)), "+v"(W4_EL(S_, QS_, (LO_) + 2)), \
+                           "+v"(SUM_) : "v"(PREV_));                                                           \
+    }
+    // element E_ - 1 as the PREV_ operand above (zero before element 0)
+#define W4_PREV(S_, QS_, E_) ((E_) >= 1 ? W4_EL(S_, QS_, (E_) >= 1 ? (E_) - 1 : 0) : zero_f)
+    const float zero_f = 0.f;
+
+    // ---- phase 1, slice S_ (literal; S1 = 4 + 4 kKS slices): MFMA S_ of "S(t+1) = ones.(-m) + K(t+1).Q~^T" (4 opening
+    //      products, which also cover the first K fragment's LDS latency, then kKS k-steps x 4) || its share of the 32
+    //      exp2 of sub-block 1 of S(t) and of the 32 packed pairs (sub-block 0 first: exp2'ed a phase ago; a pair of
+    //      sub-block 1 one slice after its second exp2), dealt by w4_lo; the 2 kNPW LDS-DMA pieces one per k-step ----
+    // packs of phase-1 slice (lo_, n_, plo_ in scope): k-th element of this slice -> its sub-block-0 pair; k-th element of
+    // the PREVIOUS slice, if odd -> the sub-block-1 pair it completes
+#define W4_P1_PACK(SC_, K_)                                                                                    \
+    if constexpr ((K_) < n_ && lo_ + (K_) < 16) { W4_PACK2(SC_, 0, 2 * (lo_ + (K_))) }                         \
+    if constexpr (s_ >= 1 && plo_ + (K_) < lo_ && ((plo_ + (K_)) & 1)) { W4_PACK2(SC_, 1, plo_ + (K_) - 1) }
+#define W4_P1(SC_, SN_, PAR_, SL_)                                                                             \
+    if constexpr ((SL_) < w4_s1(D)) {                                                                          \
+        constexpr int s_ = (SL_), ks_ = (s_ - 4) >> 2, i_ = s_ & 3, qs_ = i_ & 1, kh_ = i_ >> 1;              \
+        if constexpr (s_ >= 4 && i_ == 0) {                                                                    \
+            if constexpr (has_next_ && ks_ + 1 < kKS) {                                                        \
+                W4_LD128(ka_[(ks_ + 1) & 1][0], ka_addr[ks_ + 1], ks_off_)                                     \
+                W4_LD128(ka_[(ks_ + 1) & 1][1], ka_addr[ks_ + 1], ks_off_ + 32 * D * 2)                        \
+            }                                                                                                  \
+            if constexpr (ks_ == kKS - 2) { W4_LOADV(0, vs_off_) }                                             \
+            if constexpr (ks_ == kKS - 1) { W4_LOADV(1, vs_off_) }                                             \
+            /* K(ks) landed: behind it are K(ks+1) (2 reads), in the last two k-steps also V pairs 0, 1 */      \
+            if constexpr (has_next_) {                                                                         \
+                if constexpr (ks_ < kKS - 2) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(4) }                      \
+            }                                                                                                  \
+        }                                                                                                      \
+        if constexpr (has_next_) {                                                                             \
+            if constexpr (s_ < 4) w4_mfma_vv0<T>(SN_[qs_][kh_], ones, mneg[qs_]);                              \
+            else w4_mfma_qk<T>(SN_[qs_][kh_], ka_[ks_ & 1][kh_], qf[qs_][ks_ < 0 ? 0 : ks_]);                  \
+        }                                                                                                      \
+        if constexpr (s_ >= 4 && i_ == 1) {                                                                    \
+            if constexpr (ks_ < kNPW) { if (dma_k_) { W4_DMA_K1(t_ + 2, PAR_, ks_ < 0 ? 0 : ks_) } }           \
+            else if constexpr (ks_ < 2 * kNPW) { if (has_next_) { W4_DMA_V1(t_ + 1, 1 - (PAR_), ks_ - kNPW) } } \
+        }                                                                                                      \
+        {                                                                                                      \
+            constexpr int lo_ = w4_lo(s_, w4_s1(D)), n_ = w4_lo(s_ + 1, w4_s1(D)) - lo_;                        \
+            W4_EXPADD(SC_, 1, lo_, n_, W4_PREV(SC_, 1, lo_), psum1_)                                           \
+            constexpr int plo_ = w4_lo(s_ - 1, w4_s1(D));                 /* the previous slice's elements */  \
+            W4_P1_PACK(SC_, 0) W4_P1_PACK(SC_, 1) W4_P1_PACK(SC_, 2)                                           \
+        }                                                                                                      \
+        W4_FENCE                                                                                               \
+    }
+    // ---- phase 2, MFMA pair N_ (literal; = kDT * key step + d-tile) for sub-block QS_ (literal): slice s = 2 N_ + QS_ of
+    //      S2 = 8 kDT.  Slices 0..3 a quarter of both sub-blocks' row maxima each, slice 4 the rescale decision, the 32
+    //      exp2 of sub-block 0 of S(t+1) from slice 5 on ----
+#define W4_P2(SN_, N_, QS_)                                                                                    \
+    if constexpr ((N_) < 4 * kDT) {                                                                            \
+        constexpr int n_ = (N_), qs_ = (QS_), s_ = 2 * n_ + qs_;                                               \
+        if constexpr (qs_ == 0) {                                                                              \
+            if constexpr (n_ + 2 < 4 * kDT) { W4_LOADV(n_ + 2, vs_off_) }                                      \
+            /* pair n landed: behind it are pairs n+1, n+2 (2 reads each) */                                   \
+            if constexpr (n_ + 2 < 4 * kDT) { W4_WAIT_LGKM(4) } else if constexpr (n_ + 1 < 4 * kDT) { W4_WAIT_LGKM(2) } \
+            else { W4_WAIT_LGKM(0) }                                                                           \
+            va_ = u32x4_t{vlo_[n_ & 3][0], vlo_[n_ & 3][1], vhi_[n_ & 3][0], vhi_[n_ & 3][1]};                 \
+        }                                                                                                      \
+        w4_o_mfma<T>(4 * qs_ + (n_ % kDT), va_, pb[qs_][n_ / kDT]);                                            \
+        if constexpr (has_next_) {                                                                             \
+            if constexpr (s_ < 4) {             /* a quarter of both sub-blocks' row maxima: two independent chains */ \
+                constexpr int kh_ = s_ >> 1, o_ = 8 * (s_ & 1);                                                \
+                mxp_[0] = fmx(mxp_[0], W4_MAX8(SN_[0][kh_], o_));                                              \
+                mxp_[1] = fmx(mxp_[1], W4_MAX8(SN_[1][kh_], o_));                                              \
+                asm volatile("" : "+v"(mxp_[0]), "+v"(mxp_[1]));                                               \
+            } else if constexpr (s_ == 4) {                                                                    \
+                /* S(t+1) is relative to m_run already: its row max IS the excess over the running maximum.     \
+                   Deferred rescale: only past rescale_thr<T>() (then all lanes move, each to its own maximum). */ \
+                float mx0_, mx1_;                                                                              \
+                W4_SWAPMAX(mxp_[0], mx0_)                                                                      \
+                W4_SWAPMAX(mxp_[1], mx1_)                                                                      \
+                resc_ = __any(fmx(mx0_, mx1_) > rescale_thr<T>());                                             \
+                if (__builtin_expect(resc_, 0)) {                                                              \
+                    const float mx_[2] = {mx0_, mx1_};                                                         \
+                    _Pragma("unroll") for (int q2_ = 0; q2_ < 2; ++q2_) {                                      \
+                        const float mn_ = T::to_f32(T::from_f32(m_run[q2_] + fmx(mx_[q2_], 0.f)));             \
+                        dm_[q2_] = mn_ - m_run[q2_];                                                           \
+                        m_run[q2_] = mn_;                                                                      \
+                        mneg[q2_][0] = h == 0 ? (uint32_t)T::from_f32(-mn_) : 0u;                              \
+                        _Pragma("unroll") for (int kh_ = 0; kh_ < 2; ++kh_)                                    \
+                            _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) SN_[q2_][kh_][j_] -= dm_[q2_];   \
+                    }                                                                                          \
+                }                                                                                              \
+            } else {                                                                                           \
+                constexpr int lo_ = w4_lo(s_ - 5, w4_s2(D) - 5), cnt_ = w4_lo(s_ - 4, w4_s2(D) - 5) - lo_;      \
+                W4_EXPADD(SN_, 0, lo_, cnt_, W4_PREV(SN_, 0, lo_), psn_)                                       \
+            }                                                                                                  \
+        }                                                                                                      \
+        W4_FENCE                                                                                               \
+    }
+#define W4_P1x4(SC_, SN_, PAR_, B_) W4_P1(SC_, SN_, PAR_, (B_)) W4_P1(SC_, SN_, PAR_, (B_) + 1) W4_P1(SC_, SN_, PAR_, (B_) + 2) W4_P1(SC_, SN_, PAR_, (B_) + 3)
+#define W4_P2x2(SN_, N_) W4_P2(SN_, (N_), 0) W4_P2(SN_, (N_), 1)
+#define W4_P2x8(SN_, B_) W4_P2x2(SN_, (B_)) W4_P2x2(SN_, (B_) + 1) W4_P2x2(SN_, (B_) + 2) W4_P2x2(SN_, (B_) + 3)
 
     // ---- one key tile t of parity PAR_ (literal): SC_ = S(t) (sub-block 0 already exp2'ed, its row sum in psum0),
     //      SN_ = S(t+1).  Ring slots: K(t+1) is read from K slot 1 - PAR_, V(t) from V slot PAR_; the DMA of K(t+2)
     //      goes to K slot PAR_ and that of V(t+1) to V slot 1 - PAR_ (both free since the barrier). ----
-#define W4_TILE_F(SC_, SN_, TT_, PAR_, HN_)                                                                      \
+#define W4_TILE_F(SC_, SN_, TT_, PAR_, HN_)                                                                    \
     {                                                                                                          \
         const int t_ = (TT_);                                                                                  \
         constexpr bool has_next_ = (HN_);                                                                      \
@@ -367,14 +485,11 @@ void attn_w4_kernel(const AttnParams p) {
         __builtin_amdgcn_s_barrier();                                                                          \
         W4_FENCE                                                                                               \
         W4_STAMP(ts2)                                                                                          \
-        const bool dma_k_ = t_ + 2 < nt;     /* the 8 LDS-DMA pieces go out one per k-step of phase 1 */       \
+        const bool dma_k_ = t_ + 2 < nt;                                                                       \
         W4_STAMP(ts3)                                                                                          \
-        /* ================= phase 1: S(t+1) = ones.(-m) + K(t+1).Q~^T  ||  exp2 of sub-block 1 of S(t), packing === */ \
-        /* 36 MFMA slices: 4 opening products (they also cover the first K fragment's LDS latency), then 8 k-steps x 4. \
-           Slice s carries exp2 of element s of sub-block 1 (s < 32) and one packed pair: pairs 0..15 = sub-block 0   \
-           (exp2'ed a phase ago) in slices 0..15, pair p >= 16 = sub-block 1 elements 2(p-16), +1 in slice p + 4.     */ \
-        float psum1_ = 0.f, pend1_ = 0.f;                                                                      \
-        u32x4_t ka_[2][2];                                                                                     \
+        /* ================= phase 1 ================= */                                                       \
+        float psum1_ = 0.f;                                                                                    \
+        u32x4_t ka_[2][2], va_;                                                                                \
         u32x2_t vlo_[4], vhi_[4];                                                                              \
         if (has_next_) {                                                                                       \
             W4_LD128(ka_[0][0], ka_addr[0], ks_off_)                                                           \
@@ -384,85 +499,25 @@ void attn_w4_kernel(const AttnParams p) {
            in front of an MFMA that reads it is a hazard the recogniser cannot see through the asm */          \
         asm volatile("s_nop 3" : "+v"(mneg[0]), "+v"(mneg[1]) : "v"(ones));                                    \
         W4_FENCE                                                                                               \
-        _Pragma("unroll") for (int s_ = 0; s_ < 36; ++s_) {                                                    \
-            const int ks_ = (s_ - 4) >> 2, i_ = s_ & 3;               /* k-step / MFMA of the k-step (s >= 4) */ \
-            const int qs_ = i_ & 1, kh_ = i_ >> 1;                                                             \
-            if (s_ >= 4 && i_ == 0) {                                                                          \
-                if (has_next_ && ks_ + 1 < kKS) {                                                              \
-                    W4_LD128(ka_[(ks_ + 1) & 1][0], ka_addr[ks_ + 1], ks_off_)                                 \
-                    W4_LD128(ka_[(ks_ + 1) & 1][1], ka_addr[ks_ + 1], ks_off_ + 32 * D * 2)                    \
-                }                                                                                              \
-                if (ks_ == kKS - 2) { W4_LOADV(0, vs_off_) }                                                   \
-                if (ks_ == kKS - 1) { W4_LOADV(1, vs_off_) }                                                   \
-                /* K(ks) landed: behind it are K(ks+1) (2 reads), at ks = 6 also V pair 0, at ks = 7 V pairs 0, 1 */ \
-                if (has_next_) {                                                                               \
-                    if (ks_ < kKS - 2) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(4) }                            \
-                }                                                                                              \
-            }                                                                                                  \
-            if (has_next_) {                                                                                   \
-                if (s_ < 4) w4_mfma_vv0<T>(SN_[qs_][kh_], ones, mneg[qs_]);                                    \
-                else w4_mfma_qk<T>(SN_[qs_][kh_], ka_[ks_ & 1][kh_], qf[qs_][ks_]);                            \
-            }                                                                                                  \
-            if (s_ >= 4 && i_ == 1) {                                                                          \
-                if (ks_ < 4) { if (dma_k_) { W4_DMA_K1(t_ + 2, PAR_, ks_) } }                                  \
-                else if (has_next_) { W4_DMA_V1(t_ + 1, 1 - (PAR_), ks_ - 4) }                                 \
-            }                                                                                                  \
-            if (s_ < 32) { W4_EXP1(SC_, 1, s_, psum1_, pend1_) }                                               \
-            if (s_ < 16) { W4_PACK2(SC_, 0, 2 * s_) }                                                          \
-            else if (s_ >= 20) { W4_PACK2(SC_, 1, 2 * (s_ - 20)) }                                             \
-            W4_FENCE                                                                                           \
+        W4_P1x4(SC_, SN_, PAR_, 0) W4_P1x4(SC_, SN_, PAR_, 4) W4_P1x4(SC_, SN_, PAR_, 8)                       \
+        W4_P1x4(SC_, SN_, PAR_, 12) W4_P1x4(SC_, SN_, PAR_, 16) W4_P1x4(SC_, SN_, PAR_, 20)                    \
+        W4_P1x4(SC_, SN_, PAR_, 24) W4_P1x4(SC_, SN_, PAR_, 28) W4_P1x4(SC_, SN_, PAR_, 32)                    \
+        {                                                                  /* odd elements of the last slice */ \
+            constexpr int ll_ = w4_lo(w4_s1(D) - 1, w4_s1(D));                                                 \
+            if constexpr (ll_ < 32 && (ll_ & 1)) { W4_PACK2(SC_, 1, ll_ - 1) }                                 \
+            if constexpr (ll_ + 1 < 32 && ((ll_ + 1) & 1)) { W4_PACK2(SC_, 1, ll_) }                           \
+            if constexpr (ll_ + 2 < 32 && ((ll_ + 2) & 1)) { W4_PACK2(SC_, 1, ll_ + 1) }                       \
         }                                                                                                      \
         l_run[0] += psum0;                                                                                     \
-        l_run[1] += psum1_ + pend1_;                                                                           \
+        l_run[1] += psum1_ + W4_EL(SC_, 1, 31);                                                                \
         W4_FENCE                                                                                               \
         W4_STAMP(ts4)                                                                                          \
-        /* ================= phase 2: O^T += V(t)^T.P(t)^T  ||  row max of S(t+1), exp2 of its sub-block 0 == */ \
+        /* ================= phase 2 ================= */                                                       \
         if (has_next_) { W4_MASK(SN_, t_ + 1) }                                                                \
         float mxp_[2] = {-INFINITY, -INFINITY}, dm_[2] = {0.f, 0.f};                                           \
         bool resc_ = false;                                                                                    \
-        float psn_ = 0.f, pendn_ = 0.f;                                                                        \
-        _Pragma("unroll") for (int n_ = 0; n_ < 4 * kDT; ++n_) {                                               \
-            if (n_ + 2 < 4 * kDT) { W4_LOADV(n_ + 2, vs_off_) }                                                \
-            /* pair n landed: behind it are pairs n+1, n+2 (2 reads each) */                                   \
-            if (n_ + 2 < 4 * kDT) { W4_WAIT_LGKM(4) } else if (n_ + 1 < 4 * kDT) { W4_WAIT_LGKM(2) } else { W4_WAIT_LGKM(0) } \
-            const u32x4_t va_ = {vlo_[n_ & 3][0], vlo_[n_ & 3][1], vhi_[n_ & 3][0], vhi_[n_ & 3][1]};          \
-            _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) {                                              \
-                const int s_ = 2 * n_ + qs_;                             /* slice 0..31 */                     \
-                w4_o_mfma<T>(4 * qs_ + (n_ & 3), va_, pb[qs_][n_ >> 2]);                                       \
-                if (has_next_) {                                                                               \
-                    if (s_ < 4) {               /* a quarter of both sub-blocks' row maxima: two independent chains */ \
-                        const int kh_ = s_ >> 1, o_ = 8 * (s_ & 1);                                            \
-                        mxp_[0] = fmx(mxp_[0], W4_MAX8(SN_[0][kh_], o_));                                      \
-                        mxp_[1] = fmx(mxp_[1], W4_MAX8(SN_[1][kh_], o_));                                      \
-                        asm volatile("" : "+v"(mxp_[0]), "+v"(mxp_[1]));                                       \
-                    } else if (s_ == 4) {                                                                      \
-                        /* S(t+1) is relative to m_run already: its row max IS the excess over the running maximum. \
-                           Deferred rescale: only past rescale_thr<T>() (then all lanes move, each to its own maximum). */ \
-                        float mx0_, mx1_;                                                                      \
-                        W4_SWAPMAX(mxp_[0], mx0_)                                                              \
-                        W4_SWAPMAX(mxp_[1], mx1_)                                                              \
-                        resc_ = __any(fmx(mx0_, mx1_) > rescale_thr<T>());                                          \
-                        if (__builtin_expect(resc_, 0)) {                                                      \
-                            const float mx_[2] = {mx0_, mx1_};                                                 \
-                            _Pragma("unroll") for (int q2_ = 0; q2_ < 2; ++q2_) {                              \
-                                const float mn_ = T::to_f32(T::from_f32(m_run[q2_] + fmx(mx_[q2_], 0.f)));     \
-                                dm_[q2_] = mn_ - m_run[q2_];                                                   \
-                                m_run[q2_] = mn_;                                                              \
-                                mneg[q2_][0] = h == 0 ? (uint32_t)T::from_f32(-mn_) : 0u;                      \
-                                _Pragma("unroll") for (int kh_ = 0; kh_ < 2; ++kh_)                            \
-                                    _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) SN_[q2_][kh_][j_] -= dm_[q2_]; \
-                            }                                                                                  \
-                        }                                                                                      \
-                    } else if (s_ < 10) {       /* 32 exp2 of sub-block 0 over slices 5..31: two in 5..9, then one */ \
-                        W4_EXP1(SN_, 0, 2 * (s_ - 5), psn_, pendn_)                                            \
-                        W4_EXP1(SN_, 0, 2 * (s_ - 5) + 1, psn_, pendn_)                                        \
-                    } else {                                                                                   \
-                        W4_EXP1(SN_, 0, s_, psn_, pendn_)                                                      \
-                    }                                                                                          \
-                }                                                                                              \
-                W4_FENCE                                                                                       \
-            }                                                                                                  \
-        }                                                                                                      \
+        float psn_ = 0.f;                                                                                      \
+        W4_P2x8(SN_, 0) W4_P2x8(SN_, 4) W4_P2x8(SN_, 8) W4_P2x8(SN_, 12)                                       \
         /* the O / l side of a rescale, between tiles (after the last P(t).V(t) product) */                    \
         if (has_next_) {                                                                                       \
             if (__builtin_expect(resc_, 0)) {                                                                  \
@@ -474,7 +529,7 @@ void attn_w4_kernel(const AttnParams p) {
                 }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
-        psum0 = psn_ + pendn_;                                                                                 \
+        if (has_next_) psum0 = psn_ + W4_EL(SN_, 0, 31);        /* the last element's share of the row sum */        \
         W4_FENCE                                                                                               \
         W4_STAMP(ts5)                                                                                          \
         W4_STAMP_ACC                                                                                           \
@@ -613,7 +668,7 @@ void attn_w4_kernel(const AttnParams p) {
 #define W4_STAMP_ACC
 #endif
     // tiles 0 .. nt-2 have a successor (two per trip: the S buffers and the ring slots swap roles); the last one does not
-#define W4_TILE(A_, B_, T_, P_, H_) if constexpr (FOLD) { W4_TILE_F(A_, B_, T_, P_, H_) } else { W4_TILE_N(A_, B_, T_, P_, H_) }
+#define W4_TILE(A_, B_, T_, P_, H_) if constexpr (FOLD) { W4_TILE_F(A_, B_, T_, P_, H_) } else if constexpr (D == 128) { W4_TILE_N(A_, B_, T_, P_, H_) }
     int t = 0;
     for (; t + 2 < nt; t += 2) {
         W4_TILE(sa, sb, t, 0, true)
@@ -674,25 +729,30 @@ void attn_w4_kernel(const AttnParams p) {
   }   // piece
 }
 
-template <typename T, bool FOLD>
+template <typename T, int D, bool FOLD>
 int launch_w4(const AttnParams& p, hipStream_t st) {
+    constexpr int smem = 4 * kKV * D * 2;
     static FinoPerDeviceOnce once_a, once_b;
-    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_w4_kernel<T, 0, FOLD>), kW4Smem, "fino_attn_fwd")) return rc;
-    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_w4_kernel<T, 1, FOLD>), kW4Smem, "fino_attn_fwd")) return rc;
+    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_w4_kernel<T, D, 0, FOLD>), smem, "fino_attn_fwd")) return rc;
+    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_w4_kernel<T, D, 1, FOLD>), smem, "fino_attn_fwd")) return rc;
     const dim3 grid((unsigned)(8 * (p.full_x + p.nwg)));
     if (p.lk > 1024)
-        attn_w4_kernel<T, 0, FOLD><<<grid, kW4Threads, kW4Smem, st>>>(p);
+        attn_w4_kernel<T, D, 0, FOLD><<<grid, kW4Threads, smem, st>>>(p);
     else
-        attn_w4_kernel<T, 1, FOLD><<<grid, kW4Threads, kW4Smem, st>>>(p);
+        attn_w4_kernel<T, D, 1, FOLD><<<grid, kW4Threads, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
 
 }  // namespace
 
-// the main launch only: p carries the tail-split plan (full_x, rem_x, nwg, per) / all_partial; the caller runs the combine
-int fino_attn_launch_w4(const AttnParams& p, int dtype, hipStream_t st) {
+// the main launch only: p carries the tail-split plan (full_x, rem_x, nwg, per) / all_partial; the caller runs the combine.
+// head_dim 64 exists for the folded-scale path only (p.scale_log2 == 1): fino_attn_w4_supports says so.
+bool fino_attn_w4_supports(int head_dim, float scale_log2) { return head_dim == 128 || (head_dim == 64 && scale_log2 == 1.0f); }
+int fino_attn_launch_w4(const AttnParams& p, int dtype, int head_dim, hipStream_t st) {
     // scale * log2(e) == 1 exactly <=> the caller said FINO_ATTN_SCALE_FOLDED: q carries the softmax scale already
-    if (p.scale_log2 == 1.0f) return dtype == FINO_BF16 ? launch_w4<BF16, true>(p, st) : launch_w4<F16, true>(p, st);
-    return dtype == FINO_BF16 ? launch_w4<BF16, false>(p, st) : launch_w4<F16, false>(p, st);
+    const bool fold = p.scale_log2 == 1.0f;
+    if (head_dim == 64) return dtype == FINO_BF16 ? launch_w4<BF16, 64, true>(p, st) : launch_w4<F16, 64, true>(p, st);
+    if (fold) return dtype == FINO_BF16 ? launch_w4<BF16, 128, true>(p, st) : launch_w4<F16, 128, true>(p, st);
+    return dtype == FINO_BF16 ? launch_w4<BF16, 128, false>(p, st) : launch_w4<F16, 128, false>(p, st);
 }

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(uint16_t* __restrict
                                                             int64_t batch_stride, const uint16_t* __restrict__ w,
                                                             const uint16_t* __restrict__ b, float eps,
                                                             const float* __restrict__ cos_t,
-                                                            const float* __restrict__ sin_t, int64_t rope_row0) {
+                                                            const float* __restrict__ sin_t, int64_t rope_row0,
+                                                            float out_scale) {
     const int lanes_per_head = head_dim >> 3;
     const int64_t chunks_per_row = (int64_t)heads * lanes_per_head;
     const int64_t total = (int64_t)batch * rows * chunks_per_row;
@@ -278,6 +279,9 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(uint16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = o[j];
     }
+    // fino_headnorm_rope_scaled (1.0f: the plain op, bit for bit): q for FINO_ATTN_SCALE_FOLDED
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= out_scale;
     if (active) *reinterpret_cast<uint4*>(p) = pack8<T>(v);
 }
 
@@ -628,11 +632,12 @@ extern "C" int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, co
     return fino_rmsnorm_rope_scaled(x, rows, dim, ldx, weight, eps, cos_t, sin_t, head_dim, 1.0f, dtype, stream);
 }
 
-extern "C" int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx,
-                                  int64_t batch_stride, const void* w, const void* b, float eps, const float* cos_t,
-                                  const float* sin_t, int64_t rope_row0, int dtype, void* stream) {
+extern "C" int fino_headnorm_rope_scaled(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx,
+                                         int64_t batch_stride, const void* w, const void* b, float eps,
+                                         const float* cos_t, const float* sin_t, int64_t rope_row0, float out_scale,
+                                         int dtype, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_headnorm_rope: dtype %d", dtype);
-    FINO_CHECK(x && batch >= 0 && rows >= 0 && heads > 0, FINO_ERR_ARG, "fino_headnorm_rope: bad shape");
+    FINO_CHECK(x && batch >= 0 && rows >= 0 && heads > 0 && out_scale > 0.f, FINO_ERR_ARG, "fino_headnorm_rope: bad shape");
     FINO_CHECK(head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128, FINO_ERR_UNSUPPORTED,
                "fino_headnorm_rope: head_dim %d not in {16,32,64,128}", head_dim);
     FINO_CHECK((w == nullptr) == (b == nullptr) && (cos_t == nullptr) == (sin_t == nullptr), FINO_ERR_ARG,
@@ -647,13 +652,20 @@ extern "C" int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, i
     if (dtype == FINO_BF16)
         headnorm_rope_kernel<BF16><<<grid, 256, 0, st>>>((uint16_t*)x, batch, rows, heads, head_dim, ldx, batch_stride,
                                                          (const uint16_t*)w, (const uint16_t*)b, eps, cos_t, sin_t,
-                                                         rope_row0);
+                                                         rope_row0, out_scale);
     else
         headnorm_rope_kernel<F16><<<grid, 256, 0, st>>>((uint16_t*)x, batch, rows, heads, head_dim, ldx, batch_stride,
                                                         (const uint16_t*)w, (const uint16_t*)b, eps, cos_t, sin_t,
-                                                        rope_row0);
+                                                        rope_row0, out_scale);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
+}
+
+extern "C" int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx,
+                                  int64_t batch_stride, const void* w, const void* b, float eps, const float* cos_t,
+                                  const float* sin_t, int64_t rope_row0, int dtype, void* stream) {
+    return fino_headnorm_rope_scaled(x, batch, rows, heads, head_dim, ldx, batch_stride, w, b, eps, cos_t, sin_t, rope_row0,
+                                     1.0f, dtype, stream);
 }
 
 extern "C" int fino_patchify(const void* x, void* a, int channels, int frames, int height, int width, int pt, int ph,

@@ -150,13 +150,14 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0, out_scale=1.0)
     return x
 
 
-def headnorm_rope_(x, heads, head_dim, weight, bias, eps, cos=None, sin=None, rope_row0=0):
-    """In place on x [B, rows, heads*head_dim] (row-strided): per-head LayerNorm + RoPE on rows >= rope_row0."""
+def headnorm_rope_(x, heads, head_dim, weight, bias, eps, cos=None, sin=None, rope_row0=0, out_scale=1.0):
+    """In place on x [B, rows, heads*head_dim] (row-strided): per-head LayerNorm + RoPE on rows >= rope_row0.
+    out_scale: multiplies the result before it is stored (q for attention(scale=SCALE_FOLDED))."""
     assert x.dim() == 3 and x.stride(2) == 1
     b, rows, _ = x.shape
-    _lib.check(_lib.lib().fino_headnorm_rope(_p(x), b, rows, heads, head_dim, x.stride(1), x.stride(0), _p(weight),
-                                            _p(bias), eps, _p(cos), _p(sin), rope_row0, _dt(x), _stream()),
-               "fino_headnorm_rope")
+    _lib.check(_lib.lib().fino_headnorm_rope_scaled(_p(x), b, rows, heads, head_dim, x.stride(1), x.stride(0), _p(weight),
+                                                   _p(bias), eps, _p(cos), _p(sin), rope_row0, float(out_scale), _dt(x),
+                                                   _stream()), "fino_headnorm_rope")
     return x
 
 

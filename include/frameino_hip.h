@@ -95,6 +95,11 @@ int fino_rmsnorm_rope_scaled(void* x, int64_t rows, int dim, int64_t ldx, const 
 int fino_headnorm_rope(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx, int64_t batch_stride,
                        const void* w, const void* b, float eps, const float* cos_t, const float* sin_t,
                        int64_t rope_row0, int dtype, void* stream);
+/* The same with the result multiplied by out_scale before it is stored (rows that get RoPE: one rounding; rows that
+ * only get the LayerNorm, i.e. the text tokens, are rounded by the norm first): q for FINO_ATTN_SCALE_FOLDED. */
+int fino_headnorm_rope_scaled(void* x, int batch, int64_t rows, int heads, int head_dim, int64_t ldx,
+                              int64_t batch_stride, const void* w, const void* b, float eps, const float* cos_t,
+                              const float* sin_t, int64_t rope_row0, float out_scale, int dtype, void* stream);
 
 /* ---- attention (MFMA-bound) -----------------------------------------------------------------------------
  * o[b, i, h, :] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] ) v[b,j,h,:]   non-causal, no mask, no dropout.

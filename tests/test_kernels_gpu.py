@@ -441,26 +441,28 @@ def _sdpa_f32(q, k, v, heads, scale=None):
 @pytest.mark.parametrize("b,heads,lq,lk", [(1, 2, 64, 64), (2, 3, 257, 129), (1, 2, 300, 500), (1, 8, 1000, 77),
                                            (2, 24, 1024, 1024), (1, 24, 2000, 4500)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_four_wave_attention_kernel_and_folded_scale(b, heads, lq, lk, dtype):
+@pytest.mark.parametrize("dh", [128, 64])
+def test_four_wave_attention_kernel_and_folded_scale(b, heads, lq, lk, dtype, dh):
     """FINO_TUNE_ATTN_KERNEL = 2 (fino_attention_w4.hip): whole blocks, ragged last tile, tail split, and the
     FINO_ATTN_SCALE_FOLDED path (q pre-multiplied by scale * log2(e), running maximum folded into the MFMAs), each against
     fp32 SDPA on the q it was given (tolerance 2^-8 relative RMS); the folded q is ONE rounding of the fp32 q like the plain
-    one, so both are equally far from SDPA on the un-rounded q."""
+    one, so both are equally far from SDPA on the un-rounded q.  head_dim 64 has the 4-wave kernel for the folded path only
+    (the plain call falls back to the 8-wave kernel)."""
     from frameino_amd import _lib, ops
     g = torch.Generator(device=DEV).manual_seed(3)
-    d = heads * 128
+    d = heads * dh
     qf = torch.randn(b, lq, d, device=DEV, generator=g) * 2.0
     kv = torch.randn(b, lk, 2 * d, device=DEV, generator=g).to(dtype)
     k, v = kv[:, :, :d], kv[:, :, d:]
-    c = 128 ** -0.5 * ops.LOG2E
-    q, qs = qf.to(dtype), (qf * c).to(dtype)                 # as rmsnorm_rope_ writes q without / with out_scale
+    c = dh ** -0.5 * ops.LOG2E
+    q, qs = qf.to(dtype), (qf * c).to(dtype)                 # as rmsnorm_rope_ / headnorm_rope_ write q without / with out_scale
     ref, ref_s = _sdpa_f32(q, k, v, heads), _sdpa_f32(qs.float() / c, k, v, heads)
     lib = _lib.lib()
     try:
         lib.fino_tune_set(4, 2)
         plain = ops.attention(q, k, v, heads)
         folded = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
-        lib.fino_tune_set(4, 0)
+        lib.fino_tune_set(4, 1)
         folded8 = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
     finally:
         lib.fino_tune_set(4, 0)
@@ -521,3 +523,21 @@ def test_rmsnorm_rope_out_scale_is_one_rounding():
     assert (scaled.float() - want.float()).abs().max() <= 2.0 ** -8 * want.float().abs().max()
     assert (scaled != want).float().mean() < 0.02                     # a few 1-ulp flips from rsqrt / fma contraction
     assert rel_rms(scaled.float() / c, plain.float()) < 2.0 ** -8     # and it is the plain result, scaled
+
+
+def test_headnorm_rope_out_scale():
+    """fino_headnorm_rope_scaled: rows that get RoPE are (norm + rope) x c rounded once; the others the rounded norm x c"""
+    from frameino_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(10)
+    b, rows, heads, dh, lt = 2, 50, 3, 64, 7
+    x = torch.randn(b, rows, heads * dh, device=DEV, generator=g).bfloat16()
+    w = (1 + 0.1 * torch.randn(dh, device=DEV, generator=g)).bfloat16()
+    bi = (0.1 * torch.randn(dh, device=DEV, generator=g)).bfloat16()
+    ang = torch.rand(rows - lt, dh, device=DEV, generator=g) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    c = dh ** -0.5 * ops.LOG2E
+    plain = ops.headnorm_rope_(x.clone(), heads, dh, w, bi, 1e-6, cos, sin, rope_row0=lt)
+    scaled = ops.headnorm_rope_(x.clone(), heads, dh, w, bi, 1e-6, cos, sin, rope_row0=lt, out_scale=c)
+    assert rel_rms(scaled.float() / c, plain.float()) < 2.0 ** -8
+    # text rows: exactly the rounded plain result times c, rounded again
+    assert torch.equal(scaled[:, :lt], (plain[:, :lt].float() * c).bfloat16())

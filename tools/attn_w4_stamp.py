@@ -9,7 +9,9 @@ from frameino_amd import _lib, ops
 L, D, H = (int(x) for x in (sys.argv[1:4] + ["12288", "3072", "24"][len(sys.argv) - 1:]))
 qkv = torch.randn(2, L, 3 * D, device="cuda").bfloat16()
 _lib.lib().fino_tune_set(4, 2)
-for _ in range(3): ops.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H)
+fold = (D // H == 64) or os.environ.get("FINO_STAMP_FOLD") == "1"          # head_dim 64 exists with the folded scale only
+q = (qkv[:, :, :D].float() * ((D // H) ** -0.5 * ops.LOG2E)).bfloat16() if fold else qkv[:, :, :D]
+for _ in range(3): ops.attention(q, qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, scale=ops.SCALE_FOLDED if fold else None)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
 lib = ctypes.CDLL(os.environ["FINO_LIB_PATH"]); lib.fino_attn_w4_debug_read(buf)
