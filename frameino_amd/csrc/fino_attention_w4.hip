@@ -35,7 +35,7 @@ constexpr int kW4Waves = 4;
 constexpr int kW4Threads = kW4Waves * 64;
 // slice schedules of the fold loop (phase 1 has S1 = 4 + 4 * D/16 MFMA slices, phase 2 S2 = 8 * D/32):
 constexpr int w4_s1(int d) { return 4 + 4 * (d / 16); }
-constexpr int w4_s2(int d) { return 8 * (d / 32); }
+constexpr int w4_s2(int d) { return 8 * (d / 32 + (d == 64 ? 1 : 0)); }   // (head_dim 64: + the ones tile of the row sums)
 // 32 items dealt over `n` slices in order, item e in slice e * n / 32: slice s holds items [w4_lo(s, n), w4_lo(s + 1, n))
 constexpr int w4_lo(int s, int n) { return s <= 0 ? 0 : (s >= n ? 32 : (32 * s + n - 1) / n); }
 
@@ -99,6 +99,11 @@ void attn_w4_kernel(const AttnParams p) {
     constexpr int kW4TileBytes = kKV * D * 2;            // 16 / 8 KiB; LDS: K ring (2) + V ring (2)
     constexpr int kNPW = kW4TileBytes / 1024 / kW4Waves;   // 1-KiB LDS-DMA pieces per wave and tile (4 / 2)
     static_assert(FOLD || D == 128, "head_dim 64 is built for the folded-scale path only");
+    // head_dim 64 is bound by the softmax's vector work (per MFMA twice the exp2 / add / pack of head_dim 128): there the
+    // row sums l move to the matrix pipe -- one more "d-tile" of P.V whose V^T rows are all ones (8 MFMAs per tile into the
+    // spare accumulator tuples 2 / 6; l is rescaled with O for free) instead of 64 v_add per lane and tile.
+    constexpr bool kMS = (D == 64);
+    constexpr int kPT = kDT + (kMS ? 1 : 0);              // P.V products per key step and sub-block
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -268,8 +273,14 @@ void attn_w4_kernel(const AttnParams p) {
     // The running maximum is kept as a value of the operand type T: -m then rides into every later S accumulator as
     // one more product ("ones" x (-m), exact in the fp32 accumulate), and the softmax is exp2(S) with no per-element
     // scale-and-subtract.  ones: A[key][k = 0] = 1;  mneg[qs]: B[k = 0][q] = -m[q]  (k = 0 lives in the h = 0 lanes).
-    const u32x4_t ones = {h == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u};
+    u32x4_t ones = {h == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(ones));
     u32x4_t mneg[2];
+    const uint32_t one2 = (uint32_t)T::from_f32(1.0f) * 0x10001u;
+    u32x4_t ones_v = {one2, one2, one2, one2};                // a V^T fragment of ones (kMS)
+    // opaque from here on: a known constant is re-materialised (v_mov) right in front of the asm MFMA that reads it, which
+    // is a VALU-write -> MFMA-read hazard the recogniser cannot see
+    asm volatile("" : "+v"(ones_v));
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const float mx = fmx(fmx3(W4_MAX8(sa[qs][0], 0), W4_MAX8(sa[qs][0], 8), W4_MAX8(sa[qs][1], 0)),
@@ -366,7 +377,11 @@ void attn_w4_kernel(const AttnParams p) {
     // LO_, N_ are constant expressions (the slices are spelled out by literal index below).
 #define W4_EXPADD(S_, QS_, LO_, N_, PREV_, SUM_)                                                               \
     {                                                                                                          \
-        if constexpr ((N_) == 1)                                                                               \
+        if constexpr (kMS) {                    /* row sums on the matrix pipe: exp2 only */                    \
+            if constexpr ((N_) >= 1) asm volatile("v_exp_f32 %0, %0" : "+v"(W4_EL(S_, QS_, LO_)));             \
+            if constexpr ((N_) >= 2) asm volatile("v_exp_f32 %0, %0" : "+v"(W4_EL(S_, QS_, (LO_) + 1)));       \
+            if constexpr ((N_) >= 3) asm volatile("v_exp_f32 %0, %0" : "+v"(W4_EL(S_, QS_, (LO_) + 2)));       \
+        } else if constexpr ((N_) == 1)                                                                        \
             asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %2" : "+v"(W4_EL(S_, QS_, LO_)), "+v"(SUM_) : "v"(PREV_)); \
         else if constexpr ((N_) == 2)                                                                          \
             asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_add_f32 %2, %2, %3\n\tv_add_f32 %2, %2, %0"  \
@@ -421,20 +436,23 @@ void attn_w4_kernel(const AttnParams p) {
         }                                                                                                      \
         W4_FENCE                                                                                               \
     }
-    // ---- phase 2, MFMA pair N_ (literal; = kDT * key step + d-tile) for sub-block QS_ (literal): slice s = 2 N_ + QS_ of
-    //      S2 = 8 kDT.  Slices 0..3 a quarter of both sub-blocks' row maxima each, slice 4 the rescale decision, the 32
-    //      exp2 of sub-block 0 of S(t+1) from slice 5 on ----
-#define W4_P2(SN_, N_, QS_)                                                                                    \
-    if constexpr ((N_) < 4 * kDT) {                                                                            \
-        constexpr int n_ = (N_), qs_ = (QS_), s_ = 2 * n_ + qs_;                                               \
-        if constexpr (qs_ == 0) {                                                                              \
+    // ---- phase 2, key step ST_ (0..3), product PI_ (0..kPT-1: d-tile, or the ones tile of the row sums when PI_ == kDT),
+    //      sub-block QS_ (all literal): slice s = (ST_ * kPT + PI_) * 2 + QS_ of S2 = 8 kPT.  Slices 0..3 a quarter of both
+    //      sub-blocks' row maxima each, slice 4 the rescale decision, the 32 exp2 of sub-block 0 of S(t+1) from slice 5 on.
+    //      V^T fragments: real pair n = kDT * ST_ + PI_ is read two pairs ahead into a ring of 4 ----
+#define W4_P2(SN_, ST_, PI_, QS_)                                                                              \
+    if constexpr ((PI_) < kPT) {                                                                               \
+        constexpr int st_ = (ST_), pi_ = (PI_), qs_ = (QS_), s_ = (st_ * kPT + pi_) * 2 + qs_;                 \
+        constexpr int n_ = kDT * st_ + (pi_ < kDT ? pi_ : 0);          /* real V pair (unused for the ones tile) */ \
+        if constexpr (qs_ == 0 && pi_ < kDT) {                                                                 \
             if constexpr (n_ + 2 < 4 * kDT) { W4_LOADV(n_ + 2, vs_off_) }                                      \
             /* pair n landed: behind it are pairs n+1, n+2 (2 reads each) */                                   \
             if constexpr (n_ + 2 < 4 * kDT) { W4_WAIT_LGKM(4) } else if constexpr (n_ + 1 < 4 * kDT) { W4_WAIT_LGKM(2) } \
             else { W4_WAIT_LGKM(0) }                                                                           \
             va_ = u32x4_t{vlo_[n_ & 3][0], vlo_[n_ & 3][1], vhi_[n_ & 3][0], vhi_[n_ & 3][1]};                 \
         }                                                                                                      \
-        w4_o_mfma<T>(4 * qs_ + (n_ % kDT), va_, pb[qs_][n_ / kDT]);                                            \
+        if constexpr (pi_ < kDT) w4_o_mfma<T>(4 * qs_ + pi_, va_, pb[qs_][st_]);                               \
+        else w4_o_mfma<T>(4 * qs_ + 2, ones_v, pb[qs_][st_]);          /* l^T += ones . P^T (tuples 2 / 6) */   \
         if constexpr (has_next_) {                                                                             \
             if constexpr (s_ < 4) {             /* a quarter of both sub-blocks' row maxima: two independent chains */ \
                 constexpr int kh_ = s_ >> 1, o_ = 8 * (s_ & 1);                                                \
@@ -467,8 +485,8 @@ void attn_w4_kernel(const AttnParams p) {
         W4_FENCE                                                                                               \
     }
 #define W4_P1x4(SC_, SN_, PAR_, B_) W4_P1(SC_, SN_, PAR_, (B_)) W4_P1(SC_, SN_, PAR_, (B_) + 1) W4_P1(SC_, SN_, PAR_, (B_) + 2) W4_P1(SC_, SN_, PAR_, (B_) + 3)
-#define W4_P2x2(SN_, N_) W4_P2(SN_, (N_), 0) W4_P2(SN_, (N_), 1)
-#define W4_P2x8(SN_, B_) W4_P2x2(SN_, (B_)) W4_P2x2(SN_, (B_) + 1) W4_P2x2(SN_, (B_) + 2) W4_P2x2(SN_, (B_) + 3)
+#define W4_P2x2(SN_, ST_, PI_) W4_P2(SN_, ST_, PI_, 0) W4_P2(SN_, ST_, PI_, 1)
+#define W4_P2STEP(SN_, ST_) W4_P2x2(SN_, ST_, 0) W4_P2x2(SN_, ST_, 1) W4_P2x2(SN_, ST_, 2) W4_P2x2(SN_, ST_, 3) W4_P2x2(SN_, ST_, 4)
 
     // ---- one key tile t of parity PAR_ (literal): SC_ = S(t) (sub-block 0 already exp2'ed, its row sum in psum0),
     //      SN_ = S(t+1).  Ring slots: K(t+1) is read from K slot 1 - PAR_, V(t) from V slot PAR_; the DMA of K(t+2)
@@ -508,8 +526,10 @@ void attn_w4_kernel(const AttnParams p) {
             if constexpr (ll_ + 1 < 32 && ((ll_ + 1) & 1)) { W4_PACK2(SC_, 1, ll_) }                           \
             if constexpr (ll_ + 2 < 32 && ((ll_ + 2) & 1)) { W4_PACK2(SC_, 1, ll_ + 1) }                       \
         }                                                                                                      \
-        l_run[0] += psum0;                                                                                     \
-        l_run[1] += psum1_ + W4_EL(SC_, 1, 31);                                                                \
+        if constexpr (!kMS) {                                                                                  \
+            l_run[0] += psum0;                                                                                 \
+            l_run[1] += psum1_ + W4_EL(SC_, 1, 31);                                                            \
+        }                                                                                                      \
         W4_FENCE                                                                                               \
         W4_STAMP(ts4)                                                                                          \
         /* ================= phase 2 ================= */                                                       \
@@ -517,19 +537,19 @@ void attn_w4_kernel(const AttnParams p) {
         float mxp_[2] = {-INFINITY, -INFINITY}, dm_[2] = {0.f, 0.f};                                           \
         bool resc_ = false;                                                                                    \
         float psn_ = 0.f;                                                                                      \
-        W4_P2x8(SN_, 0) W4_P2x8(SN_, 4) W4_P2x8(SN_, 8) W4_P2x8(SN_, 12)                                       \
+        W4_P2STEP(SN_, 0) W4_P2STEP(SN_, 1) W4_P2STEP(SN_, 2) W4_P2STEP(SN_, 3)                                \
         /* the O / l side of a rescale, between tiles (after the last P(t).V(t) product) */                    \
         if (has_next_) {                                                                                       \
             if (__builtin_expect(resc_, 0)) {                                                                  \
                 asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       /* MFMA writes of O -> vector reads */ \
                 _Pragma("unroll") for (int qs_ = 0; qs_ < 2; ++qs_) {                                          \
                     const float alpha_ = __builtin_amdgcn_exp2f(-dm_[qs_]);                                    \
-                    l_run[qs_] *= alpha_;                                                                      \
+                    l_run[qs_] *= alpha_;          /* (kMS: l lives in tuples 2 / 6 and is scaled with O) */   \
                     w4_o_scale(qs_, alpha_);                                                                   \
                 }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
-        if (has_next_) psum0 = psn_ + W4_EL(SN_, 0, 31);        /* the last element's share of the row sum */        \
+        if (has_next_ && !kMS) psum0 = psn_ + W4_EL(SN_, 0, 31);        /* the last element's share of the row sum */        \
         W4_FENCE                                                                                               \
         W4_STAMP(ts5)                                                                                          \
         W4_STAMP_ACC                                                                                           \
@@ -691,8 +711,15 @@ void attn_w4_kernel(const AttnParams p) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // last MFMA writes of O -> vector reads
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qs]), __float_as_uint(l_run[qs]), false, false);
-        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        float l;
+        if constexpr (kMS) {                       // every row of the ones tile holds the full row sum of its query
+            float fl[16];
+            w4_o_read(4 * qs + 2, fl);
+            l = fl[0];
+        } else {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qs]), __float_as_uint(l_run[qs]), false, false);
+            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
         if (part >= 0) {
             // same layout as the 8-wave kernel's partials: its wave 2w + qs owns these 32 query rows
             float* w = p.ws + (int64_t)part * partial_floats<D>();
