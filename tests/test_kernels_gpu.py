@@ -541,3 +541,25 @@ def test_headnorm_rope_out_scale():
     assert rel_rms(scaled.float() / c, plain.float()) < 2.0 ** -8
     # text rows: exactly the rounded plain result times c, rounded again
     assert torch.equal(scaled[:, :lt], (plain[:, :lt].float() * c).bfloat16())
+
+
+def test_diag_mfma_peak_runs_and_counts_flops():
+    """fino_diag_mfma_peak (tools/mfma_peak.py): launches, reports the FLOPs it launched, and sustains a plausible rate"""
+    import ctypes
+    from frameino_amd import _lib
+    lib = _lib.lib()
+    scratch = torch.zeros(64 + 2 * 256 * 4, device=DEV)
+    fl = ctypes.c_double()
+    for kind in (0, 1):
+        _lib.check(lib.fino_diag_mfma_peak(kind, 2, 200, scratch.data_ptr(), ctypes.byref(fl), None), "diag")
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        _lib.check(lib.fino_diag_mfma_peak(kind, 2, 20000, scratch.data_ptr(), ctypes.byref(fl), None), "diag")
+        e.record()
+        torch.cuda.synchronize()
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert fl.value == cus * 2 * 4.0 * 20000 * 524288.0
+        tf = fl.value / (s.elapsed_time(e) * 1e-3) / 1e12
+        assert 500.0 < tf < 2600.0, tf
+    assert lib.fino_diag_mfma_peak(7, 2, 10, scratch.data_ptr(), ctypes.byref(fl), None) != 0      # bad kind -> error code
