@@ -315,7 +315,11 @@ void attn_w4_kernel(const AttnParams p) {
     // of its own prefetch in every tile.  LDS returns data in order, so "lgkmcnt(n)" = all but the last n reads landed.
 #define W4_LD128(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_));
 #define W4_LDTR(DST_, ADDR_, OFF_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_));
+#ifdef W4_X_NOLGKM         /* timing experiment: no waits for LDS fragment reads (wrong results) */
+#define W4_WAIT_LGKM(N_)
+#else
 #define W4_WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory");
+#endif
     // loop-invariant fragment addresses: ring slots and the +32-row / +16-key-row steps are instruction offsets
     uint32_t ka_addr[kKS], vl_addr[kDT], vh_addr[kDT];
 #pragma unroll
@@ -375,6 +379,9 @@ void attn_w4_kernel(const AttnParams p) {
     // exp2 of elements [LO_, LO_ + N_) of a sub-block and the row-sum adds of the elements BEFORE each of them (PREV_ =
     // element LO_ - 1, or zero), as ONE asm statement (between two statements the hazard recogniser pads with s_nop).
     // LO_, N_ are constant expressions (the slices are spelled out by literal index below).
+#ifdef W4_X_NOEXP          /* timing experiment: no exp2 / row-sum adds at all (wrong results) */
+#define W4_EXPADD(S_, QS_, LO_, N_, PREV_, SUM_)
+#else
 #define W4_EXPADD(S_, QS_, LO_, N_, PREV_, SUM_)                                                               \
     {                                                                                                          \
         if constexpr (kMS) {                    /* row sums on the matrix pipe: exp2 only */                    \
@@ -392,6 +399,7 @@ void attn_w4_kernel(const AttnParams p) {
                          : "+v"(W4_EL(S_, QS_, LO_)), "+v"(W4_EL(S_, QS_, (LO_) + 1)), "+v"(W4_EL(S_, QS_, (LO_) + 2)), \
                            "+v"(SUM_) : "v"(PREV_));                                                           \
     }
+#endif
     // element E_ - 1 as the PREV_ operand above (zero before element 0)
 #define W4_PREV(S_, QS_, E_) ((E_) >= 1 ? W4_EL(S_, QS_, (E_) >= 1 ? (E_) - 1 : 0) : zero_f)
     const float zero_f = 0.f;
