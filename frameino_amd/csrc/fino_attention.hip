@@ -420,13 +420,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
 
     // ---- staging roles: each group (waves 0-3 / 4-7) moves ITS half (32 rows) of a tile ----
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    int st_row[kLoadsPerThread], st_ch[kLoadsPerThread], st_off[kLoadsPerThread];
+    int st_row[kLoadsPerThread], st_ch[kLoadsPerThread], st_off[kLoadsPerThread], st_off_k[kLoadsPerThread];
 #pragma unroll
     for (int i = 0; i < kLoadsPerThread; ++i) {
         const int cid = (tid & 255) + i * 256;
         st_row[i] = grp * 32 + cid / kChunksPerRow;
         st_ch[i] = cid % kChunksPerRow;
         st_off[i] = lds_off<D>(st_row[i], st_ch[i]);
+        st_off_k[i] = k_lds_off<D>(st_row[i], st_ch[i]);       // K tiles have their own swizzle at head_dim 64 (k_lds_off)
     }
     u32x4_t kreg[kLoadsPerThread], vreg[kLoadsPerThread];
     // my half of K(W_+1) and V(W_): global -> registers with buffer loads: the per-thread part of the address is a fixed
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     // registers -> LDS: K ring slot (W_+1)&1, V ring slot 2 + (W_&1)
 #define PP_WRITE(W_)                                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                       \
-        *reinterpret_cast<u32x4_t*>(smem + (((W_) + 1) & 1) * kTileBytes + st_off[i_]) = kreg[i_];         \
+        *reinterpret_cast<u32x4_t*>(smem + (((W_) + 1) & 1) * kTileBytes + st_off_k[i_]) = kreg[i_];       \
         *reinterpret_cast<u32x4_t*>(smem + (2 + ((W_) & 1)) * kTileBytes + st_off[i_]) = vreg[i_];         \
     }
 
@@ -480,9 +481,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         const u32x4_t v0v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, vvo[i], 0, 0));
         const u32x4_t k1v =
             __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kvo[i], k_tile_bytes, 0));
-        *reinterpret_cast<u32x4_t*>(smem + 0 * kTileBytes + st_off[i]) = k0v;
+        *reinterpret_cast<u32x4_t*>(smem + 0 * kTileBytes + st_off_k[i]) = k0v;
         *reinterpret_cast<u32x4_t*>(smem + 2 * kTileBytes + st_off[i]) = v0v;
-        *reinterpret_cast<u32x4_t*>(smem + 1 * kTileBytes + st_off[i]) = k1v;
+        *reinterpret_cast<u32x4_t*>(smem + 1 * kTileBytes + st_off_k[i]) = k1v;
     }
     if (grp == 1) { PP_LOAD(1) }          // group 1 writes tile 1 in its first softmax phase
     __syncthreads();
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         const char* kb_ = smem + (KB_) * kTileBytes;                                                        \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) { sc0[j_] = 0.f; sc1[j_] = 0.f; }                 \
         _Pragma("unroll") for (int ks_ = 0; ks_ < kKS; ++ks_) {                                             \
-            const uint4 a0_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(r, 2 * ks_ + h));            \
-            const uint4 a1_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(32 + r, 2 * ks_ + h));       \
+            const uint4 a0_ = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(r, 2 * ks_ + h));            \
+            const uint4 a1_ = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(32 + r, 2 * ks_ + h));       \
             sc0 = T::mfma32(__builtin_bit_cast(vec8, a0_), qf[ks_], sc0);                                   \
             sc1 = T::mfma32(__builtin_bit_cast(vec8, a1_), qf[ks_], sc1);                                   \
         }                                                                                                   \
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     // are instruction offsets; and the ring slot (K: slot (t+1)&1, V: slot 2 + (t&1)) is the kTileBytes bit, toggled
     // once per tile.  Raw LDS addresses: the dynamic segment is the kernel's only LDS, so it starts at 0.
     if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
-    uint32_t ka0 = 1 * kTileBytes + lds_off<D>(r, h);
+    uint32_t ka0 = 1 * kTileBytes + k_lds_off<D>(r, h);
     uint32_t vl0 = 2 * kTileBytes + lds_off<D>(4 * h + tq, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
     uint32_t vh0 = 2 * kTileBytes + lds_off<D>(4 * h + tq + 8, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
 #define LDS_PTR(TYPE_, ADDR_) ((FINO_LDS TYPE_*)(uintptr_t)(uint32_t)(ADDR_))

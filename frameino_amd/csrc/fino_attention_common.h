@@ -66,6 +66,18 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 }
 
 
+// Byte offset of 16-byte chunk `ch` of row `row` inside a K tile.  head_dim 128: the shared lds_off image (no conflicts
+// measured).  head_dim 64 (128-byte rows): lds_off's swizzle was built for the transposed V reads and lets rows r and
+// r + 8 of a 32-row K fragment read share banks (SQ_LDS_BANK_CONFLICT 276 M cycles per launch at the CogVideoX shape,
+// profiles/r02_attn_d64_before_summary.json); a ds_read_b128 group of 16 lanes covers 16 rows x one chunk = two rows
+// per 256-byte bank line, so the 8 rows of a parity need 8 distinct chunk slots: swizzle = (row >> 1) & 7.
+template <int D>
+__device__ __forceinline__ int k_lds_off(int row, int ch) {
+    if constexpr (D == 128) return lds_off<D>(row, ch);
+    else return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+}
+
+
 }  // namespace fino_attn_ns
 
 // 4-wave kernel: defined in fino_attention_w4.hip (head_dim 128; head_dim 64 with the folded softmax scale only)

@@ -186,9 +186,10 @@ void attn_w4_kernel(const AttnParams p) {
     for (int j = 0; j < kNPW; ++j) {
         constexpr int cpr = D / 8, rpp = 1024 / (D * 2);
         const int row = 16 * wave + rpp * j + lane / cpr;
-        const int ch = ((lds_off<D>(row, lane % cpr) - row * (D * 2)) >> 4);       // = (lane % cpr) ^ swizzle(row)
-        kvo[j] = (uint32_t)((row * p.k_rs + ch * 8) * 2);
-        vvo[j] = (uint32_t)((row * p.v_rs + ch * 8) * 2);
+        const int chk = ((k_lds_off<D>(row, lane % cpr) - row * (D * 2)) >> 4);     // = (lane % cpr) ^ K swizzle(row)
+        const int chv = ((lds_off<D>(row, lane % cpr) - row * (D * 2)) >> 4);      // = (lane % cpr) ^ V swizzle(row)
+        kvo[j] = (uint32_t)((row * p.k_rs + chk * 8) * 2);
+        vvo[j] = (uint32_t)((row * p.v_rs + chv * 8) * 2);
     }
     const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
     // K(t) -> slot t & 1 (bytes 0 / 16 K), V(t) -> slot 2 + (t & 1)
@@ -214,7 +215,7 @@ void attn_w4_kernel(const AttnParams p) {
     const int tq = (lane & 15) >> 2;
     const int tp = lane & 3;
     const int g1 = (lane >> 4) & 1;
-    const uint32_t ka_base = lds_off<D>(r, h);
+    const uint32_t ka_base = k_lds_off<D>(r, h);
     const uint32_t vl_base = 2 * kW4TileBytes + lds_off<D>(4 * h + tq, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
     const uint32_t vh_base = 2 * kW4TileBytes + lds_off<D>(4 * h + tq + 8, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
 
