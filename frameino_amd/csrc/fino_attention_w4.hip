@@ -308,6 +308,13 @@ void attn_w4_kernel(const AttnParams p) {
             psum0 += sa[0][kh][j];
         }
 
+#if defined(W4_X_PACKPERM)
+    uint32_t perm_sel = 0x07060302u;
+    asm volatile("" : "+v"(perm_sel));
+#elif defined(W4_X_PACKCONST)
+    float pk_c0 = 0.25f, pk_c1 = 0.5f;
+    asm volatile("" : "+v"(pk_c0), "+v"(pk_c1));
+#endif
     u32x4_t pb[2][4];              // P(t) packed bf16: pb[sub-block][2 * key half + (j >> 3)]
 
     // The fragment reads of the tile loop are inline asm with hand-counted lgkmcnt waits.  As compiler-visible loads
@@ -359,6 +366,24 @@ void attn_w4_kernel(const AttnParams p) {
     }
 #define W4_EL(S_, QS_, E_) S_[QS_][(E_) >> 4][(E_) & 15]
     // pack elements (E_, E_ + 1) of sub-block QS_ (E_ even) into P's B-operand registers
+#ifdef W4_X_NOPACK         /* timing experiment: P is never packed (wrong results) */
+#define W4_PACK2(S_, QS_, E_)
+#elif defined(W4_X_PACKPERM)   /* timing experiment: P truncated to bf16 by one v_perm_b32 per pair */
+#define W4_PACK2(S_, QS_, E_)                                                                                  \
+    {                                                                                                          \
+        uint32_t w_;                                                                                           \
+        asm volatile("v_perm_b32 %0, %2, %1, %3" : "=v"(w_)                                                    \
+                     : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]), "v"(perm_sel)); \
+        pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
+    }
+#elif defined(W4_X_PACKCONST)  /* timing experiment: the packs read two loop-invariant registers (wrong results) */
+#define W4_PACK2(S_, QS_, E_)                                                                                  \
+    {                                                                                                          \
+        uint32_t w_;                                                                                           \
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w_) : "v"(pk_c0), "v"(pk_c1));                      \
+        pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
+    }
+#else
 #define W4_PACK2(S_, QS_, E_)                                                                                  \
     {                                                                                                          \
         uint32_t w_;                                                                                           \
@@ -370,6 +395,7 @@ void attn_w4_kernel(const AttnParams p) {
                          : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]));      \
         pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
     }
+#endif
     // V^T fragment pair n (= kDT * key step + d-tile) of the V slot at byte VS_ -> ring entry n & 3 (two 64-bit halves)
 #define W4_LOADV(N_, VS_)                                                                                      \
     {                                                                                                          \
@@ -411,6 +437,21 @@ void attn_w4_kernel(const AttnParams p) {
     //      sub-block 1 one slice after its second exp2), dealt by w4_lo; the 2 kNPW LDS-DMA pieces one per k-step ----
     // packs of phase-1 slice (lo_, n_, plo_ in scope): k-th element of this slice -> its sub-block-0 pair; k-th element of
     // the PREVIOUS slice, if odd -> the sub-block-1 pair it completes
+#ifdef W4_X_NOBAR          /* timing experiments (wrong results): no per-tile barrier / no K, V prefetch in the loop / no row maxima */
+#define W4_TILE_BARRIER
+#else
+#define W4_TILE_BARRIER __builtin_amdgcn_s_barrier();
+#endif
+#ifdef W4_X_NODMA
+    constexpr bool kDoDma = false;
+#else
+    constexpr bool kDoDma = true;
+#endif
+#ifdef W4_X_NOMAX
+    constexpr bool kNoMax = true;
+#else
+    constexpr bool kNoMax = false;
+#endif
 #define W4_P1_PACK(SC_, K_)                                                                                    \
     if constexpr ((K_) < n_ && lo_ + (K_) < 16) { W4_PACK2(SC_, 0, 2 * (lo_ + (K_))) }                         \
     if constexpr (s_ >= 1 && plo_ + (K_) < lo_ && ((plo_ + (K_)) & 1)) { W4_PACK2(SC_, 1, plo_ + (K_) - 1) }
@@ -435,7 +476,7 @@ void attn_w4_kernel(const AttnParams p) {
         }                                                                                                      \
         if constexpr (s_ >= 4 && i_ == 1) {                                                                    \
             if constexpr (ks_ < kNPW) { if (dma_k_) { W4_DMA_K1(t_ + 2, PAR_, ks_ < 0 ? 0 : ks_) } }           \
-            else if constexpr (ks_ < 2 * kNPW) { if (has_next_) { W4_DMA_V1(t_ + 1, 1 - (PAR_), ks_ - kNPW) } } \
+            else if constexpr (ks_ < 2 * kNPW) { if (has_next_ && kDoDma) { W4_DMA_V1(t_ + 1, 1 - (PAR_), ks_ - kNPW) } } \
         }                                                                                                      \
         {                                                                                                      \
             constexpr int lo_ = w4_lo(s_, w4_s1(D)), n_ = w4_lo(s_ + 1, w4_s1(D)) - lo_;                        \
@@ -463,7 +504,8 @@ void attn_w4_kernel(const AttnParams p) {
         if constexpr (pi_ < kDT) w4_o_mfma<T>(4 * qs_ + pi_, va_, pb[qs_][st_]);                               \
         else w4_o_mfma<T>(4 * qs_ + 2, ones_v, pb[qs_][st_]);          /* l^T += ones . P^T (tuples 2 / 6) */   \
         if constexpr (has_next_) {                                                                             \
-            if constexpr (s_ < 4) {             /* a quarter of both sub-blocks' row maxima: two independent chains */ \
+            if constexpr (kNoMax) {                                                                            \
+            } else if constexpr (s_ < 4) {      /* a quarter of both sub-blocks' row maxima: two independent chains */ \
                 constexpr int kh_ = s_ >> 1, o_ = 8 * (s_ & 1);                                                \
                 mxp_[0] = fmx(mxp_[0], W4_MAX8(SN_[0][kh_], o_));                                              \
                 mxp_[1] = fmx(mxp_[1], W4_MAX8(SN_[1][kh_], o_));                                              \
@@ -490,6 +532,10 @@ void attn_w4_kernel(const AttnParams p) {
                 constexpr int lo_ = w4_lo(s_ - 5, w4_s2(D) - 5), cnt_ = w4_lo(s_ - 4, w4_s2(D) - 5) - lo_;      \
                 W4_EXPADD(SN_, 0, lo_, cnt_, W4_PREV(SN_, 0, lo_), psn_)                                       \
             }                                                                                                  \
+            if constexpr (kNoMax && s_ >= 5) {                                                                 \
+                constexpr int lo_ = w4_lo(s_ - 5, w4_s2(D) - 5), cnt_ = w4_lo(s_ - 4, w4_s2(D) - 5) - lo_;      \
+                W4_EXPADD(SN_, 0, lo_, cnt_, W4_PREV(SN_, 0, lo_), psn_)                                       \
+            }                                                                                                  \
         }                                                                                                      \
         W4_FENCE                                                                                               \
     }
@@ -509,10 +555,10 @@ void attn_w4_kernel(const AttnParams p) {
         W4_STAMP(ts0)                                                                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
         W4_STAMP(ts1)                                                                                          \
-        __builtin_amdgcn_s_barrier();                                                                          \
+        W4_TILE_BARRIER                                                                                        \
         W4_FENCE                                                                                               \
         W4_STAMP(ts2)                                                                                          \
-        const bool dma_k_ = t_ + 2 < nt;                                                                       \
+        const bool dma_k_ = kDoDma && t_ + 2 < nt;                                                             \
         W4_STAMP(ts3)                                                                                          \
         /* ================= phase 1 ================= */                                                       \
         float psum1_ = 0.f;                                                                                    \
