@@ -401,6 +401,10 @@ def main():
         # the app's default clip (81 frames 704x1280, app.py:543)
         secondary["app_default_81f_704x1280_L19360"] = other_workload_ms_per_step(
             pipe, make_inputs, cfg, dev, "wan2.2-5b-81f-704x1280")
+        # the headline workload again with MXFP8 linears (e4m3 + e8m0 per 32; attention stays bf16): not the headline
+        model.enable_mxfp8_linears()
+        secondary["wan_704x1280_mxfp8_linears"] = other_workload_ms_per_step(pipe, make_inputs, cfg, dev, a.workload)
+        model.enable_mxfp8_linears(False)
         # (e) BASELINE config 5: CogVideoX-5B FrameINO 49f 480x720, bf16 and MXFP8 linears
         del pipe, st
         model.reset_caches()
