@@ -1,6 +1,7 @@
 """Seeded random-shape sweeps of the two MFMA kernels against fp32 torch on the device: the shape-dependent control
 paths (attention tail-split planning: blocks per XCD, key ranges that straddle block boundaries, head counts that
 leave XCDs empty; GEMM ragged M / N, K-tile counts, every epilogue) are exercised far beyond the hand-picked cases."""
+import os
 import random
 
 import pytest
@@ -11,6 +12,9 @@ from tests.test_kernels_gpu import gemm_ref, sdpa_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# a longer hunt on a GPU box: FINO_FUZZ_N=400 FINO_FUZZ_SEED=7 python -m pytest tests/test_fuzz_gpu.py -m gpu -q
+FUZZ_N = int(os.environ.get("FINO_FUZZ_N", 48))
+FUZZ_SEED = int(os.environ.get("FINO_FUZZ_SEED", 0))
 
 
 def _attention_cases(n, seed):
@@ -29,7 +33,7 @@ def _attention_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _attention_cases(48, 1234), ids=lambda c: "b%d_h%d_d%d_q%d_k%d" % c)
+@pytest.mark.parametrize("case", _attention_cases(FUZZ_N, 1234 + FUZZ_SEED), ids=lambda c: "b%d_h%d_d%d_q%d_k%d" % c)
 def test_attention_random_shapes(case):
     from frameino_amd import ops
     b, heads, dh, lq, lk = case
@@ -56,7 +60,7 @@ def _gemm_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _gemm_cases(48, 4321), ids=lambda c: "m%d_n%d_k%d_e%d" % c)
+@pytest.mark.parametrize("case", _gemm_cases(FUZZ_N, 4321 + FUZZ_SEED), ids=lambda c: "m%d_n%d_k%d_e%d" % c)
 def test_gemm_random_shapes(case):
     from frameino_amd import ops
     m, n, k, epi = case
@@ -70,3 +74,26 @@ def test_gemm_random_shapes(case):
     out = ops.gemm(a, w, bias, epi, res, gate, sel)
     ref = gemm_ref(a, w, bias, epi, res, gate, sel)
     assert rel_rms(out, ref.float()) < 2.0 ** -7, rel_rms(out, ref.float())
+
+
+@pytest.mark.parametrize("case", _attention_cases(FUZZ_N, 777 + FUZZ_SEED), ids=lambda c: "b%d_h%d_d%d_q%d_k%d" % c)
+def test_attention_four_wave_folded_random_shapes(case):
+    """the 4-wave kernel (FINO_TUNE_ATTN_KERNEL = 2) with the softmax scale folded into q -- CogVideoX's default
+    attention path -- over the same kind of sweep: each output against SDPA of the q it was given"""
+    from frameino_amd import _lib, ops
+    b, heads, dh, lq, lk = case
+    g = torch.Generator(device=DEV).manual_seed(hash(case) & 0xffff)
+    c = dh ** -0.5 * ops.LOG2E
+    qs = (torch.randn(b, lq, heads * dh, device=DEV, generator=g) * c).bfloat16()
+    k = torch.randn(b, lk, heads * dh, device=DEV, generator=g).bfloat16()
+    v = torch.randn(b, lk, heads * dh, device=DEV, generator=g).bfloat16()
+    lib = _lib.lib()
+    lib.fino_tune_set(4, 2)
+    try:
+        o = ops.attention(qs, k, v, heads, scale=ops.SCALE_FOLDED)
+    finally:
+        lib.fino_tune_set(4, 0)
+    ref = sdpa_ref((qs.float() / c), k, v, heads)
+    assert torch.isfinite(o.float()).all()
+    assert rel_rms(o, ref) < 2.0 ** -6, rel_rms(o, ref)
+    assert (o.float() - ref).abs().max().item() < 0.06
