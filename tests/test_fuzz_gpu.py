@@ -97,3 +97,46 @@ def test_attention_four_wave_folded_random_shapes(case):
     assert torch.isfinite(o.float()).all()
     assert rel_rms(o, ref) < 2.0 ** -6, rel_rms(o, ref)
     assert (o.float() - ref).abs().max().item() < 0.06
+
+
+def _split_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        dh = rng.choice([64, 128])
+        heads = rng.choice([1, 2, 3, 6, 12, 24])
+        b = rng.choice([1, 2])
+        lq = rng.choice([rng.randint(1, 300), rng.randint(300, 1600), 256 * rng.randint(1, 6)])
+        nparts = rng.choice([1, 2, 3])
+        lens = tuple(rng.choice([rng.randint(1, 70), rng.randint(64, 900), 64 * rng.randint(1, 12)]) for _ in range(nparts))
+        out.append((b, heads, dh, lq, lens, rng.choice([0, 2])))
+    return out
+
+
+@pytest.mark.parametrize("case", _split_cases(FUZZ_N, 99 + FUZZ_SEED), ids=lambda c: "b%d_h%d_d%d_q%d_k%s_t%d" % (
+    c[0], c[1], c[2], c[3], "+".join(map(str, c[4])), c[5]))
+def test_attention_partials_random_key_splits(case):
+    """what the token-sharded forward does (own K/V chunk, then the gathered chunks before / after it): 1-3 partials over
+    random disjoint key ranges, merged, against fp32 SDPA over all keys -- 8-wave and 4-wave kernels"""
+    from frameino_amd import _lib, ops
+    b, heads, dh, lq, lens, tune = case
+    g = torch.Generator(device=DEV).manual_seed(hash(case) & 0xffff)
+    d = heads * dh
+    lk = sum(lens)
+    q = torch.randn(b, lq, d, device=DEV, generator=g).bfloat16()
+    kv = torch.randn(b, lk, 2 * d, device=DEV, generator=g).bfloat16()
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    lib = _lib.lib()
+    lib.fino_tune_set(4, tune)
+    try:
+        parts, a = [], 0
+        for n in lens:
+            parts.append(ops.attention_partial(q, k[:, a:a + n], v[:, a:a + n], heads))
+            a += n
+        merged = ops.attention_merge(parts, b, lq, heads, dh, q.dtype)
+    finally:
+        lib.fino_tune_set(4, 0)
+    ref = sdpa_ref(q, k, v, heads)
+    assert torch.isfinite(merged.float()).all()
+    assert rel_rms(merged, ref) < 2.0 ** -6, rel_rms(merged, ref)
+    assert (merged.float() - ref).abs().max().item() < 0.06
