@@ -19,6 +19,14 @@ The reference has no multi-GPU inference path; this is new des
   GEMMs and attention instead of standing in front of its own (with one branch per rank nothing can overlap it: the
   gather is ~1.1 ms per layer on one xGMI link pair at 4 GPUs against ~2.8 ms of compute).
 
+* **heads exchange** (`exchange="heads"`, the sequence-parallel all-to-all) -- instead of gathering every rank's K|V,
+  the ranks of a token group trade token shards for head shards around the self-attention: each rank projects q | k | v
+  of ITS tokens (one fused GEMM, norm + RoPE as on one GPU), an **all-to-all** hands rank j the q | k | v of ALL tokens
+  for heads [j.H/P, (j+1).H/P), it attends those heads over the whole sequence (one launch, no partials), and a second
+  all-to-all returns the outputs to the token owners.  Bytes sent per rank and layer: (P-1)/P . n . 4D . 2 against
+  (P-1) . n . 2D . 2 received by the K|V all-gather -- equal at P = 2, half at 4, a quarter at 8 -- and on the fully
+  connected xGMI mesh every pair's link carries exactly its own 1/P share.  Needs heads % P == 0 (24 heads: 2, 4, 8).
+
 `shard_pipeline(pipe, rank, world)` picks cfg x token = 2 x (world/2) for even `world`, else 1 x world; `mode=` selects
 the interleaved plan (bench.py probes both on the node and keeps the faster).  Latents and the sampler state are
 replicated (2.2 M floats); every rank performs the same CFG+Euler update.
@@ -28,10 +36,11 @@ import torch.distributed as dist
 
 
 class TokenShard:
-    def __init__(self, rank, ways, group=None, force=False):
+    def __init__(self, rank, ways, group=None, force=False, exchange="kv"):
         # force: take the sharded code path (separate K|V / Q projections, all-gather through the communicator) even
         # with one shard -- how a single GPU exercises the RCCL call sequence (tests/test_parallel_gpu.py)
         self.rank, self.ways, self.group, self.force = rank, ways, group, force
+        self.exchange = exchange          # "kv": all-gather of K|V; "heads": all-to-all token shards <-> head shards
         self._buf = {}
         # attend to the LOCAL K/V chunk while the other ranks' chunks are still on the wire, then to what arrived, and
         # merge the partials (fino_attn_partial / fino_attn_merge): hides up to 1/ways of the attention under the gather.
@@ -85,6 +94,24 @@ class TokenShard:
         work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=async_op)
         return out, work
 
+    def heads_exchange_ok(self, heads):
+        return self.exchange == "heads" and heads % self.ways == 0
+
+    def all_to_all(self, key, send):
+        """send [ways, rows, width] (slice j goes to rank j) -> the received [ways, rows, width] (slice j came from rank j).
+        Blocking in stream order (the caller's next kernel reads the result)."""
+        recv = self._get(key, tuple(send.shape), send.dtype, send.device)
+        if dist.get_backend(self.group) == "gloo" and send.is_cuda:      # tests on one GPU: staged through host memory
+            r = torch.empty(send.shape, dtype=send.dtype)
+            dist.all_to_all_single(r, send.cpu().contiguous(), group=self.group)
+            recv.copy_(r.to(send.device))
+            return recv
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def a2a_buffer(self, key, shape, dtype, dev):
+        return self._get(key, shape, dtype, dev)
+
     def all_gather_kv(self, kv_loc):
         """-> ([ways*lpad, 2D] buffer, work handle to wait on before the attention launch)."""
         return self._all_gather("kv_all", kv_loc, True)
@@ -94,24 +121,32 @@ class TokenShard:
 
 
 class ParallelPlan:
-    def __init__(self, rank, world, cfg_ways, token_ways, token_group, cfg_group, token_group_b=None):
+    def __init__(self, rank, world, cfg_ways, token_ways, token_group, cfg_group, token_group_b=None, exchange="kv"):
         self.rank, self.world = rank, world
         self.cfg_ways, self.token_ways = cfg_ways, token_ways
         self.cfg_idx, self.tok_rank = rank // token_ways, rank % token_ways
         self.token_group, self.cfg_group = token_group, cfg_group
         force = world == 1                    # single-rank rehearsal of the N>1 call sequence
-        self.shard = TokenShard(self.tok_rank, token_ways, token_group, force)
+        self.exchange = exchange
+        self.token_group_b = token_group_b
+        self.shard = TokenShard(self.tok_rank, token_ways, token_group, force, exchange)
         # interleaved plan: a second shard object (own buffers, own communicator) for the second CFG branch
         self.interleave = token_group_b is not None
-        self.shards = (self.shard, TokenShard(self.tok_rank, token_ways, token_group_b, force)) \
+        self.shards = (self.shard, TokenShard(self.tok_rank, token_ways, token_group_b, force, exchange)) \
             if self.interleave else None
         self._buf = None
 
+    def with_exchange(self, exchange):
+        """the same ranks, groups and communicators with the other self-attention exchange (bench.py probes both)"""
+        return ParallelPlan(self.rank, self.world, self.cfg_ways, self.token_ways, self.token_group, self.cfg_group,
+                            self.token_group_b, exchange)
+
     @property
     def desc(self):
+        tail = "-heads" if self.exchange == "heads" else ""
         if self.interleave:
-            return f"token{self.token_ways}x2branches-interleaved"
-        return f"cfg{self.cfg_ways}xtoken{self.token_ways}"
+            return f"token{self.token_ways}x2branches-interleaved{tail}"
+        return f"cfg{self.cfg_ways}xtoken{self.token_ways}{tail}"
 
     def exchange_cfg(self, mine):
         """all-gather of the two CFG branches' predictions inside the pair group -> (cond_pred, uncond_pred)."""
@@ -129,7 +164,7 @@ class ParallelPlan:
         return self._buf[0], self._buf[1]
 
 
-def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False):
+def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False, exchange="kv"):
     """`allow_single`: build the plan for world == 1 too (the sharded code path forced through real communicators of
     one rank -- the rehearsal a 1-GPU box can run)."""
     if mode == "interleave":
@@ -137,7 +172,7 @@ def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False):
             raise ValueError("the interleaved plan needs at least 2 ranks")
         ga = dist.new_group(list(range(world)))      # one communicator per branch: their collectives are independent
         gb = dist.new_group(list(range(world)))
-        return ParallelPlan(rank, world, 1, world, ga, None, token_group_b=gb)
+        return ParallelPlan(rank, world, 1, world, ga, None, token_group_b=gb, exchange=exchange)
     cfg_ways = 2 if (cfg_parallel and world % 2 == 0) else 1
     token_ways = world // cfg_ways
     token_group = cfg_group = None
@@ -152,11 +187,15 @@ def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False):
         g = dist.new_group(ranks) if cfg_ways > 1 else None
         if rank in ranks:
             cfg_group = g
-    return ParallelPlan(rank, world, cfg_ways, token_ways, token_group, cfg_group)
+    return ParallelPlan(rank, world, cfg_ways, token_ways, token_group, cfg_group, exchange=exchange)
 
 
-def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None, allow_single=False):
-    plan = plan or make_plan(rank, world, cfg_parallel, mode, allow_single)
+def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None, allow_single=False, exchange="kv"):
+    plan = plan or make_plan(rank, world, cfg_parallel, mode, allow_single, exchange)
+    heads = getattr(getattr(pipe.transformer, "config", None), "num_attention_heads", None)
+    if plan.exchange == "heads" and heads is not None and heads % plan.token_ways != 0:
+        raise ValueError(f"the heads exchange needs num_attention_heads ({heads}) divisible by the token shards "
+                         f"({plan.token_ways})")
     pipe.parallel = plan
     pipe.parallel_desc = plan.desc
     pipe.token_shards = plan.token_ways

@@ -472,6 +472,25 @@ class WanTransformer3DModel(nn.Module):
                 o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                 q3 = qkv.view(b, n, 3 * d)
                 o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
+            elif sh.heads_exchange_ok(heads):
+                # heads exchange (frameino_amd/parallel.py): q | k | v of MY tokens -> all-to-all -> all tokens of MY
+                # heads -> one attention launch over the whole sequence -> all-to-all back to the token owners
+                ways = sh.ways
+                hp = heads // ways
+                dp = hp * dh
+                qkv = ws.qkv[:n]
+                self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
+                o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
+                o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                send = sh.a2a_buffer("qkv_send", (ways, lpad, 3, dp), dt, dev)       # slice j: heads of rank j
+                send[:, :n].copy_(qkv.view(n, 3, ways, dp).permute(2, 0, 1, 3))
+                recv = sh.all_to_all("qkv_recv", send)                               # slice j: tokens of rank j
+                r3 = recv.view(1, ways * lpad, 3 * dp)[:, :L]
+                oh = sh.a2a_buffer("o_send", (ways, lpad, dp), dt, dev)
+                o.attention(r3[:, :, :dp], r3[:, :, dp:2 * dp], r3[:, :, 2 * dp:], hp,
+                            out=oh.view(1, ways * lpad, dp)[:, :L], **afold)
+                orv = sh.all_to_all("o_recv", oh)                                    # slice j: heads of rank j, my tokens
+                att.view(n, ways, dp).copy_(orv[:, :n].permute(1, 0, 2))
             else:
                 # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)

@@ -31,15 +31,41 @@ def _run(pipe, a):
                         a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), int(a["steps"]))
 
 
-def _worker(rank, world, port, cfg_parallel, q, mode="split"):
+def _four_head_case():
+    """a seeded random 4-head model (the golden model has 2 heads: 4 token shards cannot trade them) and the golden
+    run's inputs; the oracle here is the same model in one process"""
+    cfg, sd, a = load_golden("wan_pipe_tiny")
+    cfg = dict(cfg, num_attention_heads=4)
+    from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
+    from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from frameino_amd.transformer_wan import WanTransformer3DModel
+    torch.manual_seed(11)
+    m = WanTransformer3DModel(**model_cfg(cfg)).float()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape) * (0.5 if p_.ndim == 1 else p_.shape[-1] ** -0.5))
+    m.reset_caches()
+    m.ops = cpu_ops
+    g = torch.Generator().manual_seed(3)
+    a = dict(a, prompt_embeds=torch.randn(1, 12, cfg["text_dim"], generator=g),
+             negative_embeds=torch.randn(1, 12, cfg["text_dim"], generator=g))
+    pipe = WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=m.eval(),
+                                   expand_timesteps=True)
+    return pipe, a
+
+
+def _worker(rank, world, port, cfg_parallel, q, mode="split", exchange="kv", four_heads=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from frameino_amd.parallel import shard_pipeline
-        cfg, sd, a = load_golden("wan_pipe_tiny")
-        pipe = _build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")})
-        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode)
+        if four_heads:
+            pipe, a = _four_head_case()
+        else:
+            cfg, sd, a = load_golden("wan_pipe_tiny")
+            pipe = _build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")})
+        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode, exchange=exchange)
         out = _run(pipe, a)
         q.put((rank, plan.desc, out))
     finally:
@@ -96,6 +122,55 @@ def test_four_rank_plans_match_single_process(mode, desc):
         assert d == desc
         torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)   # fp32; the local-first attention merges
         # (O, m, l) partials of two or three key ranges: another summation order than the single softmax pass
+
+
+def _spawn(world, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port) + tuple(args[:1]) + (q,) + tuple(args[1:])) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return outs
+
+
+@pytest.mark.parametrize("world,cfg_parallel,mode,desc", [
+    (2, False, "split", "cfg1xtoken2-heads"), (2, True, "interleave", "token2x2branches-interleaved-heads"),
+    (4, True, "split", "cfg2xtoken2-heads")])
+def test_heads_exchange_matches_single_process(world, cfg_parallel, mode, desc):
+    """the all-to-all exchange (token shards <-> head shards around the self-attention) on the golden 2-head model:
+    2 token shards, alone, with both branches interleaved, and under the CFG split of 4 ranks"""
+    cfg, sd, a = load_golden("wan_pipe_tiny")
+    single = _run(_build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}), a)
+    for rank, d, out in _spawn(world, (cfg_parallel, mode, "heads")):
+        assert d == desc
+        torch.testing.assert_close(out, single, atol=2e-5, rtol=2e-5)     # one softmax pass per head, as on one GPU
+
+
+@pytest.mark.parametrize("exchange,desc", [("heads", "token4x2branches-interleaved-heads"),
+                                           ("kv", "token4x2branches-interleaved")])
+def test_four_token_shards_of_a_four_head_model(exchange, desc):
+    """4 token shards trading 4 heads (one head per rank), both CFG branches interleaved; the K|V all-gather on the same
+    model beside it"""
+    pipe, a = _four_head_case()
+    single = _run(pipe, a)
+    assert torch.isfinite(single).all() and single.std() > 0.1
+    for rank, d, out in _spawn(4, (True, "interleave", exchange, True)):
+        assert d == desc
+        torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)
+
+
+def test_heads_exchange_refuses_indivisible_heads():
+    from frameino_amd.parallel import ParallelPlan, shard_pipeline
+    cfg, sd, _ = load_golden("wan_pipe_tiny")
+    pipe = _build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")})
+    plan = ParallelPlan(0, 3, 1, 3, None, None, exchange="heads")
+    with pytest.raises(ValueError, match="divisible"):
+        shard_pipeline(pipe, 0, 3, plan=plan)
 
 
 def test_token_shard_rows_cover_sequence_with_padding():

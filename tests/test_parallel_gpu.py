@@ -33,7 +33,7 @@ def _run(pipe, a, dev):
                         d("prompt_embeds"), d("negative_embeds"), float(a["guidance"]), int(a["steps"]))
 
 
-def _worker(rank, world, port, cfg_parallel, q, mode="split", overlap_local=True):
+def _worker(rank, world, port, cfg_parallel, q, mode="split", overlap_local=True, exchange="kv"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -41,7 +41,7 @@ def _worker(rank, world, port, cfg_parallel, q, mode="split", overlap_local=True
         from frameino_amd.parallel import shard_pipeline
         parallel.TokenShard.overlap_local = overlap_local
         pipe, a = _pipe("cuda:0")
-        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode)
+        plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode, exchange=exchange)
         out = _run(pipe, a, "cuda:0")
         q.put((rank, plan.desc, out.cpu()))
     finally:
@@ -93,7 +93,32 @@ def test_two_ranks_on_one_gpu_match_single_process(cfg_parallel, desc, overlap_l
     assert torch.equal(outs[0][2], outs[1][2])                # every rank holds the same latents
 
 
-def _nccl_worker(q, port, mode):
+@pytest.mark.parametrize("mode,desc", [("split", "cfg1xtoken2-heads"), ("interleave", "token2x2branches-interleaved-heads")])
+def test_two_ranks_on_one_gpu_heads_exchange(mode, desc):
+    """the all-to-all exchange with the real kernels: 2 token shards trading the tiny model's 2 heads (gloo, staged
+    through host memory): one attention launch per head over the whole sequence, i.e. the single-GPU arithmetic"""
+    pipe, a = _pipe("cuda:0")
+    pipe.batch_cfg = False
+    single = _run(pipe, a, "cuda:0").cpu()
+    del pipe
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, False, q, mode, True, "heads")) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, d, out in outs:
+        assert d == desc
+        assert rel_rms(out, single) < 5e-3, (rank, rel_rms(out, single))
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
+def _nccl_worker(q, port, mode, exchange="kv"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -104,7 +129,7 @@ def _nccl_worker(q, port, mode):
         pipe, a = _pipe("cuda:0")
         pipe.batch_cfg = False
         single = _run(pipe, a, "cuda:0").cpu()
-        plan = shard_pipeline(pipe, 0, 1, cfg_parallel=False, mode=mode, allow_single=True)
+        plan = shard_pipeline(pipe, 0, 1, cfg_parallel=False, mode=mode, allow_single=True, exchange=exchange)
         assert plan.shard.force and pipe.transformer.parallel is plan.shard
         assert dist.get_backend(plan.shard.group) == "nccl"
         out = _run(pipe, a, "cuda:0")
@@ -116,15 +141,18 @@ def _nccl_worker(q, port, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,desc", [("split", "cfg1xtoken1"), ("interleave", "token1x2branches-interleaved")])
-def test_sharded_path_through_rccl_single_rank(mode, desc):
+@pytest.mark.parametrize("mode,desc,exchange", [("split", "cfg1xtoken1", "kv"), ("interleave", "token1x2branches-interleaved", "kv"),
+                                                ("split", "cfg1xtoken1-heads", "heads"),
+                                                ("interleave", "token1x2branches-interleaved-heads", "heads")])
+def test_sharded_path_through_rccl_single_rank(mode, desc, exchange):
     """backend nccl (= RCCL), world_size 1: TokenShard.all_gather_kv -> all_gather_into_tensor(async_op=True) issued
     on the branch's stream, work.wait() before the attention launch, all_gather_out, and -- interleave -- two
-    communicators driven alternately from two HIP streams.  One GPU cannot show bandwidth; it does prove the call
-    sequence, the stream semantics and that the result is the unsharded one."""
+    communicators driven alternately from two HIP streams; `exchange="heads"`: the two all_to_all_single calls around
+    the self-attention instead.  One GPU cannot show bandwidth; it does prove the call sequence, the stream semantics
+    and that the result is the unsharded one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_nccl_worker, args=(q, _free_port(), mode))
+    p = ctx.Process(target=_nccl_worker, args=(q, _free_port(), mode, exchange))
     p.start()
     try:
         d, single, out, out2 = q.get(timeout=600)
