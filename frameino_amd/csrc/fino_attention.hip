@@ -82,9 +82,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnPara
         bx = p.full_x + tb;
         if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
     }
-    const int hb = xcd + 8 * (bx / p.nqb);
-    const int qb = bx % p.nqb;
-    if (hb >= p.batch * p.heads) continue;
+    int hb, qb;
+    if (!attn_map_block(p, xcd, bx, hb, qb)) continue;
     if (p.all_partial) part = hb * p.nqb + qb;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
@@ -393,9 +392,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         bx = p.full_x + tb;
         if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
     }
-    const int hb = xcd + 8 * (bx / p.nqb);
-    const int qb = bx % p.nqb;
-    if (hb >= p.batch * p.heads) continue;
+    int hb, qb;
+    if (!attn_map_block(p, xcd, bx, hb, qb)) continue;
     if (p.all_partial) part = hb * p.nqb + qb;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
@@ -742,9 +740,8 @@ __global__ __launch_bounds__(kWaves * 64) void attn_combine_kernel(const AttnPar
     const int xcd = blockIdx.x & 7, tb = blockIdx.x >> 3;
     const int dt = blockIdx.y;
     const int bx = p.full_x + tb;
-    const int hb = xcd + 8 * (bx / p.nqb);
-    const int qb = bx % p.nqb;
-    if (hb >= p.batch * p.heads) return;
+    int hb, qb;
+    if (!attn_map_block(p, xcd, bx, hb, qb)) return;
     const int ntall = (p.lk + kKV - 1) / kKV;
     // workgroups (ranges) that hold a piece of this block; one range = the block ran whole and is already stored
     const int c_first = (int)(((int64_t)tb * ntall) / p.per);
@@ -847,7 +844,9 @@ struct SplitPlan { int full_x, rem_x, nwg, per; };
 inline SplitPlan plan_split(int batch, int heads, int nqb, int nt) {
     constexpr int kMinTiles = 8;
     const int cus_x = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
-    const int nblk_x = ((batch * heads + 7) / 8) * nqb;
+    int vsplit, nqb_v;
+    attn_virtual_heads(batch, heads, nqb, vsplit, nqb_v);
+    const int nblk_x = ((batch * heads * vsplit + 7) / 8) * nqb_v;
     SplitPlan sp{nblk_x, 0, 0, 1};
     const int rem = nblk_x % cus_x;
     if (rem == 0) return sp;
@@ -876,9 +875,9 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
         return rc;
     if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_pp_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
         return rc;
-    const int hb = p.batch * p.heads;
-    const int groups = (hb + 7) / 8;
-    SplitPlan sp{groups * p.nqb, 0, 0, 1};
+    attn_virtual_heads(p.batch, p.heads, p.nqb, p.vsplit, p.nqb_v);
+    const int groups = (p.batch * p.heads * p.vsplit + 7) / 8;
+    SplitPlan sp{groups * p.nqb_v, 0, 0, 1};
     if (p.ws && !p.all_partial) {
         sp = plan_split(p.batch, p.heads, p.nqb, (p.lk + kKV - 1) / kKV);
         const int64_t need = (int64_t)8 * sp.nwg * 2 * partial_floats<D>() * 4;
@@ -887,7 +886,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
             return FINO_ERR_ARG;
         }
     }
-    if (p.all_partial) sp = SplitPlan{groups * p.nqb, 0, 0, 1};       // no tail split: every block is a partial anyway
+    if (p.all_partial) sp = SplitPlan{groups * p.nqb_v, 0, 0, 1};     // no tail split: every block is a partial anyway
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
     // head_dim 128 has two kernels.  On gaussian operands the 4-wave one is the faster standalone (B = 2, 24 heads, 12320^2:

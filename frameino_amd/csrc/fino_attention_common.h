@@ -28,6 +28,9 @@ struct AttnParams {
     int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
     float scale_log2;
     int nqb;  // q blocks per head
+    // XCD balance when batch*heads is not a multiple of 8 (see attn_map_block): every head is cut into `vsplit` virtual
+    // heads of `nqb_v` q-blocks; vsplit = 1, nqb_v = nqb otherwise
+    int vsplit, nqb_v;
     // tail split (see plan_split): per XCD the first `full_x` blocks run whole; the key tiles of the remaining `rem_x`
     // blocks form one stream that `nwg` workgroups cut into ranges of `per` tiles, leaving (O, m, l) partials in `ws`.
     int full_x, rem_x, nwg, per;
@@ -36,6 +39,28 @@ struct AttnParams {
     // storing O -- attention over one key range of several, merged by fino_attn_merge
     int all_partial;
 };
+
+// (XCD, slot in that XCD's list of blocks) -> (head-batch, q-block); false: an empty slot.  The q-blocks of one head run on
+// ONE XCD (hb = xcd + 8 g), so its K/V stream through that XCD's L2 only -- as long as batch*heads is a multiple of 8.
+// Otherwise (3, 6 or 12 heads per rank after the multi-GPU heads exchange) whole XCDs would idle: then every head is cut
+// into vsplit = 8 / gcd(batch*heads, 8) virtual heads of nqb_v = ceil(nqb / vsplit) consecutive q-blocks, whose count IS a
+// multiple of 8, and the same list walk spreads them over all eight XCDs.
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool attn_map_block(const AttnParams& p, int xcd, int bx, int& hb, int& qb) {
+    const int hv = xcd + 8 * (bx / p.nqb_v);
+    hb = hv / p.vsplit;
+    qb = (hv - hb * p.vsplit) * p.nqb_v + bx % p.nqb_v;
+    return hb < p.batch * p.heads && qb < p.nqb;
+}
+#endif
+// host side of the same rule: virtual heads per launch and q-blocks per virtual head
+inline void attn_virtual_heads(int batch, int heads, int nqb, int& vsplit, int& nqb_v) {
+    const int hb = batch * heads;
+    int g = hb % 8 == 0 ? 8 : (hb % 4 == 0 ? 4 : (hb % 2 == 0 ? 2 : 1));      // gcd(hb, 8)
+    vsplit = 8 / g;
+    if (vsplit > nqb) vsplit = 1;                    // fewer q-blocks than pieces: nothing to spread
+    nqb_v = (nqb + vsplit - 1) / vsplit;
+}
 
 // floats per partial: O^T accumulators in thread order + per-thread m and l
 template <int D>

@@ -139,12 +139,14 @@ void attn_w4_kernel(const AttnParams p) {
     }
     // (wave-uniform by construction; said explicitly, or the piece loop makes the compiler treat the K/V resources
     //  and DMA offsets as divergent and wrap every LDS-DMA in a readfirstlane loop)
-    const int hb = __builtin_amdgcn_readfirstlane(xcd + 8 * (bx / p.nqb));
-    const int qb = __builtin_amdgcn_readfirstlane(bx % p.nqb);
+    int hb_, qb_;
+    const bool mapped = attn_map_block(p, xcd, bx, hb_, qb_);
+    const int hb = __builtin_amdgcn_readfirstlane(hb_);
+    const int qb = __builtin_amdgcn_readfirstlane(qb_);
     t_begin = __builtin_amdgcn_readfirstlane(t_begin);
     t_end = __builtin_amdgcn_readfirstlane(t_end);
     part = __builtin_amdgcn_readfirstlane(part);
-    if (hb >= p.batch * p.heads) continue;
+    if (!mapped) continue;
     if (p.all_partial) part = hb * p.nqb + qb;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;

@@ -23,6 +23,11 @@ class FakeShard(TokenShard):
         out[:t.shape[0]].copy_(t)
         return out, None
 
+    def all_to_all(self, key, send):            # heads exchange: every slice "arrives" as a copy of what was sent
+        recv = self._get(key, tuple(send.shape), send.dtype, send.device)
+        recv.copy_(send)
+        return recv
+
 
 def main():
     from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
@@ -71,6 +76,18 @@ def main():
                                         shards=(FakeShard(0, ways), FakeShard(0, ways)))
         model.parallel = pipe.parallel.shards[0]
         print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+    # the same plans with the heads exchange (all-to-all instead of the K|V all-gather; attention over H/ways heads x all tokens)
+    for ways in (2, 4):
+        sh = FakeShard(0, ways, exchange="heads")
+        pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
+                                        exchange_cfg=lambda mine: (mine, mine))
+        model.parallel = sh
+        print(f"split-heads      N={2 * ways}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+    for ways in (2, 4, 8):
+        pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
+                                        shards=(FakeShard(0, ways, exchange="heads"), FakeShard(0, ways, exchange="heads")))
+        model.parallel = pipe.parallel.shards[0]
+        print(f"interleave-heads N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank")
 
 
 if __name__ == "__main__":
