@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--plan", choices=["auto", "split", "interleave"], default="auto",
                     help="N>1: cfg x token split, both CFG branches interleaved on token shards, or (auto, >= 4 GPUs) "
                          "measure split, then probe interleave under a watchdog and keep the faster")
+    ap.add_argument("--exchange", choices=["auto", "kv", "heads"], default="auto",
+                    help="N>1 self-attention exchange of the token shards: K|V all-gather, heads all-to-all, or (auto) "
+                         "both probed")
     ap.add_argument("--mxfp8", action="store_true",
                     help="NOT the headline: large linears on the MXFP8 path (BASELINE config 5 style), attention in bf16")
     ap.add_argument("--logit-scale", type=float, default=1.0,
@@ -188,10 +191,20 @@ def main():
         from frameino_amd.parallel import make_plan, shard_pipeline
         dog.arm("communicators", a.stall_s)
         # every rank creates every communicator, in the same order
+        base = {}
         if a.plan in ("auto", "split"):
-            plans["split"] = make_plan(rank, world, True, "split")
+            base["split"] = make_plan(rank, world, True, "split")
         if a.plan == "interleave" or (a.plan == "auto" and world >= 4):
-            plans["interleave"] = make_plan(rank, world, mode="interleave")
+            base["interleave"] = make_plan(rank, world, mode="interleave")
+        # each plan with the K|V all-gather and with the heads all-to-all (same communicators); the all-gather form of the
+        # first plan is measured first -- its line stands whatever happens in the probes that follow
+        nheads = cfg["num_attention_heads"]
+        for name, pl in base.items():
+            heads_ok = pl.token_ways > 1 and nheads % pl.token_ways == 0
+            if a.exchange in ("auto", "kv") or not heads_ok:
+                plans[name] = pl
+            if a.exchange in ("auto", "heads") and heads_ok:
+                plans[name + "-heads"] = pl.with_exchange("heads")
         shard_pipeline(pipe, rank, world, plan=next(iter(plans.values())))
         dog.disarm()
     pipe.use_hip_graph = a.graph
@@ -286,6 +299,29 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 5 * 1e3
 
+    def heads_a2a_us(plan):
+        """the two all-to-all calls of one layer-call of the heads exchange (q|k|v out, o back), alone on the wire"""
+        sh = plan.shard
+        if sh.ways <= 1:
+            return None
+        _, n_, lpad = sh.rows(L)
+        dp = model.inner_dim // sh.ways
+        s1 = sh.a2a_buffer("qkv_send", (sh.ways, lpad, 3, dp), torch.bfloat16, dev)
+        s2 = sh.a2a_buffer("o_send", (sh.ways, lpad, dp), torch.bfloat16, dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(6):
+            if rep == 1:
+                torch.cuda.synchronize()
+                e0.record()
+            sh.all_to_all("qkv_recv", s1)
+            sh.all_to_all("o_recv", s2)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5 * 1e3
+
+    def wire_us(plan):
+        return heads_a2a_us(plan) if plan.exchange == "heads" else kv_gather_us(plan)
+
     base_cfg = {"workload": a.workload, "tokens": L, "layers": cfg["num_layers"], "guidance": 5.0, "id_frames": nid}
 
     def result_line(elapsed, parallelism, extra_cfg, roofline=None, cpu=None, use_graph=False):
@@ -319,32 +355,39 @@ def main():
         elapsed, _ = timed_run(a.warmup, a.steps)
         assert torch.isfinite(st.lat).all(), "non-finite latents"
         probe = {first.desc: elapsed / a.steps * 1e3}
-        gather_us = {first.desc: kv_gather_us(first)}
+        gather_us = {first.desc: wire_us(first)}
 
         def line_for(el, plan):
             return result_line(el, plan.desc, {"rccl_ranks": world, "backend": backend, "plan_probe_ms_per_step": probe,
-                                               "kv_allgather_us_per_layer_call": gather_us.get(plan.desc),
-                                               "local_first_attention": bool(plan.shard.overlap_local)})
+                                               "exchange_us_per_layer_call_alone_on_the_wire": gather_us,
+                                               "local_first_attention": bool(plan.shard.overlap_local) and plan.exchange == "kv",
+                                               "attention_exchange": plan.exchange if plan.token_ways > 1 else None})
 
         best = (elapsed, first)
         line = line_for(*best)
         if len(names) > 1:
             # The first plan's line exists; from here on a stall costs nothing: the watchdog prints that line and leaves.
-            second = plans[names[1]]
-            dog.arm(f"probe ({second.desc})", a.stall_s, fallback=line)
-            shard_pipeline(pipe, rank, world, plan=second)
-            el_p, _ = timed_run(1, 2)
-            probe[second.desc] = el_p / 2 * 1e3
-            gather_us[second.desc] = kv_gather_us(second)
-            if rank == 0:
-                print(f"[bench] {first.desc}: {probe[first.desc]:.1f} ms/step; {second.desc}: {probe[second.desc]:.1f} "
-                      f"ms/step (probe)", file=sys.stderr, flush=True)
-            if probe[second.desc] < 0.98 * probe[first.desc]:
-                dog.arm(f"timed run ({second.desc})", a.stall_s + 2.0 * total, fallback=line)
+            cand = None
+            for nm in names[1:]:
+                other = plans[nm]
+                dog.arm(f"probe ({other.desc})", a.stall_s, fallback=line)
+                shard_pipeline(pipe, rank, world, plan=other)
+                el_p, _ = timed_run(1, 2)
+                probe[other.desc] = el_p / 2 * 1e3
+                gather_us[other.desc] = wire_us(other)
+                if rank == 0:
+                    print(f"[bench] {first.desc}: {probe[first.desc]:.1f} ms/step; {other.desc}: "
+                          f"{probe[other.desc]:.1f} ms/step (probe)", file=sys.stderr, flush=True)
+                if cand is None or probe[other.desc] < probe[cand.desc]:
+                    cand = other
+                line = line_for(*best)                                   # carries the probe times so far
+            if probe[cand.desc] < 0.98 * probe[first.desc]:
+                dog.arm(f"timed run ({cand.desc})", a.stall_s + 2.0 * total, fallback=line)
+                shard_pipeline(pipe, rank, world, plan=cand)
                 el2, _ = timed_run(a.warmup, a.steps)
                 if el2 < elapsed and bool(torch.isfinite(st.lat).all()):
-                    best = (el2, second)
-            line = line_for(*best)                                       # carries both plans' probe times
+                    best = (el2, cand)
+            line = line_for(*best)                                       # carries every plan's probe time
         dog.disarm()
         if rank == 0:
             print(line, flush=True)
