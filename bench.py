@@ -360,7 +360,7 @@ def main():
         def line_for(el, plan):
             return result_line(el, plan.desc, {"rccl_ranks": world, "backend": backend, "plan_probe_ms_per_step": probe,
                                                "exchange_us_per_layer_call_alone_on_the_wire": gather_us,
-                                               "local_first_attention": bool(plan.shard.overlap_local) and plan.exchange == "kv",
+                                               "local_first_attention": plan.shard.local_first() and plan.exchange == "kv",
                                                "attention_exchange": plan.exchange if plan.token_ways > 1 else None})
 
         best = (elapsed, first)

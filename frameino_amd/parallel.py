@@ -46,8 +46,13 @@ class TokenShard:
         # merge the partials (fino_attn_partial / fino_attn_merge): hides up to 1/ways of the attention under the gather.
 
     # attend to the own K/V chunk while the gather is in flight and merge (O, m, l) partials; False = one attention
-    # launch over the gathered keys after the wait (bit-identical arithmetic to the unsharded forward)
-    overlap_local = True
+    # launch over the gathered keys after the wait (bit-identical arithmetic to the unsharded forward); "auto": only with
+    # 2 shards -- the partials + merge cost ~0.19 ms per layer-call over the single pass (profiles/
+    # r02_heads_exchange_parts.txt) and hide 1/ways of the attention: 0.42 ms of 0.84 at 2 shards, 0.11 of 0.45 at 4
+    overlap_local = "auto"
+
+    def local_first(self):
+        return self.ways <= 2 if self.overlap_local == "auto" else bool(self.overlap_local)
 
     @property
     def active(self):

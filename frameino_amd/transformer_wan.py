@@ -499,7 +499,7 @@ class WanTransformer3DModel(nn.Module):
                 kv_all, work = sh.all_gather_kv(kv_loc)
                 self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
                 o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
-                if getattr(sh, "overlap_local", False):
+                if sh.local_first():
                     # local keys first -- nothing of it waits for the wire -- then what the gather delivered before /
                     # after the own chunk; the (O, m, l) partials are merged (same softmax up to fp32 summation order)
                     qv = q2.view(1, n, d)
