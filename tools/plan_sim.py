@@ -53,41 +53,47 @@ def main():
     st.t_rows[1:2] = 700.0
     st.dt[0] = -0.01
 
+    host_ms = [0.0]
+
     def timed(n=2):
+        """ms per step; host_ms[0]: the host's share (time to ENQUEUE a step: if it is close to the step time, the rank is
+        launch-bound, not GPU-bound)"""
         with torch.no_grad():
             pipe._step(st)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n):
                 pipe._step(st)
+            t1 = time.perf_counter()
             torch.cuda.synchronize()
+        host_ms[0] = (t1 - t0) / n * 1e3
         return (time.perf_counter() - t0) / n * 1e3
 
-    print(f"N=1 (batch-2 forward): {timed():.1f} ms/step")
+    print(f"N=1 (batch-2 forward): {timed():.1f} ms/step (host enqueue {host_ms[0]:.1f} ms)")
     for ways in (1, 2, 4):          # split plans: one branch per rank, token_ways = N/2
         n_gpus = 2 * ways
         sh = FakeShard(0, ways)
         pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
                                         exchange_cfg=lambda mine: (mine, mine))
         model.parallel = sh if ways > 1 else None
-        print(f"split      N={n_gpus}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+        print(f"split      N={n_gpus}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
     for ways in (2, 4, 8):          # interleaved plans: both branches per rank, token_ways = N
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways), FakeShard(0, ways)))
         model.parallel = pipe.parallel.shards[0]
-        print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+        print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
     # the same plans with the heads exchange (all-to-all instead of the K|V all-gather; attention over H/ways heads x all tokens)
     for ways in (2, 4):
         sh = FakeShard(0, ways, exchange="heads")
         pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
                                         exchange_cfg=lambda mine: (mine, mine))
         model.parallel = sh
-        print(f"split-heads      N={2 * ways}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+        print(f"split-heads      N={2 * ways}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
     for ways in (2, 4, 8):
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways, exchange="heads"), FakeShard(0, ways, exchange="heads")))
         model.parallel = pipe.parallel.shards[0]
-        print(f"interleave-heads N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank")
+        print(f"interleave-heads N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
 
 
 if __name__ == "__main__":
