@@ -313,7 +313,7 @@ def main():
             if rep == 1:
                 torch.cuda.synchronize()
                 e0.record()
-            sh.all_to_all("qkv_recv", s1)
+            sh.all_to_all("qkv_recv", s1)            # (the forward sends the same bytes in TokenShard.head_groups pieces)
             sh.all_to_all("o_recv", s2)
         e1.record()
         torch.cuda.synchronize()

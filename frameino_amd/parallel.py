@@ -102,17 +102,27 @@ class TokenShard:
     def heads_exchange_ok(self, heads):
         return self.exchange == "heads" and heads % self.ways == 0
 
-    def all_to_all(self, key, send):
-        """send [ways, rows, width] (slice j goes to rank j) -> the received [ways, rows, width] (slice j came from rank j).
-        Blocking in stream order (the caller's next kernel reads the result)."""
+    # the rank's heads travel in this many groups (each its own all-to-all): group g+1 is on the wire while group g is
+    # attended to, and group g's outputs return while group g+1 is attended to
+    head_groups = 2
+
+    def head_ranges(self, hp):
+        """[(h0, h1), ...]: the rank's hp heads cut into min(head_groups, hp) near-equal runs"""
+        g = max(1, min(int(self.head_groups), hp))
+        cuts = [hp * i // g for i in range(g + 1)]
+        return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+    def all_to_all(self, key, send, async_op=False):
+        """send [ways, rows, width] (slice j goes to rank j) -> (received [ways, rows, width]: slice j came from rank j,
+        work handle or None).  Without async_op the call is blocking in stream order."""
         recv = self._get(key, tuple(send.shape), send.dtype, send.device)
         if dist.get_backend(self.group) == "gloo" and send.is_cuda:      # tests on one GPU: staged through host memory
             r = torch.empty(send.shape, dtype=send.dtype)
             dist.all_to_all_single(r, send.cpu().contiguous(), group=self.group)
             recv.copy_(r.to(send.device))
-            return recv
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv
+            return recv, None
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        return recv, (work if async_op else None)
 
     def a2a_buffer(self, key, shape, dtype, dev):
         return self._get(key, shape, dtype, dev)
@@ -139,6 +149,11 @@ class ParallelPlan:
         self.interleave = token_group_b is not None
         self.shards = (self.shard, TokenShard(self.tok_rank, token_ways, token_group_b, force, exchange)) \
             if self.interleave else None
+        if self.interleave:
+            # the other CFG branch is what flies under a branch's all-to-alls here; cutting the heads into groups only
+            # costs (two half-size attention launches: +4-6 % GPU work, tools/plan_sim.py)
+            for sh in self.shards:
+                sh.head_groups = 1
         self._buf = None
 
     def with_exchange(self, exchange):

@@ -482,15 +482,29 @@ class WanTransformer3DModel(nn.Module):
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
                 o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
                 o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
-                send = sh.a2a_buffer("qkv_send", (ways, lpad, 3, dp), dt, dev)       # slice j: heads of rank j
-                send[:, :n].copy_(qkv.view(n, 3, ways, dp).permute(2, 0, 1, 3))
-                recv = sh.all_to_all("qkv_recv", send)                               # slice j: tokens of rank j
-                r3 = recv.view(1, ways * lpad, 3 * dp)[:, :L]
-                oh = sh.a2a_buffer("o_send", (ways, lpad, dp), dt, dev)
-                o.attention(r3[:, :, :dp], r3[:, :, dp:2 * dp], r3[:, :, 2 * dp:], hp,
-                            out=oh.view(1, ways * lpad, dp)[:, :L], **afold)
-                orv = sh.all_to_all("o_recv", oh)                                    # slice j: heads of rank j, my tokens
-                att.view(n, ways, dp).copy_(orv[:, :n].permute(1, 0, 2))
+                # the heads travel in groups, every group its own all-to-all on the communicator's stream: while group g
+                # is attended to, group g+1 arrives and group g-1's outputs leave
+                q4 = qkv.view(n, 3, ways, dp)
+                inflight = []
+                for gi, (h0, h1) in enumerate(sh.head_ranges(hp)):
+                    dg = (h1 - h0) * dh
+                    send = sh.a2a_buffer(f"qkv_send{gi}", (ways, lpad, 3, dg), dt, dev)   # slice j: heads of rank j
+                    send[:, :n].copy_(q4[:, :, :, h0 * dh:h1 * dh].permute(2, 0, 1, 3))
+                    inflight.append((gi, h0, h1, dg) + sh.all_to_all(f"qkv_recv{gi}", send, async_op=True))
+                back = []
+                for gi, h0, h1, dg, recv, work in inflight:                                # slice j: tokens of rank j
+                    if work is not None:
+                        work.wait()
+                    r3 = recv.view(1, ways * lpad, 3 * dg)[:, :L]
+                    oh = sh.a2a_buffer(f"o_send{gi}", (ways, lpad, dg), dt, dev)
+                    o.attention(r3[:, :, :dg], r3[:, :, dg:2 * dg], r3[:, :, 2 * dg:], h1 - h0,
+                                out=oh.view(1, ways * lpad, dg)[:, :L], **afold)
+                    back.append((h0, h1) + sh.all_to_all(f"o_recv{gi}", oh, async_op=True))
+                a3 = att.view(n, ways, dp)
+                for h0, h1, orv, work in back:                                             # slice j: heads of rank j
+                    if work is not None:
+                        work.wait()
+                    a3[:, :, h0 * dh:h1 * dh].copy_(orv[:, :n].permute(1, 0, 2))
             else:
                 # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)

@@ -164,6 +164,19 @@ def test_four_token_shards_of_a_four_head_model(exchange, desc):
         torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)
 
 
+def test_two_token_shards_trade_two_head_groups():
+    """4 heads on 2 token shards: each rank's 2 heads travel as two groups (TokenShard.head_groups), i.e. two all-to-alls
+    in flight around two attention launches"""
+    from frameino_amd.parallel import TokenShard
+    assert TokenShard(0, 2).head_ranges(2) == [(0, 1), (1, 2)] and TokenShard(0, 8).head_ranges(3) == [(0, 1), (1, 3)]
+    assert TokenShard(0, 2).head_ranges(1) == [(0, 1)] and TokenShard(0, 2).head_ranges(12) == [(0, 6), (6, 12)]
+    pipe, a = _four_head_case()
+    single = _run(pipe, a)
+    for rank, d, out in _spawn(2, (False, "split", "heads", True)):
+        assert d == "cfg1xtoken2-heads"
+        torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)
+
+
 def test_heads_exchange_refuses_indivisible_heads():
     from frameino_amd.parallel import ParallelPlan, shard_pipeline
     cfg, sd, _ = load_golden("wan_pipe_tiny")

@@ -23,10 +23,10 @@ class FakeShard(TokenShard):
         out[:t.shape[0]].copy_(t)
         return out, None
 
-    def all_to_all(self, key, send):            # heads exchange: every slice "arrives" as a copy of what was sent
+    def all_to_all(self, key, send, async_op=False):   # heads exchange: every slice "arrives" as a copy of what was sent
         recv = self._get(key, tuple(send.shape), send.dtype, send.device)
         recv.copy_(send)
-        return recv
+        return recv, None
 
 
 def main():
@@ -92,6 +92,8 @@ def main():
     for ways in (2, 4, 8):
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways, exchange="heads"), FakeShard(0, ways, exchange="heads")))
+        for sh in pipe.parallel.shards:
+            sh.head_groups = 1                  # as ParallelPlan sets it for the interleaved plan
         model.parallel = pipe.parallel.shards[0]
         print(f"interleave-heads N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
 
