@@ -23,8 +23,6 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define LD128(R_, OFF_) "ds_read_b128 %" #R_ ", %20 offset:" #OFF_ "\n\t"
 #define LDTR(R_, OFF_) "ds_read_b64_tr_b16 %" #R_ ", %20 offset:" #OFF_ "\n\t"
 #define WAITL(N_) "s_waitcnt lgkmcnt(" #N_ ")\n\t"
-#define SADD "s_add_u32 %25, %25, %24\n\t"
-#define RDL "v_readlane_b32 %25, %18, 3\n\t"
 #define MFMA_AB(T_) "v_mfma_f32_32x32x16_bf16 %" #T_ ", %4, %23, %" #T_ "\n\t"
 #define BODYA(F0_, F1_, F2_, F3_)                                                                                    \
     asm volatile(MFMA_AB(0) F0_ MFMA_AB(1) F1_ MFMA_AB(2) F2_ MFMA_AB(3) F3_                                         \
@@ -84,8 +82,6 @@ __global__ __launch_bounds__(256) void gap_kernel(uint64_t* out, const uint4* op
         if constexpr (V == 20) BODY(LD128(21, 0) LD128(22, 1024), LD128(21, 2048) LD128(22, 3072), LD128(21, 4096) LD128(22, 5120), LD128(21, 6144) LD128(22, 7168) WAITL(0))
         if constexpr (V == 21) BODY(LDTR(26, 0) LDTR(27, 1024), LDTR(26, 2048) LDTR(27, 3072), LDTR(26, 4096) LDTR(27, 5120), LDTR(26, 6144) LDTR(27, 7168) WAITL(0))
         if constexpr (V == 22) BODY(NOP NOP NOP NOP, NOP NOP NOP NOP, NOP NOP NOP NOP, NOP NOP NOP NOP)
-        if constexpr (V == 23) BODY(SADD SADD SADD SADD, SADD SADD SADD SADD, SADD SADD SADD SADD, SADD SADD SADD SADD)
-        if constexpr (V == 24) BODY(RDL SADD RDL SADD, RDL SADD RDL SADD, RDL SADD RDL SADD, RDL SADD RDL SADD)
         if constexpr (V == 25) BODY(EXP(6) EXP(7) CVT(14, 8, 9) CVT(15, 10, 11) LD128(21, 0), EXP(8) EXP(9) CVT(16, 12, 13) CVT(17, 6, 7) LD128(22, 1024), EXP(10) EXP(11) CVT(14, 12, 13) CVT(15, 6, 7) LDTR(26, 2048), EXP(12) EXP(13) CVT(16, 8, 9) CVT(17, 10, 11) LDTR(27, 3072) WAITL(2))
         if constexpr (V == 32) BODY(LD128(21, 0), LD128(22, 1024), LD128(21, 2048), LD128(22, 3072))
         if constexpr (V == 33) BODY(LD128(21, 0) LD128(22, 1024), LD128(21, 2048) LD128(22, 3072), LD128(21, 4096) LD128(22, 5120), LD128(21, 6144) LD128(22, 7168))
@@ -107,7 +103,6 @@ __global__ __launch_bounds__(256) void gap_kernel(uint64_t* out, const uint4* op
         if constexpr (V == 28) BODY(EXP(6) EXP(7) CVT(14, 12, 13), EXP(8) EXP(9) CVT(15, 6, 7), EXP(10) EXP(11) CVT(16, 8, 9), EXP(12) EXP(13) CVT(17, 10, 11))
         if constexpr (V == 29) BODY(EXP(6) EXP(7) CVT(14, 6, 7), EXP(8) EXP(9) CVT(15, 8, 9), EXP(10) EXP(11) CVT(16, 10, 11), EXP(12) EXP(13) CVT(17, 12, 13))
         if constexpr (V == 30) BODY(EXP(6) EXP(7) NOP CVT(14, 6, 7), EXP(8) EXP(9) NOP CVT(15, 8, 9), EXP(10) EXP(11) NOP CVT(16, 10, 11), EXP(12) EXP(13) NOP CVT(17, 12, 13))
-        if constexpr (V == 31) BODY(EXP(6) EXP(7) CVT(14, 8, 9) CVT(15, 10, 11) SADD SADD, EXP(8) EXP(9) CVT(16, 12, 13) CVT(17, 6, 7) NOP RDL, EXP(10) EXP(11) CVT(14, 12, 13) CVT(15, 6, 7) LD128(21, 0) LD128(22, 1024), EXP(12) EXP(13) CVT(16, 8, 9) CVT(17, 10, 11) WAITL(0))
       }
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -207,14 +202,11 @@ int main(int argc, char** argv) {
     run<43, 8>("+ 2 exp + 2 cvt of THIS gap's exps + add", out, opnd, cus, iters);
     run<45, 8>("+ 2 exp + 2 max3 reading the previous gap's exps + add", out, opnd, cus, iters);
     run<22, 8>("+ 4 s_nop 0", out, opnd, cus, iters);
-    run<23, 8>("+ 4 s_add_u32", out, opnd, cus, iters);
-    run<24, 8>("+ 2 (v_readlane_b32 + s_add_u32)", out, opnd, cus, iters);
     run<25, 8>("+ 2 exp + 2 cvt + 1 ds_read", out, opnd, cus, iters);
     run<26, 8>("MFMA only, B operand in AGPRs", out, opnd, cus, iters);
     run<27, 8>("B in AGPRs + 2 exp + 2 cvt", out, opnd, cus, iters);
     run<28, 8>("+ 2 exp + cvt of the previous gap's exps", out, opnd, cus, iters);
     run<29, 8>("+ 2 exp + cvt of THIS gap's exps", out, opnd, cus, iters);
     run<30, 8>("+ 2 exp + s_nop 0 + cvt of this gap's exps", out, opnd, cus, iters);
-    run<31, 8>("+ 2 exp + 2 cvt + (2 salu | nop, readlane | 2 ds_read | wait)", out, opnd, cus, iters);
     return 0;
 }
