@@ -69,6 +69,26 @@ def main():
         host_ms[0] = (t1 - t0) / n * 1e3
         return (time.perf_counter() - t0) / n * 1e3
 
+    if os.environ.get("FINO_PLAN_SIM_SK"):          # A/B: 1 = never stream-K, 2 = whenever legal (FINO_TUNE_GEMM_STREAM_K)
+        from frameino_amd import _lib
+        _lib.lib().fino_tune_set(3, int(os.environ["FINO_PLAN_SIM_SK"]))
+    only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. "interleave:8" or "split-heads:4": that plan alone (profiling)
+    if only:
+        kind, ways = only.split(":")
+        ways = int(ways)
+        ex = "heads" if kind.endswith("heads") else "kv"
+        if kind.startswith("interleave"):
+            pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
+                                            shards=(FakeShard(0, ways, exchange=ex), FakeShard(0, ways, exchange=ex)))
+            for sh in pipe.parallel.shards:
+                sh.head_groups = 1
+            model.parallel = pipe.parallel.shards[0]
+        else:
+            pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
+                                            exchange_cfg=lambda mine: (mine, mine))
+            model.parallel = FakeShard(0, ways, exchange=ex) if ways > 1 else None
+        print(f"{only}: {timed(3):.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
+        return
     print(f"N=1 (batch-2 forward): {timed():.1f} ms/step (host enqueue {host_ms[0]:.1f} ms)")
     for ways in (1, 2, 4):          # split plans: one branch per rank, token_ways = N/2
         n_gpus = 2 * ways
