@@ -62,6 +62,33 @@ def test_self_attention_full_size(b, lq):
         assert torch.equal(o2.float(), o.float() * 2)
 
 
+@pytest.mark.parametrize("heads,lq", [(12, L), (6, L), (3, L), (3, 25088)])
+def test_self_attention_full_size_head_shards(heads, lq):
+    """what a rank attends to after the multi-GPU heads exchange: H/P heads (P = 2, 4, 8 token shards) over the WHOLE
+    sequence, read through the strides of the received [tokens, 3, H/P * Dh] buffer.  batch * heads is not a multiple of
+    8 there: the virtual-head mapping (attn_map_block) spreads the q-blocks of every head over all XCDs."""
+    from frameino_amd import ops
+    dp = heads * DH
+    g = torch.Generator(device=DEV).manual_seed(7)
+    recv = torch.randn(1, lq, 3 * dp, device=DEV, generator=g).bfloat16()
+    q, k, v = recv[:, :, :dp], recv[:, :, dp:2 * dp], recv[:, :, 2 * dp:]
+    out = torch.zeros(1, lq + 40, dp, device=DEV, dtype=torch.bfloat16)
+    o = ops.attention(q, k, v, heads, out=out[:, :lq])
+    assert torch.isfinite(o.float()).all() and not out[:, lq:].any()
+    rows = torch.tensor(sorted({0, 255, 256, lq - 1, (lq // 256) * 256 - 1, min((lq // 256) * 256, lq - 1), lq // 2, lq // 8 * 3} |
+                               set(torch.randint(0, lq, (24,)).tolist())), device=DEV)
+    ref = _attn_rows_ref(q, k, v, rows, heads)
+    assert rel_rms(o[0, rows], ref) < 2.0 ** -6
+    ops.SPLIT_ATTENTION_TAIL = False
+    try:
+        o1 = ops.attention(q, k, v, heads)
+    finally:
+        ops.SPLIT_ATTENTION_TAIL = True
+    assert rel_rms(o, o1.float()) < 2.0 ** -8
+    o_one = ops.attention(q, k, torch.ones_like(v), heads)
+    assert (o_one.float() - 1).abs().max().item() < 2.0 ** -6           # every row of P sums to one: no block was skipped
+
+
 @pytest.mark.parametrize("n,k,epi", [(3 * D, D, 0), (D, D, 3), (FF, D, 1), (D, FF, 3)])
 def test_gemm_full_size_sampled_rows(n, k, epi):
     """The four GEMM shapes of a Wan block at M = 2 x 12320 rows (CFG-batched), sampled rows vs fp32."""
