@@ -165,3 +165,98 @@ def test_sharded_path_through_rccl_single_rank(mode, desc, exchange):
     assert torch.isfinite(out).all() and torch.equal(out, out2)
     # separate K|V and Q projections instead of the fused QKV GEMM: same per-element arithmetic
     assert rel_rms(out, single) < 5e-3, rel_rms(out, single)
+
+
+class _Loopback:
+    """the wire of P token shards simulated inside ONE process: every simulated rank runs its forward in its own thread on
+    the same (default) stream and meets the others at the exchanges"""
+
+    def __init__(self, ways):
+        import threading
+        self.ways, self.slots, self.barrier = ways, [None] * ways, threading.Barrier(ways)
+
+
+def _loopback_shard(board, rank, exchange):
+    from frameino_amd.parallel import TokenShard
+
+    class Shard(TokenShard):
+        def _meet(self, t):
+            board.slots[self.rank] = t
+            board.barrier.wait()            # every rank has ENQUEUED what produces its tensor (one stream: ordered)
+            got = list(board.slots)
+            return got
+
+        def _all_gather(self, key, t, async_op):
+            out = self._get(key, (self.ways * t.shape[0],) + tuple(t.shape[1:]), t.dtype, t.device)
+            for j, tj in enumerate(self._meet(t)):
+                out[j * t.shape[0]:(j + 1) * t.shape[0]].copy_(tj)
+            board.barrier.wait()            # nobody overwrites its buffer before all copies are enqueued
+            return out, None
+
+        def all_to_all(self, key, send, async_op=False):
+            recv = self._get(key, tuple(send.shape), send.dtype, send.device)
+            for j, sj in enumerate(self._meet(send)):
+                recv[j].copy_(sj[self.rank])
+            board.barrier.wait()
+            return recv, None
+
+    return Shard(rank, board.ways, exchange=exchange)
+
+
+@pytest.mark.parametrize("ways,exchange,lat_hw", [(4, "heads", (44, 80)), (8, "heads", (44, 80)), (4, "kv", (44, 80)),
+                                                  (8, "kv", (44, 80)), (2, "kv", (44, 80)),
+                                                  (8, "heads", (64, 112)), (8, "kv", (64, 112))])
+def test_full_size_token_shards_in_one_process(ways, exchange, lat_hw):
+    """Wan2.2-5B width, L = 12320, 2 layers: the forwards of all P simulated ranks (threads, loopback exchanges) against
+    the unsharded forward -- the real kernels on the real shard shapes (1540 / 3080 / 6160 tokens per rank; 3 / 6 heads
+    per rank after the heads exchange), which no multi-process test on one GPU reaches.  (64, 112): BASELINE config 4's
+    clip, 1024x1792, L = 25088 on 8 shards."""
+    import threading
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model
+    from frameino_amd.configs import WAN22_5B_CFG
+    cfg = dict(WAN22_5B_CFG, num_layers=2)
+    dev = torch.device("cuda")
+    m = build_model(cfg, dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    lh, lw = lat_hw
+    x = torch.randn(1, 96, 14, lh, lw, device=dev, generator=g).bfloat16()
+    pe = torch.randn(1, 512, cfg["text_dim"], device=dev, generator=g).bfloat16()
+    L = 14 * (lh // 2) * (lw // 2)
+    sel = (torch.arange(L, device=dev) >= (lh // 2) * (lw // 2)).to(torch.int32)
+    t_rows = torch.tensor([0.0, 700.0], device=dev)
+    with torch.no_grad():
+        ref = m(x, None, pe, return_dict=False, timestep_rows=(t_rows, sel))[0].float()
+        board = _Loopback(ways)
+        gens, outs, errs = [], [None] * ways, []
+        for r in range(ways):                      # bind every rank's workspace / shard under its own cache context
+            with m.cache_context(f"rank{r}"):
+                gen = m.forward_steps(x, None, pe, None, False, None, (t_rows, sel), shard=_loopback_shard(board, r, exchange))
+                next(gen)
+            gens.append(gen)
+
+        def drive(r):
+            try:
+                with torch.no_grad():
+                    while True:
+                        next(gens[r])
+            except StopIteration as done:
+                outs[r] = done.value[0]
+            except Exception as ex:      # noqa: BLE001
+                errs.append((r, repr(ex)))
+                board.barrier.abort()
+
+        ths = [threading.Thread(target=drive, args=(r,)) for r in range(ways)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        torch.cuda.synchronize()
+    assert not errs, errs
+    assert ref.std().item() > 1e-3
+    for r in range(ways):
+        assert outs[r] is not None and torch.isfinite(outs[r].float()).all()
+        e = rel_rms(outs[r], ref)
+        assert e < 5e-3, (r, e)
+    assert all(torch.equal(outs[0], outs[r]) for r in range(1, ways))
