@@ -367,27 +367,36 @@ def main():
         line = line_for(*best)
         if len(names) > 1:
             # The first plan's line exists; from here on a stall costs nothing: the watchdog prints that line and leaves.
-            cand = None
-            for nm in names[1:]:
-                other = plans[nm]
-                dog.arm(f"probe ({other.desc})", a.stall_s, fallback=line)
-                shard_pipeline(pipe, rank, world, plan=other)
-                el_p, _ = timed_run(1, 2)
-                probe[other.desc] = el_p / 2 * 1e3
-                gather_us[other.desc] = wire_us(other)
+            # An exception in a probe (a collective the node's RCCL refuses, an out-of-memory) is treated like a stall: the
+            # line already measured goes out and the process leaves -- the other ranks' watchdogs do the same.
+            try:
+                cand = None
+                for nm in names[1:]:
+                    other = plans[nm]
+                    dog.arm(f"probe ({other.desc})", a.stall_s, fallback=line)
+                    shard_pipeline(pipe, rank, world, plan=other)
+                    el_p, _ = timed_run(1, 2)
+                    probe[other.desc] = el_p / 2 * 1e3
+                    gather_us[other.desc] = wire_us(other)
+                    if rank == 0:
+                        print(f"[bench] {first.desc}: {probe[first.desc]:.1f} ms/step; {other.desc}: "
+                              f"{probe[other.desc]:.1f} ms/step (probe)", file=sys.stderr, flush=True)
+                    if cand is None or probe[other.desc] < probe[cand.desc]:
+                        cand = other
+                    line = line_for(*best)                               # carries the probe times so far
+                if probe[cand.desc] < 0.98 * probe[first.desc]:
+                    dog.arm(f"timed run ({cand.desc})", a.stall_s + 2.0 * total, fallback=line)
+                    shard_pipeline(pipe, rank, world, plan=cand)
+                    el2, _ = timed_run(a.warmup, a.steps)
+                    if el2 < elapsed and bool(torch.isfinite(st.lat).all()):
+                        best = (el2, cand)
+                line = line_for(*best)                                   # carries every plan's probe time
+            except Exception as ex:      # noqa: BLE001
+                print(f"[bench] rank {rank}: {type(ex).__name__} while probing another plan: {ex} -- leaving with the "
+                      f"line already measured", file=sys.stderr, flush=True)
                 if rank == 0:
-                    print(f"[bench] {first.desc}: {probe[first.desc]:.1f} ms/step; {other.desc}: "
-                          f"{probe[other.desc]:.1f} ms/step (probe)", file=sys.stderr, flush=True)
-                if cand is None or probe[other.desc] < probe[cand.desc]:
-                    cand = other
-                line = line_for(*best)                                   # carries the probe times so far
-            if probe[cand.desc] < 0.98 * probe[first.desc]:
-                dog.arm(f"timed run ({cand.desc})", a.stall_s + 2.0 * total, fallback=line)
-                shard_pipeline(pipe, rank, world, plan=cand)
-                el2, _ = timed_run(a.warmup, a.steps)
-                if el2 < elapsed and bool(torch.isfinite(st.lat).all()):
-                    best = (el2, cand)
-            line = line_for(*best)                                       # carries every plan's probe time
+                    print(line, flush=True)
+                os._exit(0)
         dog.disarm()
         if rank == 0:
             print(line, flush=True)
