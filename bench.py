@@ -41,6 +41,13 @@ def wan_flops_per_forward(L, cfg, text_len=512):
     return nl * per_layer + 2 * L * kin * d + 2 * L * d * cfg["out_channels"] * 4 + 2 * text_len * (cfg["text_dim"] * d + d * d)
 
 
+def wan_flops_shared_prefix(L, cfg):
+    """what the CFG-batched forward computes ONCE for both branches (WanTransformer3DModel.dedup_shared_prefix): the patch
+    embedding and layer 0's self-attention branch (QKV, SDPA, out projection)"""
+    d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    return 2 * L * cfg["in_channels"] * 4 * d + 8 * L * d * d + 4 * L * L * d
+
+
 def build_model(cfg, device, seed=0):
     """Random-init Wan2.2-5B (no checkpoints offline): N(0, 0.02^2) weights generated on the device."""
     from frameino_amd.random_init import random_wan_model
@@ -90,9 +97,12 @@ class Watchdog:
     `fallback` is a JSON line already measured: rank 0 prints it before leaving, so the driver still gets a valid
     line.  Never re-exec: the process has touched the GPU; os._exit tears the context down."""
 
+    ABORT_KEY = "fino_bench_abort"
+
     def __init__(self, rank):
         import threading
         self.rank, self.phase, self.deadline, self.fallback, self.ok = rank, "init", None, None, False
+        self.store = None              # the process group's store once it exists: carries a peer's "I am leaving"
         self._lock = threading.Lock()
         t = threading.Thread(target=self._run, daemon=True)
         t.start()
@@ -106,14 +116,33 @@ class Watchdog:
         with self._lock:
             self.deadline = None
 
+    def abort(self, why):
+        """a rank that cannot go on (exception in a probe) tells its peers before it leaves: their watchdogs see the key
+        within half a second instead of sitting in the next collective until their own deadline"""
+        try:
+            if self.store is not None:
+                self.store.set(self.ABORT_KEY, f"rank {self.rank}: {why}")
+        except Exception:      # noqa: BLE001  (rank 0 = the store's host may be gone already)
+            pass
+
+    def _peer_left(self):
+        if self.store is None:
+            return False
+        try:
+            return bool(self.store.check([self.ABORT_KEY]))
+        except Exception:      # noqa: BLE001  the store's host (rank 0) has left
+            return True
+
     def _run(self):
         while True:
             time.sleep(0.5)
             with self._lock:
-                if self.deadline is None or time.monotonic() < self.deadline:
-                    continue
+                armed = self.deadline is not None
+                late = armed and time.monotonic() >= self.deadline
                 phase, fb, ok = self.phase, self.fallback, self.ok
-            print(f"[bench] rank {self.rank}: phase '{phase}' stalled -- leaving"
+            if not late and not (armed and fb is not None and self._peer_left()):
+                continue
+            print(f"[bench] rank {self.rank}: phase '{phase}' {'stalled' if late else 'left by a peer'} -- leaving"
                   f"{' with the line already measured' if fb else ''}", file=sys.stderr, flush=True)
             if fb is not None and self.rank == 0:
                 print(fb, flush=True)
@@ -152,6 +181,7 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}: the line's n_gpus would be a guess")
     backend = os.environ.get("FINO_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 flow on fewer GPUs than ranks
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
@@ -165,6 +195,10 @@ def main():
         else:
             dist.init_process_group(backend)
         dog.disarm()
+        try:
+            dog.store = dist.distributed_c10d._get_default_store()
+        except Exception:      # noqa: BLE001
+            dog.store = None
 
     from frameino_amd import _lib, ops
     _lib.load()                                   # no fallback: fail here if the HIP library is missing
@@ -326,7 +360,10 @@ def main():
 
     def result_line(elapsed, parallelism, extra_cfg, roofline=None, cpu=None, use_graph=False):
         ms_step = elapsed / a.steps * 1e3
-        flops_step = 2 * wan_flops_per_forward(L, cfg)
+        # FLOPs actually issued: on one GPU the two CFG branches are one batch-2 forward whose branch-invariant prefix
+        # runs once (the N > 1 plans run two whole batch-1 forwards)
+        shared = world == 1 and getattr(model, "dedup_shared_prefix", False) and not getattr(pipe, "cfg_streams", False)
+        flops_step = 2 * wan_flops_per_forward(L, cfg) - (wan_flops_shared_prefix(L, cfg) if shared else 0)
         out = {
             "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,
@@ -336,7 +373,8 @@ def main():
             "data": "synthetic",
             "config": dict(base_cfg, hip_graph=bool(use_graph), parallelism=parallelism,
                            sec_per_50_step_clip_denoise_only=50 * ms_step / 1e3,
-                           model_tflops_per_s=flops_step / (ms_step * 1e-3) / 1e12, **extra_cfg),
+                           model_tflops_per_s=flops_step / (ms_step * 1e-3) / 1e12,
+                           model_flops_per_step_issued=flops_step, **extra_cfg),
         }
         if a.layers:
             out["config"]["INVALID_reduced_layers"] = a.layers
@@ -394,8 +432,10 @@ def main():
             except Exception as ex:      # noqa: BLE001
                 print(f"[bench] rank {rank}: {type(ex).__name__} while probing another plan: {ex} -- leaving with the "
                       f"line already measured", file=sys.stderr, flush=True)
+                dog.abort(f"{type(ex).__name__} in a probe")      # peers leave at once (each with the same line on rank 0)
                 if rank == 0:
                     print(line, flush=True)
+                    time.sleep(1.5)                                # keep the store up for the peers' next poll
                 os._exit(0)
         dog.disarm()
         if rank == 0:
@@ -476,9 +516,9 @@ def main():
         alg_bytes = batch * 4 * L * heads * dh * 2           # Q, K, V read + O written, bf16
         roofline = {"bound": "mfma", "kernel": "attn_pp_kernel<BF16,128,0> (3D self-attention)",
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                    # what the matrix pipe ALONE sustains on gaussian operands before the board's power cap takes the
-                    # clock down (tools/mfma_peak.py, profiles/r02_mfma_peak.txt); the step runs at that cap throughout
-                    "power_capped_peak": 1870.0, "frac_of_power_capped_peak": ach / 1870.0,
+                    # what the matrix pipe ALONE sustains on THIS box on gaussian operands before the board's power cap
+                    # takes the clock down: measured in this run (fino_diag_mfma_peak, 32x32x16 bf16, ~0.25 s launches)
+                    **measured_mfma_peak(dev, ach),
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "algorithmic_bytes": alg_bytes,
                     "traffic_over_algorithmic": None if traffic is None else traffic / alg_bytes,
@@ -489,7 +529,86 @@ def main():
                     "launch_mix": "per batch-2 forward 29 launches cover both CFG branches; layer 0's (identical for "
                                   "the branches) covers one: achieved = summed algorithmic FLOPs / summed durations"}
     cpu = None if a.no_cpu_baseline else cpu_baseline(cfg, L)
+    if cpu is not None and a.workload != "tiny":
+        try:
+            cpu.update(cpu_config1())
+        except Exception as ex:      # noqa: BLE001
+            cpu["config1_s"] = None
+            cpu["config1_sample"] = f"failed: {type(ex).__name__}: {ex}"
     print(result_line(elapsed, "single", extra, roofline, cpu, use_graph=a.graph), flush=True)
+
+
+def measured_mfma_peak(dev, achieved_tflops):
+    """`power_capped_peak`: dense bf16 MFMA rate of the whole chip with ONLY the matrix pipe working (every wave issues
+    independent v_mfma_f32_32x32x16_bf16 from registers, 2 waves per SIMD, gaussian operand bits), over launches long
+    enough (~0.25 s each, 3 of them after one warm launch) for the power manager to settle.  A measurement of this box
+    in this run -- never a constant from another one; None if the diagnostic fails."""
+    import ctypes
+    from frameino_amd import _lib
+    try:
+        lib = _lib.lib()
+        scratch = torch.zeros(64 + 2 * 256 * 4, device=dev)
+        g = torch.Generator(device=dev).manual_seed(0)
+        ops_view = scratch[64:].view(torch.bfloat16)
+        ops_view.copy_(torch.randn(ops_view.shape, device=dev, generator=g).bfloat16())
+        fl = ctypes.c_double()
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def run(iters):
+            _lib.check(lib.fino_diag_mfma_peak(0, 2, iters, scratch.data_ptr(), ctypes.byref(fl), stream),
+                       "fino_diag_mfma_peak")
+        run(100)
+        run(400000)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            run(400000)
+        e1.record()
+        torch.cuda.synchronize()
+        tf = fl.value / (e0.elapsed_time(e1) / 3 * 1e-3) / 1e12
+        return {"power_capped_peak": tf, "frac_of_power_capped_peak": achieved_tflops / tf,
+                "power_capped_peak_source": "measured in this run: fino_diag_mfma_peak, 32x32x16 bf16, gaussian operands, "
+                                            "2 waves/SIMD, 3 launches of 4e5 MFMAs per wave"}
+    except Exception as ex:      # noqa: BLE001
+        return {"power_capped_peak": None, "frac_of_power_capped_peak": None,
+                "power_capped_peak_source": f"not measured ({type(ex).__name__}: {ex})"}
+
+
+def cpu_config1(budget_s=12.0):
+    """BASELINE config 1 (CogVideoX-I2V-5B stage-1 pipeline, 13 frames 256x256, 10 steps, fp32 on
+    the host) through the oracle.  All of it is ~2.5e14 FLOP -- an hour on host cores -- so the timed SAMPLE is three
+    denoise steps (B = 2 forward + CFG + DDIM each) of the full-width model with 2 of its 42 layers; `config1_s` extrapolates
+    it by layers and steps and says so."""
+    from oracle import cog_pipeline as CP
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG as COG5B
+    from frameino_amd.pipeline_cogvideox_i2v_motion import CogVideoXImageToVideoPipeline
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = dict(COG5B, use_FrameIn=False, num_layers=2)
+    g = torch.Generator().manual_seed(1)
+    m = CogVideoXTransformer3DModel(**cfg)                 # the mirror only as a container of reference-keyed parameters
+    with torch.no_grad():
+        for name, p_ in m.named_parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.02 if p_.ndim > 1 else 0.1) +
+                     (1.0 if name.endswith("norm.weight") or "norm_q.weight" in name or "norm_k.weight" in name else 0.0))
+        m.patch_embed.pos_embedding.copy_(torch.randn(m.patch_embed.pos_embedding.shape, generator=g) * 0.1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    rot = CogVideoXImageToVideoPipeline(transformer=m, scheduler=None)._prepare_rotary_positional_embeddings(256, 256, 4, "cpu")
+    del m
+    F_, C_, h, w = 4, 16, 32, 32
+    lat = torch.randn(1, F_, C_, h, w, generator=g)
+    img = torch.cat([torch.randn(1, 1, C_, h, w, generator=g), torch.zeros(1, F_ - 1, C_, h, w)], 1)
+    trj = torch.randn(1, F_, C_, h, w, generator=g)
+    pe, ne = torch.randn(1, 226, 4096, generator=g), torch.randn(1, 226, 4096, generator=g)
+    t0 = time.time()
+    nst = 3
+    CP.cog_denoise_loop(sd, cfg, lat, img, trj, None, pe, ne, rot, 6.0, nst)
+    t_step2 = (time.time() - t0) / nst
+    layers = COG5B["num_layers"]
+    return {"config1_s": t_step2 * layers / 2 * 10,
+            "config1_sample": f"oracle stage-1 CogVideoX pipeline, fp32, 13 f 256x256 (L = 226 + 1024, B = 2), full width, "
+                              f"{nst} steps with 2 of {layers} layers: {t_step2:.2f} s per step; extrapolated "
+                              f"x {layers // 2} (layers) x 10 (steps)"}
 
 
 def unipc_ms_per_step(pipe_euler, model, inputs, dev, steps=3):

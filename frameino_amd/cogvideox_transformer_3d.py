@@ -122,6 +122,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._fp8 = {}
+        self._fp8_pending = False
         # q leaves its LayerNorm + RoPE kernel multiplied by head_dim**-0.5 * log2(e) and the attention kernels take q.k as
         # the exp2 argument (FINO_ATTN_SCALE_FOLDED): at head_dim 64 that selects the 4-wave kernel with the running maximum
         # folded into its MFMAs (-5 % per step).  Video rows: one rounding of q.c instead of q; the 226 text rows (LayerNorm
@@ -172,29 +173,28 @@ class CogVideoXTransformer3DModel(nn.Module):
         with torch.no_grad():
             for k, t in list(self.named_parameters()) + list(self.named_buffers()):
                 t.data = sd[k].to(dtype or sd[k].dtype).to(t.device).contiguous()
-        if self.reset_caches():
-            self.enable_mxfp8_linears()
+        self.reset_caches()
         return self
 
     def reset_caches(self):
         """Drop everything derived from the parameters (packed / fused copies, MXFP8 weights, positional tables);
         called whenever the parameters may have changed or moved."""
-        had_fp8 = bool(self._fp8)
+        had_fp8 = bool(self._fp8) or self._fp8_pending
         self._packed = None
         self._fp8 = {}
+        self._fp8_pending = had_fp8      # re-quantised lazily by the next forward, from wherever the parameters are then
         self._pos_cache.clear()
         return had_fp8
 
     def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .half()
         out = super()._apply(fn, *args, **kwargs)
-        if hasattr(self, "_pos_cache") and self.reset_caches():
-            self.enable_mxfp8_linears()
+        if hasattr(self, "_pos_cache"):
+            self.reset_caches()
         return out
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
-        if self.reset_caches():
-            self.enable_mxfp8_linears()
+        self.reset_caches()
         return out
 
     # ---- packing ----
@@ -205,6 +205,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         Attention, norms, embeddings and the output head stay in the model dtype.  No reference counterpart (SURVEY
         F11): compared with this model's own bf16 forward."""
         self._fp8 = {}
+        self._fp8_pending = False
         if not enabled:
             return self
         pk = self._packed or self._pack()
@@ -284,6 +285,8 @@ class CogVideoXTransformer3DModel(nn.Module):
         if attention_kwargs is not None:
             attention_kwargs = dict(attention_kwargs)
             attention_kwargs.pop("scale", None)
+        if self._fp8_pending:
+            self.enable_mxfp8_linears()
         pk = self._packed or self._pack()
         default_procs = self._default_processors()
         c = self.config

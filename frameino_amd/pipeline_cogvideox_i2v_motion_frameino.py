@@ -66,6 +66,20 @@ class CogVideoXPipelineOutput(SimpleNamespace):
     pass
 
 
+def _one_generator(generator, batch_size=1):
+    """diffusers' randn_tensor rule for a list of generators: its length must equal the batch size, and a list of one
+    IS that generator (one video per call here) -- never silently dropped."""
+    if isinstance(generator, (list, tuple)):
+        if len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
+                             f"the generators.")
+        if batch_size != 1:
+            raise NotImplementedError("one video per call")
+        return generator[0]
+    return generator
+
+
 class CogVideoXImageToVideoPipeline:
     _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
     extend_rope_by_first_frame = True             # :834-839 (the ID frame reuses the first frame's RoPE rows)
@@ -109,6 +123,7 @@ class CogVideoXImageToVideoPipeline:
         dev, dt = latents.device, tr.dtype
         if latents.shape[0] != 1:
             raise NotImplementedError("one video per call")
+        generator = _one_generator(generator)
         cfg_on = guidance_scale > 1.0 and negative_prompt_embeds is not None
         self.scheduler.set_timesteps(num_inference_steps, device=dev)
         ts = self.scheduler.timesteps
@@ -218,9 +233,10 @@ class CogVideoXImageToVideoPipeline:
         pad = torch.zeros((batch_size, nlf - 1, num_channels_latents, lh, lw), device=device, dtype=dtype)
         image_latents = torch.cat([image_latents, pad], dim=1)
         if latents is None:
-            gdev = generator.device if isinstance(generator, torch.Generator) else device
-            latents = torch.randn((batch_size, nlf, num_channels_latents, lh, lw), generator=generator
-                                  if isinstance(generator, torch.Generator) else None, device=gdev, dtype=dtype).to(device)
+            g1 = _one_generator(generator, batch_size)
+            gdev = g1.device if g1 is not None else device
+            latents = torch.randn((batch_size, nlf, num_channels_latents, lh, lw), generator=g1, device=gdev,
+                                  dtype=dtype).to(device)
         else:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma, image_latents
@@ -278,7 +294,7 @@ class CogVideoXImageToVideoPipeline:
         gscale = guidance_scale if negative_prompt_embeds is not None else 1.0
         out = self.denoise(latents, image_latents, traj_latents, id_latent, prompt_embeds, negative_prompt_embeds,
                            gscale, num_inference_steps, use_dynamic_cfg, None, attention_kwargs, callback_on_step_end,
-                           generator if isinstance(generator, torch.Generator) else None)
+                           generator)
         if output_type == "latent":
             video = out
         else:

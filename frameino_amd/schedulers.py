@@ -145,10 +145,11 @@ class CogVideoXDPMScheduler(CogVideoXDDIMScheduler):
             rows.append([float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(m1), float(m2), m3, m4, float(mn),
                          1.0 if use_old else 0.0])
         self.coefs = torch.tensor(rows, dtype=torch.float32, device=device)
+        self._use_old = [r[7] != 0.0 for r in rows]          # host copy: the loop must not sync on the device table
 
     def draws(self, i):
         """number of standard-normal tensors diffusers' step consumes at step i"""
-        return 2 if self.coefs[i, 7].item() != 0 else 1
+        return 2 if self._use_old[i] else 1
 
     def noise(self, i, shape, generator, device, dtype):
         """the draw step i uses (the LAST of its `draws(i)` draws), sampled like diffusers' randn_tensor: on the

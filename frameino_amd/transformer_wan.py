@@ -140,6 +140,7 @@ class WanTransformer3DModel(nn.Module):
         self.ops = ops            # kernel front end (tests of the sharding logic inject a CPU stand-in)
         self.parallel = None      # frameino_amd.parallel.TokenShard or None
         self._fp8 = {}            # (layer, linear) -> (e4m3 weight bytes, MX scales); see enable_mxfp8_linears
+        self._fp8_pending = False # MXFP8 was on when the parameters last moved / changed: re-quantise at the next forward
         self.dedup_shared_prefix = True   # A/B knob: CFG-batched call computes the branch-invariant prefix once
         # True: q of the self-attention leaves its norm + RoPE kernel already multiplied by head_dim**-0.5 * log2(e) (fp32,
         # one rounding) and the attention kernels take q.k as the exp2 argument (FINO_ATTN_SCALE_FOLDED), which lets the
@@ -184,17 +185,19 @@ class WanTransformer3DModel(nn.Module):
                 keep32 = any(s in k for s in self._keep_in_fp32_modules)
                 t = sd[k].to(torch.float32 if keep32 else (dtype or sd[k].dtype))
                 p.data = t.to(p.device).contiguous()
-        if self.reset_caches():
-            self.enable_mxfp8_linears()
+        self.reset_caches()
         return self
 
     # ------------------------------------------------------------------ derived state
     def reset_caches(self):
         """Drop everything derived from the parameters or the prompt: packed/fused weight copies, MXFP8 weights, text
         K/V, RoPE tables, workspaces.  Called whenever the parameters may have changed or moved."""
-        had_fp8 = bool(self._fp8)
+        had_fp8 = bool(self._fp8) or self._fp8_pending
         self._packed = None
         self._fp8 = {}
+        # the MXFP8 weights are re-quantised lazily, by the next forward, from wherever the parameters are then: a
+        # `.to("cpu")` / `.float()` in between must not run the GPU quantiser on host tensors or leave the module half moved
+        self._fp8_pending = had_fp8
         self._text_cache.clear()
         self._rope_cache.clear()
         self._ws.clear()
@@ -202,14 +205,13 @@ class WanTransformer3DModel(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .half() / .float(): parameters move or change
         out = super()._apply(fn, *args, **kwargs)
-        if hasattr(self, "_text_cache") and self.reset_caches():
-            self.enable_mxfp8_linears()
+        if hasattr(self, "_text_cache"):
+            self.reset_caches()
         return out
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
-        if self.reset_caches():
-            self.enable_mxfp8_linears()
+        self.reset_caches()
         return out
 
     def _default_processors(self):
@@ -244,6 +246,7 @@ class WanTransformer3DModel(nn.Module):
         and the output head stay in the model dtype.  There is no reference counterpart: the result is
         compared with this model's own bf16 forward (tests/test_mxfp8_gpu.py)."""
         self._fp8 = {}
+        self._fp8_pending = False
         if not enabled:
             return self
         pk = self._packed or self._pack()
@@ -364,6 +367,8 @@ class WanTransformer3DModel(nn.Module):
             attention_kwargs = dict(attention_kwargs)
             attention_kwargs.pop("scale", None)                                    # LoRA scale (:463-476): no PEFT here
         b = hidden_states.shape[0]
+        if self._fp8_pending:
+            self.enable_mxfp8_linears()
         pk = self._packed or self._pack()
         default_procs = self._default_processors()
         o = self.ops
@@ -399,8 +404,12 @@ class WanTransformer3DModel(nn.Module):
             cos, sin = self._rope_cache[key]
 
         # ---- timestep rows + selector (F7) ----
+        # `same_rows`: every batch element sees the same modulation rows BY CONSTRUCTION (the selector of one element
+        # repeated, or one scalar timestep) -- the precondition of the shared prefix below
+        same_rows = False
         if timestep_rows is not None:
             t_rows, sel = timestep_rows
+            same_rows = True
             if sel is not None and sh is not None:
                 sel = sel[lo:lo + n].contiguous()
             if sel is not None and b > 1:
@@ -410,11 +419,15 @@ class WanTransformer3DModel(nn.Module):
             sel = inv.to(torch.int32).contiguous()
             if sh is not None:
                 sel = sel[lo:lo + n].contiguous()
+            elif timestep.shape[0] == 1 and b > 1:                                 # one row of per-token values: broadcast
+                sel = sel.repeat(b)
+                same_rows = True
         else:
             t_rows = timestep.reshape(-1)
             sel = None if b == 1 else torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(n)
             if t_rows.numel() == 1 and b > 1:
                 sel = None
+                same_rows = True
         temb, tproj = self._time_rows(t_rows.to(dev), encoder_hidden_states.dtype)       # [R,D], [R,6,D]
         # per-layer modulation tables: scale_shift_table + temb.float()  (:317-319)  -> [R, layers, 6, D] fp32
         mod = (pk.sst[None] + tproj.float()[:, None]).contiguous()
@@ -427,8 +440,9 @@ class WanTransformer3DModel(nn.Module):
         # `shared`: the batch elements are the SAME latent (the pipeline's CFG-batched call passes x.expand(2, ...)) under
         # the same timestep rows: everything up to the first text cross-attention is identical for them, so the patch
         # embedding and layer 0's self-attention branch run once and their result is copied (exactly what each element
-        # would have computed).
-        shared = self.dedup_shared_prefix and b > 1 and sh is None and hidden_states.stride(0) == 0 and default_procs
+        # would have computed).  A per-sample timestep ([b] or [b, L] values) takes the general path.
+        shared = (self.dedup_shared_prefix and b > 1 and sh is None and hidden_states.stride(0) == 0 and default_procs
+                  and same_rows)
         if b == 1 or shared:
             a_rows = o.patchify(hidden_states[0], cfg.patch_size)[lo:lo + n]
         else:

@@ -41,6 +41,57 @@ def test_derived_state_is_dropped_when_parameters_move_or_change():
     assert m._packed is None
 
 
+def test_mxfp8_requantise_is_deferred_to_the_next_forward():
+    """with MXFP8 on, `.to()` / `load_state_dict` must not run the (GPU) quantiser on the spot -- a move to the
+    host would raise half way through; the flag is remembered and the next forward re-quantises."""
+    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+    cog = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=16, in_channels=6, out_channels=2,
+                                      time_embed_dim=16, text_embed_dim=8, num_layers=1, sample_width=8, sample_height=8,
+                                      sample_frames=9, max_text_seq_length=5, use_rotary_positional_embeddings=True,
+                                      use_learned_positional_embeddings=True)
+    for m in (_tiny(), cog):
+        m._fp8 = {(0, "qkv"): ("bytes", "scales")}          # as left by enable_mxfp8_linears() on a GPU
+        m.to(torch.float64)                                   # no quantiser call (it would fail: no GPU here)
+        assert not m._fp8 and m._fp8_pending
+        m.load_state_dict(m.state_dict())
+        assert m._fp8_pending
+        m.enable_mxfp8_linears(False)
+        assert not m._fp8_pending
+
+
+def test_shared_prefix_needs_identical_modulation_rows():
+    """`x.expand(2, ...)` with two DIFFERENT timesteps is a legal call; the branch-invariant-prefix
+    shortcut must not serve element 0's layer-0 branch to element 1."""
+    from tests import cpu_ops
+    torch.manual_seed(5)
+    m = _tiny().float().eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape) * (0.5 if p_.ndim == 1 else p_.shape[-1] ** -0.5))
+    m.reset_caches()
+    m.ops = cpu_ops
+    x = torch.randn(1, 8, 2, 4, 4)
+    txt = torch.randn(2, 6, 16)
+    L = 2 * 2 * 2
+
+    def run(ts, dedup, **kw):
+        m.dedup_shared_prefix = dedup
+        return m(x.expand(2, -1, -1, -1, -1), ts, txt, return_dict=False, **kw)[0]
+
+    for ts in (torch.tensor([900.0, 100.0]),                                  # per-sample scalar timesteps
+               torch.stack([torch.full((L,), 900.0), torch.full((L,), 100.0)])):     # per-sample per-token timesteps
+        on, off = run(ts, True), run(ts, False)
+        assert torch.equal(on, off)
+        assert (on[0] - on[1]).abs().max() > 1e-3                             # the elements really differ
+    # the cases the shortcut is for stay bit-identical to the general path
+    per_tok = torch.full((1, L), 700.0)
+    per_tok[0, :4] = 0.0
+    for ts, kw in ((torch.tensor([500.0]), {}), (per_tok, {}),
+                   (None, {"timestep_rows": (torch.tensor([0.0, 700.0]),
+                                             (per_tok[0] > 0).to(torch.int32))})):
+        assert torch.equal(run(ts, True, **kw), run(ts, False, **kw))
+
+
 def test_swapping_a_processor_after_the_first_forward_is_seen():
     from frameino_amd.attention_processor import MI355WanAttnProcessor
 
