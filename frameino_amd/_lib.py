@@ -96,6 +96,12 @@ def load(path=LIB_PATH):
             f"frameino_amd: HIP library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C frameino_amd/csrc`). There is no CPU fallback for the product path.")
     lib = ctypes.CDLL(path)
+    lib.fino_version.restype = c_int
+    if lib.fino_version() < 0 and os.environ.get("FINO_ALLOW_EXPERIMENT") != "1":
+        raise RuntimeError(
+            f"frameino_amd: {path} is a timing-EXPERIMENT build (compiled with -DFINO_EXPERIMENT: its kernels may skip "
+            f"work and return wrong results; fino_version() = {lib.fino_version()}).  It is refused as the product library; "
+            f"set FINO_ALLOW_EXPERIMENT=1 for the tools/ scripts that time it.")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

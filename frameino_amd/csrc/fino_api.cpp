@@ -17,7 +17,11 @@ void fino_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fino_last_error(void) { return g_err; }
+#ifdef FINO_EXPERIMENT
+extern "C" int fino_version(void) { return -FINO_VERSION; }   // timing-experiment build: never the product (see the header)
+#else
 extern "C" int fino_version(void) { return FINO_VERSION; }
+#endif
 
 // ---- tuning knobs (diagnostics / A-B timing in one process; never needed for correct results) ----
 static std::atomic<int> g_tune[FINO_TUNE_COUNT];

@@ -7,6 +7,17 @@
 
 #include "../../include/frameino_hip.h"
 
+// Timing-experiment switches that produce WRONG RESULTS (kept because DESIGN.md section 4.1 cites their measurements):
+// they compile only together with -DFINO_EXPERIMENT, which makes fino_version() negative (fino_api.cpp) so that
+// frameino_amd._lib.load() refuses the library unless FINO_ALLOW_EXPERIMENT=1.
+//   make variant NAME=nopack VFLAGS="-DFINO_EXPERIMENT -DW4_X_NOPACK"
+#if (defined(W4_X_NOLGKM) || defined(W4_X_NOPACK) || defined(W4_X_PACKPERM) || defined(W4_X_PACKCONST) || \
+     defined(W4_X_NOEXP) || defined(W4_X_NOBAR) || defined(W4_X_NODMA) || defined(W4_X_NOMAX) ||           \
+     defined(FINO_GEMM_DESYNC_EXP)) &&                                                                      \
+    !defined(FINO_EXPERIMENT)
+#error "wrong-result timing experiments (W4_X_*, FINO_GEMM_DESYNC_EXP) need -DFINO_EXPERIMENT: see fino_common.h"
+#endif
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));

@@ -31,6 +31,9 @@ enum {
     FINO_ERR_UNSUPPORTED = -3
 };
 
+/* FINO_VERSION for a product build.  A library compiled with -DFINO_EXPERIMENT (the only way to enable the kernels'
+ * wrong-result timing-experiment switches, csrc/fino_common.h) reports -FINO_VERSION: frameino_amd._lib.load() refuses
+ * it unless FINO_ALLOW_EXPERIMENT=1 is set, so such a build can never pass for the product by accident. */
 int fino_version(void);
 const char* fino_last_error(void);
 

@@ -69,3 +69,30 @@ def test_product_path_has_no_cpu_fallback():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_an_experiment_build_is_refused_as_the_product_library(tmp_path, monkeypatch):
+    """a library compiled with -DFINO_EXPERIMENT (wrong-result timing switches) reports a negative version
+    and `_lib.load()` refuses it unless FINO_ALLOW_EXPERIMENT=1; the switches themselves do not compile without the macro."""
+    import subprocess
+    src = tmp_path / "fake.c"
+    src.write_text("int fino_version(void) { return -100; }\n")
+    so = tmp_path / "libfake_experiment.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    monkeypatch.delenv("FINO_ALLOW_EXPERIMENT", raising=False)
+    with pytest.raises(RuntimeError, match="EXPERIMENT build"):
+        _lib.load(str(so))
+    monkeypatch.setenv("FINO_ALLOW_EXPERIMENT", "1")
+    with pytest.raises(AttributeError):              # accepted, then fails on the first symbol the stand-in lacks
+        _lib.load(str(so))
+    # the guard in the sources: every wrong-result switch is tied to FINO_EXPERIMENT, and the version follows the macro
+    csrc = os.path.join(os.path.dirname(_lib.HEADER_PATH), "..", "frameino_amd", "csrc")
+    common = open(os.path.join(csrc, "fino_common.h")).read()
+    import re
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cpp")):
+            used |= set(re.findall(r"\b(W4_X_[A-Z]+|FINO_GEMM_DESYNC_EXP)\b", open(os.path.join(csrc, f)).read()))
+    guard = common[common.index("#if (defined("):common.index("#error")]
+    assert used and all(f"defined({u})" in guard for u in used), sorted(used)
+    assert "return -FINO_VERSION" in open(os.path.join(csrc, "fino_api.cpp")).read()

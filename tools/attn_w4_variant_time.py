@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the 4-wave folded-scale attention kernel from the library named by FINO_LIB_PATH (experiment builds:
-`make -C frameino_amd/csrc variant NAME=x VFLAGS=-DW4_X_...`; their results are wrong by design, only the time counts).
+`make -C frameino_amd/csrc variant NAME=x VFLAGS="-DFINO_EXPERIMENT -DW4_X_..."`, run with FINO_ALLOW_EXPERIMENT=1; their results are wrong by design, only the time counts).
 usage: attn_w4_variant_time.py [head_dim=64] [L=19126] [heads=48]"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
