@@ -521,15 +521,37 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
-// ---- stream-K for the partial last round of tiles (long-K GEMMs) ----------------------------------------------------
-// With T tiles on C CUs the last round holds rem = T mod C tiles and lasts a whole tile time (FFN-down: 1164 tiles = 4.55
-// rounds, K = 14336: 270 us for 55 % of the CUs).  Here the first T - rem tiles run as whole tiles (gemm_pp_kernel on a
-// grid of T - rem), then the rem tail tiles' rem x nk K-tile units are dealt to up to C workgroups in equal contiguous
-// ranges of `per` units (a range touches at most two tiles since per < nk): every piece leaves its fp32 accumulators in a
-// caller-owned workspace in thread order (this kernel carries no epilogue: nothing but the main loop's registers), and
-// gemm_sk_combine_kernel sums a tile's 1-3 pieces and runs the normal epilogue.
-// Pays only for long K: the partials cost ~0.5 MB of traffic per tail tile whatever K is (profiles/r02_gemm_raster.md).
-template <typename T>
+// ---- stream-K: the last, partial round of tiles (or a whole GEMM of fewer tiles than CUs) balanced over all CUs ------
+// With T tiles on C CUs the last round holds T mod C tiles and lasts a whole tile time: 1164 tiles (M = 24640, N = 3072)
+// are 4.55 rounds paid as 5, the 156 tiles of a 3080-row token shard keep 100 of 256 CUs idle for the whole GEMM.
+// ONE launch: blocks [0, sk_full) run the first sk_full tiles of the raster whole; the K-tile units of the remaining
+// sk_rem tiles (one or two rounds' worth) form one stream that sk_nwg further blocks cut into equal contiguous ranges.
+// A range = [tail of a tile][whole tiles][head of a tile].  Its leading piece, when it does not start a tile, leaves
+// its fp32 accumulators in the range's workspace slot (thread order, 16-B sc1 write-through stores) and raises the
+// range's flag -- EARLY in the block's life; the block that holds a tile's first K-tiles reaches that piece LAST in
+// its range, adds the slots of the ranges that follow inside the same tile (sc1 loads behind an sc1 flag poll: the
+// hand-off form of MI355X_MICROARCH.md "inter-workgroup visibility": every byte stored and loaded sc1, every storing wave
+// drained before the one flag store, the pollers' block barrier before the loads) and runs the ordinary epilogue.
+// So a block only ever waits for what other blocks produced at their start; flags are reset by their one consumer
+// (the workspace's flag area is zero before the first launch and after every launch: hipGraph-replayable).
+// Range boundaries closer than kSkSnap K-tiles to a tile edge snap to it (no 1-K-tile pieces with a whole pipeline ramp).
+constexpr int kSkSnap = 4;
+constexpr int kSkFlagStride = 32;                                       // ints: one 128-B line per flag
+constexpr int kSkMaxWg = 512;
+constexpr int64_t kSkFlagBytes = (int64_t)kSkMaxWg * kSkFlagStride * 4;   // fixed-size flag area at the workspace's start
+constexpr int64_t kSkPartialBytes = (int64_t)32 * kThreads * 16;        // one slot: 256 x 256 fp32
+
+__host__ __device__ __forceinline__ int64_t sk_range_begin(int64_t units, int nwg, int nk, int s) {
+    int64_t b = units * s / nwg;
+    const int r = (int)(b % nk);
+    if (nk >= 4 * kSkSnap) {
+        if (r < kSkSnap) b -= r;
+        else if (nk - r < kSkSnap) b += nk - r;
+    }
+    return b;
+}
+
+template <typename T, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_sk_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -539,56 +561,75 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_sk_kernel(const GemmParams p
     const int wn = wave & 3;
     const int nk = (int)(p.k / BK);
     f32x4_t acc[8][4];
-    const int w = (int)blockIdx.x;
-    const int64_t u0 = (int64_t)w * p.sk_per;
-    const int64_t uend = (int64_t)p.sk_rem * nk;
-    const int64_t u1 = u0 + p.sk_per < uend ? u0 + p.sk_per : uend;
-    const int t_first = (int)(u0 / nk);
-    const int npieces = (int)((u1 - 1) / nk) - t_first + 1;
-    for (int piece = 0; piece < npieces; ++piece) {
-        if (piece > 0) __syncthreads();                      // the previous piece's LDS stages are free
-        const int tl = t_first + piece;
-        const int64_t b0 = (int64_t)tl * nk;
-        const int kb = u0 > b0 ? (int)(u0 - b0) : 0;
-        const int ke = u1 - b0 < nk ? (int)(u1 - b0) : nk;
+    // one code path for both kinds of block: a whole-tile block is the range [id * nk, (id + 1) * nk) of the raster's
+    // K-tile units; a stream block the range sk_full * nk + [begin(s), begin(s + 1))
+    const int64_t units = (int64_t)p.sk_rem * nk;
+    const int64_t base_u = (int64_t)p.sk_full * nk;
+    int s = -1;
+    int64_t u, u1;
+    if ((int)blockIdx.x < p.sk_full) {
+        u = (int64_t)xcd_remap((int)blockIdx.x, p.sk_full) * nk;
+        u1 = u + nk;
+    } else {
+        s = xcd_remap((int)blockIdx.x - p.sk_full, p.sk_nwg);
+        u = base_u + sk_range_begin(units, p.sk_nwg, nk, s);
+        u1 = base_u + sk_range_begin(units, p.sk_nwg, nk, s + 1);
+    }
+    const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.sk_ws, 0, (int)(p.sk_nwg * kSkPartialBytes), 0x00020000);
+    bool first = true;
+    while (u < u1) {
+        if (!first) __syncthreads();                         // the previous piece's epilogue / LDS stages are done with
+        first = false;
+        const int tl = (int)(u / nk);
+        const int kb = (int)(u - (int64_t)tl * nk);
+        const int64_t tile_end = (int64_t)(tl + 1) * nk;
+        const int ke = (int)((u1 < tile_end ? u1 : tile_end) - (int64_t)tl * nk);
         int tm, tn;
-        tile_raster(p, p.sk_full + tl, tm, tn);
-        pp_mainloop<T, false>(p, smem, (int64_t)tm * BM, (int64_t)tn * BN, kb, ke - kb, acc, tid, lane, wave, wm, wn);
-        f32x4_t* part = reinterpret_cast<f32x4_t*>(p.sk_ws) + ((int64_t)w * 2 + piece) * (32 * kThreads);
+        tile_raster(p, tl, tm, tn);
+        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+        pp_mainloop<T, false>(p, smem, m0, n0, kb, ke - kb, acc, tid, lane, wave, wm, wn);
+        if (kb > 0) {
+            // ---- contributor: publish the accumulators (write-through), drain, one flag store ----
+            const int base = s * (int)kSkPartialBytes;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[(i * 4 + j) * kThreads + tid] = acc[i][j];
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), ws_rsrc, tid * 16,
+                                                           base + (i * 4 + j) * (kThreads * 16), 16 /* sc1 */);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(p.sk_flags + s * kSkFlagStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ke < nk) {
+                // ---- owner of a split tile: add the slots of the ranges that begin inside it ----
+                for (int c = s + 1; c < p.sk_nwg && base_u + sk_range_begin(units, p.sk_nwg, nk, c) < tile_end; ++c) {
+                    if (tid == 0) {
+                        int* f = p.sk_flags + c * kSkFlagStride;
+                        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                            __builtin_amdgcn_s_sleep(4);
+                        __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // its one consumer resets it
+                    }
+                    __syncthreads();
+                    const int base = c * (int)kSkPartialBytes;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        u32x4_t t4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            t4[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                    ws_rsrc, tid * 16, base + (i * 4 + j) * (kThreads * 16), 16));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] += __builtin_bit_cast(f32x4_t, t4[j]);
+                    }
+                }
+            }
+            gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
+        }
+        u = (int64_t)tl * nk + ke;
     }
-}
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void gemm_sk_combine_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int nk = (int)(p.k / BK);
-    const int tl = blockIdx.x;
-    const int c_first = (int)(((int64_t)tl * nk) / p.sk_per);
-    const int c_last = (int)((((int64_t)tl + 1) * nk - 1) / p.sk_per);
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int c = c_first; c <= c_last; ++c) {
-        const int piece = tl - (int)(((int64_t)c * p.sk_per) / nk);
-        const f32x4_t* part = reinterpret_cast<const f32x4_t*>(p.sk_ws) + ((int64_t)c * 2 + piece) * (32 * kThreads);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += part[(i * 4 + j) * kThreads + tid];
-    }
-    int tm, tn;
-    tile_raster(p, p.sk_full + tl, tm, tn);
-    gemm_epilogue<T, EPI>(acc, p, smem, (int64_t)tm * BM, (int64_t)tn * BN, tid, lane, wm, wn);
 }
 
 template <typename T, int EPI, bool GENERIC, bool CONV = false>
@@ -609,25 +650,27 @@ int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
-// Stream-K plan for the partial last round: worth it only when a tile is long (K >= 8192: the fp32 partials cost the same
-// ~0.5 MB per tail tile whatever K is) and the last round leaves most of the chip idle.  Measured (tools/gemm_sk_ab.py,
-// K = 14336): the tail kernel + combine cost ~130 us on top of the tail's share of a round (partials written and read
-// back, a second pipeline ramp in ranges that straddle two tiles), a round is ~350 us: M = 12320 (76 tail tiles, 30 % of
-// a round) 984 -> 884 us, M = 24640 (141 tail tiles, 55 %) 1713 -> 1721 us.  Hence: only when the tail fills <= 40 %.
-struct SkPlan { int full, rem, per, nwg; };
+// Stream-K plan.  DP time = ceil(T / C) tile times, stream-K time = T / C tile times + the hand-off (slot publish + one
+// slot read on the owner's critical path: ~10 us, about 6 K-tiles of work): split when the idle part of the last round,
+// in K-tiles, exceeds kSkMinWasteKTiles.  The stream covers the last one-to-two rounds' worth of tiles ("two-tile"
+// stream-K: a range is >= one tile long, so a tile has at most two pieces, and the slot is published long before its
+// consumer asks for it); with fewer tiles than CUs all of them.
+constexpr int kSkMinWasteKTiles = 10;
+struct SkPlan { int full, rem, nwg; };
 inline SkPlan plan_stream_k(int tiles, int nk, int cus) {
-    SkPlan sp{tiles, 0, 1, 0};
+    SkPlan sp{tiles, 0, 0};
+    const int mode = fino_tune_get(FINO_TUNE_GEMM_STREAM_K);      // 1 = never, 2 = whenever legal (A/B)
+    if (mode == 1 || nk < 8 || tiles <= 0 || cus <= 0 || cus > kSkMaxWg) return sp;
     const int rem = tiles % cus;
-    const int max_fill = fino_tune_get(FINO_TUNE_GEMM_STREAM_K) == 2 ? 90 : 40;          // 2 = A/B: split whenever legal
-    if (fino_tune_get(FINO_TUNE_GEMM_STREAM_K) == 1) return sp;                          // 1 = A/B: never
-    if (tiles < cus || rem == 0 || nk < 128 || rem * 100 > cus * max_fill) return sp;
-    const int64_t units = (int64_t)rem * nk;
-    const int per = (int)((units + cus - 1) / cus);
-    if (per >= nk || per < 8) return sp;
-    sp.full = tiles - rem;
-    sp.rem = rem;
-    sp.per = per;
-    sp.nwg = (int)((units + per - 1) / per);
+    if (rem == 0) return sp;
+    const int64_t idle_ktiles = (int64_t)(cus - rem) * nk / cus;   // (ceil(T/C) - T/C) * nk
+    if (mode != 2 && idle_ktiles < kSkMinWasteKTiles) return sp;
+    const int rounds = tiles / cus;
+    sp.full = rounds >= 2 ? (rounds - 1) * cus : 0;
+    sp.rem = tiles - sp.full;
+    const int64_t units = (int64_t)sp.rem * nk;
+    sp.nwg = (int)(units / 8 < cus ? units / 8 : cus);
+    if (sp.nwg < 2) return SkPlan{tiles, 0, 0};
     return sp;
 }
 inline int gemm_device_cus() {
@@ -641,20 +684,11 @@ inline int gemm_device_cus() {
     }
     return c;
 }
-constexpr int64_t kSkPartialBytes = (int64_t)32 * kThreads * 16;        // one piece: 256 x 256 fp32
-
 template <typename T, int EPI>
 int launch_gemm_sk(const GemmParams& p, hipStream_t st) {
-    static FinoPerDeviceOnce once_a, once_b, once_c;
-    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&gemm_sk_kernel<T>), kSmemBytes, "fino_gemm")) return rc;
-    if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&gemm_sk_combine_kernel<T, EPI>), kSmemBytes, "fino_gemm")) return rc;
-    if (int rc = fino_max_smem_once(once_c, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, false>), kSmemBytes, "fino_gemm")) return rc;
-    // whole tiles: the ordinary kernel on the leading sk_full tiles of the raster (a multiple of the CU count)
-    gemm_pp_kernel<T, EPI, false><<<dim3((unsigned)p.sk_full), kThreads, kSmemBytes, st>>>(p);
-    FINO_LAUNCH_CHECK();
-    gemm_sk_kernel<T><<<dim3((unsigned)p.sk_nwg), kThreads, kSmemBytes, st>>>(p);
-    FINO_LAUNCH_CHECK();
-    gemm_sk_combine_kernel<T, EPI><<<dim3((unsigned)p.sk_rem), kThreads, kSmemBytes, st>>>(p);
+    static FinoPerDeviceOnce once;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_sk_kernel<T, EPI>), kSmemBytes, "fino_gemm")) return rc;
+    gemm_sk_kernel<T, EPI><<<dim3((unsigned)(p.sk_full + p.sk_nwg)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -744,7 +778,7 @@ extern "C" int64_t fino_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0 || k % BK != 0) return 0;
     const int tiles = (int)((m + BM - 1) / BM) * (int)((n + BN - 1) / BN);
     const SkPlan sp = plan_stream_k(tiles, (int)(k / BK), gemm_device_cus());
-    return sp.rem > 0 ? (int64_t)sp.nwg * 2 * kSkPartialBytes : 0;
+    return sp.rem > 0 ? kSkFlagBytes + (int64_t)sp.nwg * kSkPartialBytes : 0;
 }
 
 extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
@@ -789,10 +823,12 @@ extern "C" int fino_gemm_ws(const void* a, const void* w, const void* bias, void
         FINO_CHECK(fino_aligned16(workspace), FINO_ERR_ARG, "fino_gemm_ws: workspace must be 16-byte aligned");
         const SkPlan sp = plan_stream_k(p.tiles_m * p.tiles_n, (int)(k / BK), gemm_device_cus());
         if (sp.rem > 0) {
-            const int64_t need = (int64_t)sp.nwg * 2 * kSkPartialBytes;
+            const int64_t need = kSkFlagBytes + (int64_t)sp.nwg * kSkPartialBytes;
             FINO_CHECK(workspace_bytes >= need, FINO_ERR_ARG, "fino_gemm_ws: workspace %lld B < %lld B",
                        (long long)workspace_bytes, (long long)need);
-            p.sk_full = sp.full; p.sk_rem = sp.rem; p.sk_per = sp.per; p.sk_nwg = sp.nwg; p.sk_ws = (float*)workspace;
+            p.sk_full = sp.full; p.sk_rem = sp.rem; p.sk_nwg = sp.nwg;
+            p.sk_flags = (int*)workspace;
+            p.sk_ws = (float*)((char*)workspace + kSkFlagBytes);
         }
     }
     if (dtype == FINO_BF16)

@@ -22,10 +22,13 @@ struct GemmParams {
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
     int group_m;                     // tile rows per raster group (tile_coords); 0 = default
-    // stream-K over the partial last round (gemm_sk_kernel): the first sk_full tiles run whole, the K-tile units of the
-    // last sk_rem tiles are dealt in ranges of sk_per units; fp32 partials in sk_ws ([range][2 pieces][32][512] x 16 B)
-    int sk_full, sk_rem, sk_per, sk_nwg;
+    // stream-K (gemm_sk_kernel, one launch): the first sk_full tiles of the raster run whole (one block each), the
+    // K-tile units of the last sk_rem tiles are dealt to sk_nwg more blocks in equal contiguous ranges; a range's leading
+    // piece that does not start a tile leaves its fp32 accumulators in sk_ws (slot = range index, [32][512] x 16 B) and
+    // raises sk_flags[32 * range]; the block that holds a tile's FIRST K-tiles adds them and runs the epilogue
+    int sk_full, sk_rem, sk_nwg;
     float* sk_ws;
+    int* sk_flags;
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents

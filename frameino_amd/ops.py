@@ -235,7 +235,8 @@ def attention_merge(parts, batch, lq, heads, head_dim, dtype, out=None):
     return out
 
 
-_gemm_ws = {}      # (device index, stream) -> fp32 workspace of the stream-K tail (caller-owned per the C ABI; grown on demand)
+_gemm_ws = {}      # (device index, stream) -> stream-K workspace (caller-owned per the C ABI; grown on demand; its flag area
+                   # must start out zero and every launch leaves it zero: allocated with zeros)
 
 
 def _gemm_workspace(m, n, k, device):
@@ -245,7 +246,7 @@ def _gemm_workspace(m, n, k, device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _gemm_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
-        ws = _gemm_ws[key] = torch.empty(need // 4, dtype=torch.float32, device=device)
+        ws = _gemm_ws[key] = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
     return ws, need
 
 

@@ -40,7 +40,7 @@ const char* fino_last_error(void);
 /* Tuning knobs for A/B timing of kernel variants inside one process (tools/): results never depend on them.
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
  * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
- * ping-pong one.  FINO_TUNE_GEMM_STREAM_K: 1 = never use the stream-K tail of fino_gemm_ws, 2 = whenever legal.
+ * ping-pong one.  FINO_TUNE_GEMM_STREAM_K: 1 = never use stream-K in fino_gemm_ws, 2 = whenever legal.
  * FINO_TUNE_ATTN_KERNEL (head_dim 128): 2 = the 4-wave one-wave-per-SIMD kernel instead of the 8-wave ping-pong one. */
 enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_STREAM_K = 3,
        FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_COUNT = 8 };
@@ -161,11 +161,14 @@ enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EP
 int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
               int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
-/* fino_gemm with a caller-owned fp32 workspace of fino_gemm_workspace_bytes(M, N, K) bytes (0 = not needed): for long K
- * (>= 8192) a partial last round of 256x256 tiles that fills <= 40 % of the CUs is run stream-K -- its K-tile units dealt to
- * all CUs in equal ranges, partial accumulators summed by a small further launch that also runs the epilogue.  Same
- * results up to fp32 summation order in the split tiles.  (FFN-down of a Wan block on one CFG branch, nn.Linear
- * 14336 -> 3072 at M = 12320: 588 tiles = 2.3 rounds of 256 CUs: 984 -> 884 us.) */
+/* fino_gemm with a caller-owned workspace of fino_gemm_workspace_bytes(M, N, K) bytes (0 = not needed) for stream-K:
+ * when the last round of 256x256 tiles would leave CUs idle for more than ~10 K-tiles of work (or the GEMM has fewer tiles
+ * than CUs: the token-shard shapes), the K-tile units of the last one-to-two rounds' tiles are dealt to all CUs in equal
+ * contiguous ranges inside the SAME launch; a range's piece that does not start its tile is handed to the block that does
+ * through the workspace (fp32, write-through stores behind a flag), which adds it and runs the epilogue.  Same results up
+ * to fp32 summation order in the split tiles, deterministic for a given shape.  Workspace contract: 16-byte aligned, its
+ * first 64 KiB (the flags) ZERO before the first launch that uses it -- every launch leaves them zero again -- and not
+ * shared by launches that may run concurrently (one workspace per stream). */
 int64_t fino_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int fino_gemm_ws(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k, int64_t lda,
                  int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,

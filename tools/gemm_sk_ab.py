@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Stream-K tail of fino_gemm_ws forced on / off (FINO_TUNE_GEMM_STREAM_K = 2 / 1) at the FFN-down shapes, interleaved,
-median.  (The default, 0, splits only when the tail fills <= 40 % of a round.)"""
+"""Stream-K of fino_gemm_ws forced off / on / default policy (FINO_TUNE_GEMM_STREAM_K = 1 / 2 / 0) at every block GEMM of a
+Wan2.2-5B layer, for the one-GPU row counts (24640 = both CFG branches, 12320) and the token-shard ones (6160 / 3080 /
+1540), interleaved on one box, median of 7 x 5 launches.  usage: gemm_sk_ab.py [rows ...]"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,37 +9,40 @@ from frameino_amd import _lib, ops
 lib = _lib.lib()
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
-for M, n, k, nm in [(24640, 3072, 14336, "Wan FFN-down B=2"), (12320, 3072, 14336, "Wan FFN-down B=1"),
-                    (38252, 3072, 12288, "Cog FFN-down B=2"),
-                    # token shards (bench.py --gpus 4 / 8): fewer tiles than CUs, dealt whole by default (0)
-                    (6160, 3072, 14336, "FFN-down 2 shards"), (3080, 3072, 14336, "FFN-down 4 shards"),
-                    (1540, 3072, 14336, "FFN-down 8 shards")]:
-    A = torch.randn(M, k, device=dev, generator=g).bfloat16()
-    W = (torch.randn(n, k, device=dev, generator=g) * 0.02).bfloat16()
-    b = torch.randn(n, device=dev, generator=g).bfloat16()
-    res = torch.randn(M, n, device=dev, generator=g).bfloat16()
-    gate = torch.randn(2, n, device=dev, generator=g)
-    sel = (torch.arange(M, device=dev) % 2).to(torch.int32)
-    out = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
-    f = lambda: ops.gemm(A, W, b, 3, res, gate, sel, out=out)
-    r = {2: [], 1: []}
-    outs = {}
-    lib.fino_tune_set(3, 0); f(); f()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(10): f()
-    e.record(); torch.cuda.synchronize(); t_def = s.elapsed_time(e) / 10 * 1e3
-    for off in (1, 2):
-        lib.fino_tune_set(3, off); f(); f(); outs[off] = out.clone()
-    for _ in range(7):
-        for off in (1, 2):
-            lib.fino_tune_set(3, off)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(5): f()
-            e.record(); torch.cuda.synchronize(); r[off].append(s.elapsed_time(e) / 5 * 1e3)
-    lib.fino_tune_set(3, 0)
-    d = (outs[2].float() - outs[1].float()).abs().max().item()
-    t1, t0 = statistics.median(r[1]), statistics.median(r[2])
-    print(f"{nm:18s} {M}x{n}x{k}: whole tiles {t1:7.1f} us ({2.0*M*n*k/t1/1e6:5.0f} TF)  stream-K tail {t0:7.1f} us "
-          f"({2.0*M*n*k/t0/1e6:5.0f} TF)  ws {lib.fino_gemm_workspace_bytes(M, n, k) / 2**20:.0f} MiB  max|diff| {d:.4f}  default {t_def:7.1f} us")
+D, FF = 3072, 14336
+rows = [int(x) for x in sys.argv[1:]] or [24640, 12320, 6160, 3080, 1540]
+shapes = [("qkv", 3 * D, D, 0), ("kv", 2 * D, D, 0), ("q/q2", D, D, 0), ("out", D, D, 3), ("out2", D, D, 2),
+          ("ffn_up", FF, D, 1), ("ffn_down", D, FF, 3)]
+tot = {}
+for M in rows:
+    for nm, n, k, epi in shapes:
+        A = torch.randn(M, k, device=dev, generator=g).bfloat16()
+        W = (torch.randn(n, k, device=dev, generator=g) * 0.02).bfloat16()
+        b = torch.randn(n, device=dev, generator=g).bfloat16()
+        res = torch.randn(M, n, device=dev, generator=g).bfloat16() if epi >= 2 else None
+        gate = torch.randn(2, n, device=dev, generator=g) if epi >= 3 else None
+        sel = (torch.arange(M, device=dev) % 2).to(torch.int32) if epi >= 3 else None
+        out = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
+        f = lambda: ops.gemm(A, W, b, epi, res, gate, sel, out=out)
+        r = {0: [], 1: [], 2: []}
+        for mode in (1, 2, 0):
+            lib.fino_tune_set(3, mode); f(); f()
+        for _ in range(7):
+            for mode in (1, 2, 0):
+                lib.fino_tune_set(3, mode)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(5): f()
+                e.record(); torch.cuda.synchronize(); r[mode].append(s.elapsed_time(e) / 5 * 1e3)
+        lib.fino_tune_set(3, 2); ws2 = lib.fino_gemm_workspace_bytes(M, n, k)
+        lib.fino_tune_set(3, 0); ws0 = lib.fino_gemm_workspace_bytes(M, n, k)
+        t = {m_: statistics.median(v) for m_, v in r.items()}
+        tiles = -(-M // 256) * -(-n // 256)
+        fl = 2.0 * M * n * k
+        for m_ in t:
+            tot[(M, m_)] = tot.get((M, m_), 0.0) + t[m_]
+        print(f"M={M:6d} {nm:9s} N={n:5d} K={k:5d} tiles {tiles:5d} ({tiles / 256:5.2f} rounds): whole {t[1]:7.1f} us "
+              f"({fl / t[1] / 1e6:5.0f} TF)  stream-K {t[2]:7.1f} us ({fl / t[2] / 1e6:5.0f} TF){'' if ws2 else ' [n/a]'}  "
+              f"default {t[0]:7.1f} us [{'sk' if ws0 else 'whole'}]", flush=True)
+    print(f"M={M:6d} layer sum (qkv + q/q2 + out + out2 + ffn_up + ffn_down, kv not counted): whole "
+          f"{tot[(M, 1)] - 0:8.1f} us  stream-K {tot[(M, 2)]:8.1f} us  default {tot[(M, 0)]:8.1f} us  (all seven lines summed)")
