@@ -59,9 +59,7 @@ SIGNATURES = {
     "fino_resize_area_pad_u8": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
     "fino_u8_hwc_to_chw_unit": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
-    "fino_gemm_ws": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
-                     c_i64, c_void_p],
-    "fino_gemm_workspace_bytes": [c_i64, c_i64, c_i64],
+    "fino_gemm_plan": [c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)],
     "fino_skinny_linear": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
     "fino_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
     "fino_unpatchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
@@ -79,7 +77,7 @@ SIGNATURES = {
     "fino_vae_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
 }
 _RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64, "fino_mxfp8_scale_bytes": c_i64,
-             "fino_groupnorm_workspace_bytes": c_i64, "fino_gemm_workspace_bytes": c_i64,
+             "fino_groupnorm_workspace_bytes": c_i64,
              "fino_attn_partial_bytes": c_i64}
 
 

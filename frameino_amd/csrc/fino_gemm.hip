@@ -304,11 +304,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 // its rows can touch, so the offsets fit 32 bits on tensors of any size (fino_conv3d checks the per-tile span).
 // The main loop of one output tile over K-tiles [kb, kb + nk): everything between the tile coordinates and the
 // accumulators (the whole-tile kernel passes kb = 0, nk = K / 64; the stream-K kernel a key... a K range).
-template <typename T, bool CONV>
+// MI = 16-row fragments per wave: the tile is BM_ = 32 * MI rows high, group g (waves 4g .. 4g+3) owns rows [16 MI g,
+// 16 MI (g + 1)); 8 = the 256 x 256 tile.  Lower tiles exist for ROW COUNTS, not for speed per FLOP: 3080 rows (a 4-way
+// token shard) are 13 x 12 = 156 tiles of 256 x 256 on 256 CUs -- 100 CUs idle for the whole GEMM -- but 20 x 12 = 240
+// tiles of 160 x 256 in one round of 0.625 of the time (fino_gemm's planner, plan_tiles below).  A tiles are staged in
+// MI pieces of 32 rows: group 0 issues the first ceil(MI / 2) of them (they cover every row IT reads: its loads one phase
+// later must find them landed, and only its own vmcnt wait can vouch for that), group 1 the rest.
+template <typename T, bool CONV, int MI>
 __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, const int64_t m0, const int64_t n0,
-                                            const int kb, const int nk, f32x4_t (&acc)[8][4], const int tid,
+                                            const int kb, const int nk, f32x4_t (&acc)[MI][4], const int tid,
                                             const int lane, const int wave, const int wm, const int wn) {
     typedef typename T::vec8 vec8;
+    static_assert(MI >= 2 && MI <= 8, "tile height 64 .. 256");
+    static_assert(!CONV || MI == 8, "the implicit-GEMM gather is built for 256-row tiles");
+    enum : int { NA0 = (MI + 1) / 2, NA1 = MI - (MI + 1) / 2 };      // A pieces (32 rows each) issued by group 0 / group 1
 
     // ---- LDS-DMA pieces: 8 tile rows x 128 B per wave-instruction; swizzle on the source chunk ----
     // buffer_load_dwordx4 ... lds: the per-lane part of the address is ONE 32-bit byte offset per piece (row base +
@@ -318,8 +327,11 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     const int sk = ((lane & 7) ^ ((4 * (wn & 1) + (lane >> 4)) & 7)) * 8;   // = (phys chunk ^ swz(row)) * 8 elements
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.w, 0, (int)(((p.n - 1) * p.ldw + p.k) * 2), 0x00020000);
-    // A piece q (0..3) of my group: tile rows wm*128 + q*32 + wn*8 + r8;  W piece q (0..7): rows q*32 + wn*8 + r8
-    uint32_t a_off[4], w_off[8];
+    // my A piece qi (0 .. NA0-1 or NA1-1) is tile piece aq0 + qi: tile rows (aq0 + qi)*32 + wn*8 + r8;  W piece q (0..7):
+    // rows q*32 + wn*8 + r8
+    const int aq0 = wm == 0 ? 0 : NA0;
+    uint32_t a_off[4], w_off[8];                 // (NA0 <= 4 used; a fixed bound: a dependent one indexed by the unrolled
+                                                 // prologue loop below makes the host pass reject the template)
     // CONV state: packed output position of my 4 A rows; the tap (dt, dh, dw) and channel chunk of the NEXT tile to stage
     uint32_t pos[CONV ? 4 : 1];
     int ck = 0, tap_t = 0, tap_h = 0, tap_w = 0, t_first = 0, t_in_first = 0;
@@ -335,8 +347,8 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         a_bytes = (int64_t)(p.ti - t_in_first) * frame * 2;
         a_bytes = a_bytes > 0x7fffffffll ? 0x7fffffffll : a_bytes;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int64_t gm = m0 + wm * 128 + q * 32 + wn * 8 + r8;
+        for (int q = 0; q < NA0; ++q) {
+            int64_t gm = m0 + (aq0 + q) * 32 + wn * 8 + r8;
             gm = gm < p.m ? gm : p.m - 1;
             const int t = (int)(gm / hw);
             const int rem = (int)(gm - (int64_t)t * hw);
@@ -349,10 +361,10 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     auto conv_offsets = [&]() {
         const int hlim = p.up ? 2 * p.hi : p.hi, wlim = p.up ? 2 * p.wi : p.wi;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ti = (t_first + (int)(pos[q] >> 24)) * p.st + tap_t - p.pt;
-            int hi = (int)((pos[q] >> 12) & 0xfffu) * p.sh + tap_h - p.ph;
-            int wi = (int)(pos[q] & 0xfffu) * p.sw + tap_w - p.pw;
+        for (int q = 0; q < NA0; ++q) {
+            const int ti = (t_first + (int)(pos[CONV ? q : 0] >> 24)) * p.st + tap_t - p.pt;
+            int hi = (int)((pos[CONV ? q : 0] >> 12) & 0xfffu) * p.sh + tap_h - p.ph;
+            int wi = (int)(pos[CONV ? q : 0] & 0xfffu) * p.sw + tap_w - p.pw;
             const bool ok = (unsigned)ti < (unsigned)p.ti && (unsigned)hi < (unsigned)hlim && (unsigned)wi < (unsigned)wlim;
             if (p.up) { hi >>= 1; wi >>= 1; }
             const uint32_t off = (uint32_t)(((((ti - t_in_first) * p.hi + hi) * p.wi + wi) * (int)p.lda + sk) * 2);
@@ -374,8 +386,8 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         conv_offsets();
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int64_t gm = m0 + wm * 128 + q * 32 + wn * 8 + r8;
+        for (int q = 0; q < NA0; ++q) {
+            int64_t gm = m0 + (aq0 + q) * 32 + wn * 8 + r8;
             gm = gm < p.m ? gm : p.m - 1;
             a_off[q] = (uint32_t)((gm * p.lda + sk) * 2);
         }
@@ -391,10 +403,12 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         gn = gn < p.n ? gn : p.n - 1;
         w_off[q] = (uint32_t)((gn * p.ldw + sk) * 2);
     }
-#define PP_DMA_A(STAGE_, KT_, Q_)                                                                                 \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
-        a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + (wm * 128 + (Q_) * 32 + wn * 8) * 128), 16,      \
-        a_off[Q_], CONV ? ck * (BK * 2) : (kb + (KT_)) * (BK * 2), 0, 0);
+    // my A piece QI_ (a compile-time index; group 1 has NA1 <= NA0 of them)
+#define PP_DMA_A(STAGE_, KT_, QI_)                                                                                \
+    if ((QI_) < NA1 || wm == 0)                                                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
+            a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + ((aq0 + (QI_)) * 32 + wn * 8) * 128), 16,    \
+            a_off[QI_], CONV ? ck * (BK * 2) : (kb + (KT_)) * (BK * 2), 0, 0);
 #define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
     if (!CONV || (Q_) < w_pieces)                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
@@ -403,25 +417,25 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
 
     const int frow = lane & 15;
     const int pch0 = (lane >> 4) ^ (frow >> 1);
-    const int a_base = (wm * 128 + frow) * 128;
+    const int a_base = (wm * (16 * MI) + frow) * 128;
     const int w_base = kTileBytes + (wn * 64 + frow) * 128;
 
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: tiles 0 and 1 whole (each group its A half and half of W)
+    // prologue: tiles 0 and 1 whole (each group its A pieces and half of W)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        PP_DMA_A(0, 0, q)
+        if (q < NA0) { PP_DMA_A(0, 0, q) }
         if (wm == 0) { PP_DMA_W(0, 0, q) } else { PP_DMA_W(0, 0, 4 + q) }
     }
     if constexpr (CONV) conv_next();
     if (nk > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            PP_DMA_A(1, 1, q)
+            if (q < NA0) { PP_DMA_A(1, 1, q) }
             if (wm == 0) { PP_DMA_W(1, 1, q) } else { PP_DMA_W(1, 1, 4 + q) }
         }
         if constexpr (CONV) conv_next();
@@ -430,7 +444,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // phase 0: group 1 has nothing to compute yet
 
-    u32x4_t af[2][8], wf[2][4];
+    u32x4_t af[2][MI], wf[2][4];
 #ifdef FINO_GEMM_STAMP
     unsigned long long t0, t1, t2, t3, t4, acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #define PSTAMP(V_) { __builtin_amdgcn_sched_barrier(0); STAMP(V_) __builtin_amdgcn_sched_barrier(0); }
@@ -441,18 +455,18 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         const int cur = t & 1;
         const char* sb = smem + cur * kStageBytes;
         PSTAMP(t0)
-        // ---------------- LOAD(t): all fragments of my 128x64 (A) and 64x64 (W) operand blocks ----------------
+        // ---------------- LOAD(t): all fragments of my (16 MI)x64 (A) and 64x64 (W) operand blocks ----------------
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int pch = (pch0 ^ (kk << 2)) << 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) wf[kk][j] = *reinterpret_cast<const u32x4_t*>(sb + w_base + j * 2048 + pch);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(sb + a_base + i * 2048 + pch);
+            for (int i = 0; i < MI; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(sb + a_base + i * 2048 + pch);
         }
         if (t >= 1 && t + 1 < nk) {                  // tile t+1 into the stage tile t-1 has left
 #pragma unroll
-            for (int q = 0; q < 4; ++q) PP_DMA_A(cur ^ 1, t + 1, q)
+            for (int q = 0; q < NA0; ++q) PP_DMA_A(cur ^ 1, t + 1, q)
             if (wm == 0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { PP_DMA_W(cur ^ 1, t + 1, q) }
@@ -465,11 +479,11 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(t2)
-        // ---------------- COMPUTE(t): 64 MFMAs from registers ----------------
+        // ---------------- COMPUTE(t): 8 MI MFMAs from registers ----------------
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
@@ -499,7 +513,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
 #undef PP_DMA_W
 }
 
-template <typename T, int EPI, bool CONV = false>
+template <typename T, int EPI, bool CONV = false, int MI = 8>
 __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -509,127 +523,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     const int wn = wave & 3;
     int tm, tn;
     tile_coords(p, tm, tn);
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    f32x4_t acc[8][4];
+    const int64_t m0 = (int64_t)tm * (32 * MI), n0 = (int64_t)tn * BN;
+    f32x4_t acc[MI][4];
     int nk = (int)(p.k / BK);
 #ifdef FINO_GEMM_DESYNC_EXP
     // TIMING EXPERIMENT ONLY (wrong results): the first round's tiles stop after 1/8 .. 8/8 of K, so that the CUs leave
     // lock step and the epilogue bursts of later rounds are spread in time
     if (blockIdx.x < 256) nk = nk * (int)((blockIdx.x >> 3) % 8 + 1) / 8;
 #endif
-    pp_mainloop<T, CONV>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn);
-    gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
-}
-
-// ---- stream-K: the last, partial round of tiles (or a whole GEMM of fewer tiles than CUs) balanced over all CUs ------
-// With T tiles on C CUs the last round holds T mod C tiles and lasts a whole tile time: 1164 tiles (M = 24640, N = 3072)
-// are 4.55 rounds paid as 5, the 156 tiles of a 3080-row token shard keep 100 of 256 CUs idle for the whole GEMM.
-// ONE launch: blocks [0, sk_full) run the first sk_full tiles of the raster whole; the K-tile units of the remaining
-// sk_rem tiles (one or two rounds' worth) form one stream that sk_nwg further blocks cut into equal contiguous ranges.
-// A range = [tail of a tile][whole tiles][head of a tile].  Its leading piece, when it does not start a tile, leaves
-// its fp32 accumulators in the range's workspace slot (thread order, 16-B sc1 write-through stores) and raises the
-// range's flag -- EARLY in the block's life; the block that holds a tile's first K-tiles reaches that piece LAST in
-// its range, adds the slots of the ranges that follow inside the same tile (sc1 loads behind an sc1 flag poll: the
-// hand-off form of MI355X_MICROARCH.md "inter-workgroup visibility": every byte stored and loaded sc1, every storing wave
-// drained before the one flag store, the pollers' block barrier before the loads) and runs the ordinary epilogue.
-// So a block only ever waits for what other blocks produced at their start; flags are reset by their one consumer
-// (the workspace's flag area is zero before the first launch and after every launch: hipGraph-replayable).
-// Range boundaries closer than kSkSnap K-tiles to a tile edge snap to it (no 1-K-tile pieces with a whole pipeline ramp).
-constexpr int kSkSnap = 4;
-constexpr int kSkFlagStride = 32;                                       // ints: one 128-B line per flag
-constexpr int kSkMaxWg = 512;
-constexpr int64_t kSkFlagBytes = (int64_t)kSkMaxWg * kSkFlagStride * 4;   // fixed-size flag area at the workspace's start
-constexpr int64_t kSkPartialBytes = (int64_t)32 * kThreads * 16;        // one slot: 256 x 256 fp32
-
-__host__ __device__ __forceinline__ int64_t sk_range_begin(int64_t units, int nwg, int nk, int s) {
-    int64_t b = units * s / nwg;
-    const int r = (int)(b % nk);
-    if (nk >= 4 * kSkSnap) {
-        if (r < kSkSnap) b -= r;
-        else if (nk - r < kSkSnap) b += nk - r;
-    }
-    return b;
-}
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void gemm_sk_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2;
-    const int wn = wave & 3;
-    const int nk = (int)(p.k / BK);
-    f32x4_t acc[8][4];
-    // one code path for both kinds of block: a whole-tile block is the range [id * nk, (id + 1) * nk) of the raster's
-    // K-tile units; a stream block the range sk_full * nk + [begin(s), begin(s + 1))
-    const int64_t units = (int64_t)p.sk_rem * nk;
-    const int64_t base_u = (int64_t)p.sk_full * nk;
-    int s = -1;
-    int64_t u, u1;
-    if ((int)blockIdx.x < p.sk_full) {
-        u = (int64_t)xcd_remap((int)blockIdx.x, p.sk_full) * nk;
-        u1 = u + nk;
-    } else {
-        s = xcd_remap((int)blockIdx.x - p.sk_full, p.sk_nwg);
-        u = base_u + sk_range_begin(units, p.sk_nwg, nk, s);
-        u1 = base_u + sk_range_begin(units, p.sk_nwg, nk, s + 1);
-    }
-    const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.sk_ws, 0, (int)(p.sk_nwg * kSkPartialBytes), 0x00020000);
-    bool first = true;
-    while (u < u1) {
-        if (!first) __syncthreads();                         // the previous piece's epilogue / LDS stages are done with
-        first = false;
-        const int tl = (int)(u / nk);
-        const int kb = (int)(u - (int64_t)tl * nk);
-        const int64_t tile_end = (int64_t)(tl + 1) * nk;
-        const int ke = (int)((u1 < tile_end ? u1 : tile_end) - (int64_t)tl * nk);
-        int tm, tn;
-        tile_raster(p, tl, tm, tn);
-        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-        pp_mainloop<T, false>(p, smem, m0, n0, kb, ke - kb, acc, tid, lane, wave, wm, wn);
-        if (kb > 0) {
-            // ---- contributor: publish the accumulators (write-through), drain, one flag store ----
-            const int base = s * (int)kSkPartialBytes;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), ws_rsrc, tid * 16,
-                                                           base + (i * 4 + j) * (kThreads * 16), 16 /* sc1 */);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store(p.sk_flags + s * kSkFlagStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (ke < nk) {
-                // ---- owner of a split tile: add the slots of the ranges that begin inside it ----
-                for (int c = s + 1; c < p.sk_nwg && base_u + sk_range_begin(units, p.sk_nwg, nk, c) < tile_end; ++c) {
-                    if (tid == 0) {
-                        int* f = p.sk_flags + c * kSkFlagStride;
-                        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                            __builtin_amdgcn_s_sleep(4);
-                        __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // its one consumer resets it
-                    }
-                    __syncthreads();
-                    const int base = c * (int)kSkPartialBytes;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        u32x4_t t4[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            t4[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                    ws_rsrc, tid * 16, base + (i * 4 + j) * (kThreads * 16), 16));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] += __builtin_bit_cast(f32x4_t, t4[j]);
-                    }
-                }
-            }
-            gemm_epilogue<T, EPI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
-        }
-        u = (int64_t)tl * nk + ke;
-    }
+    pp_mainloop<T, CONV, MI>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn);
+    gemm_epilogue<T, EPI, false, MI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
 template <typename T, int EPI, bool GENERIC, bool CONV = false>
@@ -641,38 +544,15 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
-template <typename T, int EPI, bool CONV = false>
+template <typename T, int EPI, bool CONV = false, int MI = 8>
 int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     static FinoPerDeviceOnce once;
-    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV>), kSmemBytes, "fino_gemm")) return rc;
-    gemm_pp_kernel<T, EPI, CONV><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV, MI>), kSmemBytes, "fino_gemm")) return rc;
+    gemm_pp_kernel<T, EPI, CONV, MI><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
 
-// Stream-K plan.  DP time = ceil(T / C) tile times, stream-K time = T / C tile times + the hand-off (slot publish + one
-// slot read on the owner's critical path: ~10 us, about 6 K-tiles of work): split when the idle part of the last round,
-// in K-tiles, exceeds kSkMinWasteKTiles.  The stream covers the last one-to-two rounds' worth of tiles ("two-tile"
-// stream-K: a range is >= one tile long, so a tile has at most two pieces, and the slot is published long before its
-// consumer asks for it); with fewer tiles than CUs all of them.
-constexpr int kSkMinWasteKTiles = 10;
-struct SkPlan { int full, rem, nwg; };
-inline SkPlan plan_stream_k(int tiles, int nk, int cus) {
-    SkPlan sp{tiles, 0, 0};
-    const int mode = fino_tune_get(FINO_TUNE_GEMM_STREAM_K);      // 1 = never, 2 = whenever legal (A/B)
-    if (mode == 1 || nk < 8 || tiles <= 0 || cus <= 0 || cus > kSkMaxWg) return sp;
-    const int rem = tiles % cus;
-    if (rem == 0) return sp;
-    const int64_t idle_ktiles = (int64_t)(cus - rem) * nk / cus;   // (ceil(T/C) - T/C) * nk
-    if (mode != 2 && idle_ktiles < kSkMinWasteKTiles) return sp;
-    const int rounds = tiles / cus;
-    sp.full = rounds >= 2 ? (rounds - 1) * cus : 0;
-    sp.rem = tiles - sp.full;
-    const int64_t units = (int64_t)sp.rem * nk;
-    sp.nwg = (int)(units / 8 < cus ? units / 8 : cus);
-    if (sp.nwg < 2) return SkPlan{tiles, 0, 0};
-    return sp;
-}
 inline int gemm_device_cus() {
     static std::atomic<int> cus[kFinoMaxDevices];
     const int dev = fino_current_device();
@@ -684,13 +564,42 @@ inline int gemm_device_cus() {
     }
     return c;
 }
-template <typename T, int EPI>
-int launch_gemm_sk(const GemmParams& p, hipStream_t st) {
-    static FinoPerDeviceOnce once;
-    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_sk_kernel<T, EPI>), kSmemBytes, "fino_gemm")) return rc;
-    gemm_sk_kernel<T, EPI><<<dim3((unsigned)(p.sk_full + p.sk_nwg)), kThreads, kSmemBytes, st>>>(p);
-    FINO_LAUNCH_CHECK();
-    return FINO_OK;
+
+// ---- tile-height plan: which rows run as 256-row tiles, which as lower ones ------------------------------------------
+// Every tile of a launch lasts the same time, so a launch costs ceil(tiles / CUs) ROUNDS whatever the last round holds:
+// 1164 tiles (M = 24640, N = 3072) are 4.55 rounds paid as 5; the 156 tiles of a 3080-row token shard keep 100 of the 256
+// CUs idle for the whole GEMM.  Dealing the K-tiles of that last round to all CUs (stream-K) was built and measured in
+// round 3 and loses even with a free hand-off: blocks that start at different K offsets no longer walk K in lock step, and
+// the A / W panels that concurrent tiles share in L2 at every step stop being shared (profiles/r03_gemm_sk_*.txt).  What
+// keeps the lock step is changing the tile HEIGHT: the leading rows run as 256-row tiles in a whole number of rounds, the
+// rest as tiles of 32 * mi rows chosen so that they fill (at most) one more round -- two launches, same kernel family.
+//   cost(launch) = rounds * (kTileFixed + 32 * mi) [row-units]: a tile's time is its rows plus a fixed part (pipeline ramp,
+//   epilogue, W panel traffic that does not shrink with the height); fitted on tools/gemm_tile_ab.py.
+struct TilePlan { int64_t rows1; int mi2; };          // rows1 rows as 256-row tiles (may be 0 or M), the rest with mi2
+constexpr int kTileFixed = 40;
+inline double plan_cost(int64_t rows, int mi, int tiles_n, int cus) {
+    if (rows <= 0) return 0.0;
+    const int64_t bm = 32 * mi;
+    const int64_t tiles = ((rows + bm - 1) / bm) * tiles_n;
+    return (double)((tiles + cus - 1) / cus) * (double)(kTileFixed + bm) + 6.0;       // + a launch boundary
+}
+inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus) {
+    const int forced = fino_tune_get(FINO_TUNE_GEMM_TILE_M);          // A/B: 1..7 -> one launch of that height; 8 -> 256 only
+    if (forced >= 2 && forced <= 7) return TilePlan{0, forced};
+    TilePlan best{m, 8};
+    if (forced == 8) return best;
+    double best_c = plan_cost(m, 8, tiles_n, cus);
+    const int64_t rows256 = (m + 255) / 256;
+    for (int64_t r1 = 0; r1 <= rows256; ++r1) {
+        const int64_t rows1 = r1 * 256 < m ? r1 * 256 : m;
+        const double c1 = plan_cost(rows1, 8, tiles_n, cus);
+        if (rows1 == m) continue;
+        for (int mi = 2; mi <= 8; ++mi) {
+            const double c = c1 + plan_cost(m - rows1, mi, tiles_n, cus);
+            if (c < best_c - 1e-9) { best_c = c; best = TilePlan{rows1, mi}; }
+        }
+    }
+    return best;
 }
 
 inline bool use_pingpong() {
@@ -702,26 +611,46 @@ inline bool use_pingpong() {
     return v == 1;
 }
 
+template <typename T, int EPI>
+int launch_gemm_pp_mi(const GemmParams& p, int mi, hipStream_t st) {
+    switch (mi) {
+        case 2: return launch_gemm_pp<T, EPI, false, 2>(p, st);
+        case 3: return launch_gemm_pp<T, EPI, false, 3>(p, st);
+        case 4: return launch_gemm_pp<T, EPI, false, 4>(p, st);
+        case 5: return launch_gemm_pp<T, EPI, false, 5>(p, st);
+        case 6: return launch_gemm_pp<T, EPI, false, 6>(p, st);
+        case 7: return launch_gemm_pp<T, EPI, false, 7>(p, st);
+        default: return launch_gemm_pp<T, EPI, false, 8>(p, st);
+    }
+}
+
+// rows [r0, r0 + rows) of the GEMM as one launch of 32 * mi-row tiles
+template <typename T>
+int launch_gemm_rows(GemmParams p, int64_t r0, int64_t rows, int mi, int epi, hipStream_t st) {
+    p.a += r0 * p.lda;
+    p.c += r0 * p.ldc;
+    if (p.r) p.r += r0 * p.ldr;
+    if (p.sel) p.sel += r0;
+    p.m = rows;
+    p.tiles_m = (int)((rows + 32 * mi - 1) / (32 * mi));
+    switch (epi) {
+        case FINO_EPI_NONE: return launch_gemm_pp_mi<T, FINO_EPI_NONE>(p, mi, st);
+        case FINO_EPI_GELU_TANH: return launch_gemm_pp_mi<T, FINO_EPI_GELU_TANH>(p, mi, st);
+        case FINO_EPI_RESIDUAL: return launch_gemm_pp_mi<T, FINO_EPI_RESIDUAL>(p, mi, st);
+        case FINO_EPI_GATED_RESIDUAL_STAGED: return launch_gemm_pp_mi<T, FINO_EPI_GATED_RESIDUAL_STAGED>(p, mi, st);
+        default: return launch_gemm_pp_mi<T, FINO_EPI_GATED_RESIDUAL>(p, mi, st);
+    }
+}
+
 template <typename T, bool GENERIC>
 int launch_gemm_e(const GemmParams& p, int epi, hipStream_t st) {
     const bool fits32 = ((p.m - 1) * p.lda + p.k) * 2 < (1ll << 31) && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
-    if (!GENERIC && use_pingpong() && fits32 && p.sk_rem > 0) {
-        switch (epi) {
-            case FINO_EPI_NONE: return launch_gemm_sk<T, FINO_EPI_NONE>(p, st);
-            case FINO_EPI_GELU_TANH: return launch_gemm_sk<T, FINO_EPI_GELU_TANH>(p, st);
-            case FINO_EPI_RESIDUAL: return launch_gemm_sk<T, FINO_EPI_RESIDUAL>(p, st);
-            case FINO_EPI_GATED_RESIDUAL_STAGED: return launch_gemm_sk<T, FINO_EPI_GATED_RESIDUAL_STAGED>(p, st);
-            default: return launch_gemm_sk<T, FINO_EPI_GATED_RESIDUAL>(p, st);
-        }
-    }
     if (!GENERIC && use_pingpong() && fits32) {
-        switch (epi) {
-            case FINO_EPI_NONE: return launch_gemm_pp<T, FINO_EPI_NONE>(p, st);
-            case FINO_EPI_GELU_TANH: return launch_gemm_pp<T, FINO_EPI_GELU_TANH>(p, st);
-            case FINO_EPI_RESIDUAL: return launch_gemm_pp<T, FINO_EPI_RESIDUAL>(p, st);
-            case FINO_EPI_GATED_RESIDUAL_STAGED: return launch_gemm_pp<T, FINO_EPI_GATED_RESIDUAL_STAGED>(p, st);
-            default: return launch_gemm_pp<T, FINO_EPI_GATED_RESIDUAL>(p, st);
-        }
+        const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus());
+        if (tp.rows1 > 0)
+            if (int rc = launch_gemm_rows<T>(p, 0, tp.rows1, 8, epi, st)) return rc;
+        if (tp.rows1 < p.m) return launch_gemm_rows<T>(p, tp.rows1, p.m - tp.rows1, tp.mi2, epi, st);
+        return FINO_OK;
     }
     switch (epi) {
         case FINO_EPI_NONE: return launch_gemm_t<T, FINO_EPI_NONE, GENERIC>(p, st);
@@ -774,24 +703,17 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int64_t fino_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-    if (m <= 0 || n <= 0 || k <= 0 || k % BK != 0) return 0;
-    const int tiles = (int)((m + BM - 1) / BM) * (int)((n + BN - 1) / BN);
-    const SkPlan sp = plan_stream_k(tiles, (int)(k / BK), gemm_device_cus());
-    return sp.rem > 0 ? kSkFlagBytes + (int64_t)sp.nwg * kSkPartialBytes : 0;
+extern "C" int fino_gemm_plan(int64_t m, int64_t n, int64_t* rows_256, int* tile_rows_rest) {
+    if (m <= 0 || n <= 0) return FINO_ERR_ARG;
+    const TilePlan tp = plan_tiles(m, (int)((n + BN - 1) / BN), gemm_device_cus());
+    if (rows_256) *rows_256 = tp.rows1;
+    if (tile_rows_rest) *tile_rows_rest = tp.rows1 < m ? 32 * tp.mi2 : 0;
+    return FINO_OK;
 }
 
 extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
                          int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
                          const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream) {
-    return fino_gemm_ws(a, w, bias, c, m, n, k, lda, ldw, ldc, epilogue, r, ldr, gate, mod_stride, sel, dtype, nullptr, 0,
-                        stream);
-}
-
-extern "C" int fino_gemm_ws(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
-                            int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
-                            const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* workspace,
-                            int64_t workspace_bytes, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm: dtype %d", dtype);
     FINO_CHECK(a && w && c, FINO_ERR_ARG, "fino_gemm: null pointer");
     FINO_CHECK(m >= 0 && n > 0 && k > 0, FINO_ERR_ARG, "fino_gemm: bad shape M=%lld N=%lld K=%lld", (long long)m,
@@ -816,21 +738,9 @@ extern "C" int fino_gemm_ws(const void* a, const void* w, const void* bias, void
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
     p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
-    if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
     hipStream_t st = (hipStream_t)stream;
     const bool generic = (k % BK) != 0;
-    if (workspace && !generic) {
-        FINO_CHECK(fino_aligned16(workspace), FINO_ERR_ARG, "fino_gemm_ws: workspace must be 16-byte aligned");
-        const SkPlan sp = plan_stream_k(p.tiles_m * p.tiles_n, (int)(k / BK), gemm_device_cus());
-        if (sp.rem > 0) {
-            const int64_t need = kSkFlagBytes + (int64_t)sp.nwg * kSkPartialBytes;
-            FINO_CHECK(workspace_bytes >= need, FINO_ERR_ARG, "fino_gemm_ws: workspace %lld B < %lld B",
-                       (long long)workspace_bytes, (long long)need);
-            p.sk_full = sp.full; p.sk_rem = sp.rem; p.sk_nwg = sp.nwg;
-            p.sk_flags = (int*)workspace;
-            p.sk_ws = (float*)((char*)workspace + kSkFlagBytes);
-        }
-    }
+    if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
     if (dtype == FINO_BF16)
         return generic ? launch_gemm_e<BF16, true>(p, epilogue, st) : launch_gemm_e<BF16, false>(p, epilogue, st);
     return generic ? launch_gemm_e<F16, true>(p, epilogue, st) : launch_gemm_e<F16, false>(p, epilogue, st);

@@ -22,13 +22,6 @@ struct GemmParams {
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
     int group_m;                     // tile rows per raster group (tile_coords); 0 = default
-    // stream-K (gemm_sk_kernel, one launch): the first sk_full tiles of the raster run whole (one block each), the
-    // K-tile units of the last sk_rem tiles are dealt to sk_nwg more blocks in equal contiguous ranges; a range's leading
-    // piece that does not start a tile leaves its fp32 accumulators in sk_ws (slot = range index, [32][512] x 16 B) and
-    // raises sk_flags[32 * range]; the block that holds a tile's FIRST K-tiles adds them and runs the epilogue
-    int sk_full, sk_rem, sk_nwg;
-    float* sk_ws;
-    int* sk_flags;
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents
@@ -113,19 +106,20 @@ __device__ __forceinline__ void tile_raster(const GemmParams& p, int id, int& tm
     tn = in_group / gsz;
 }
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
-    // (with a stream-K tail the grid holds only the sk_full leading tiles of the raster)
-    tile_raster(p, xcd_remap((int)blockIdx.x, p.sk_rem > 0 ? p.sk_full : p.tiles_m * p.tiles_n), tm, tn);
+    tile_raster(p, xcd_remap((int)blockIdx.x, p.tiles_m * p.tiles_n), tm, tn);
 }
 
 // Shared by both main-loop variants.  Every wave must be past its last LDS operand read (barrier) before the call.
-template <typename T, int EPI, bool QOUT = false>
-__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[8][4], const GemmParams& p, char* smem, int64_t m0,
+// MI = 16-row fragments per wave: the tile is 32 * MI rows high (256 by default; fino_gemm.hip picks lower tiles for row
+// counts that 256-row tiles would spread badly over the CUs)
+template <typename T, int EPI, bool QOUT = false, int MI = 8>
+__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmParams& p, char* smem, int64_t m0,
                                               int64_t n0, int tid, int lane, int wm, int wn) {
     // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
-    // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*128 + i*16 + (lane&15)
+    // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*16*MI + i*16 + (lane&15)
     constexpr bool kHasRes =
         EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED;
-    constexpr int kIters = (BM * BN / 8) / kThreads;      // 16 row-chunks of 16 bytes per thread
+    constexpr int kIters = (32 * MI * BN / 8) / kThreads;      // 2 * MI row-chunks of 16 bytes per thread (16 at 256 rows)
     // The residual tile is this epilogue's only long-latency input and depends on nothing computed here: all 16 loads
     // per thread go out FIRST and fly under the accumulator conversion + LDS staging (every CU reaches its epilogue
     // at about the same time, so these reads are an HBM burst: 4 in flight per thread measured ~24 us per round of
@@ -155,8 +149,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[8][4], const GemmPa
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wm * 128 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * (16 * MI) + i * 16 + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float y[4];

@@ -235,19 +235,12 @@ def attention_merge(parts, batch, lq, heads, head_dim, dtype, out=None):
     return out
 
 
-_gemm_ws = {}      # (device index, stream) -> stream-K workspace (caller-owned per the C ABI; grown on demand; its flag area
-                   # must start out zero and every launch leaves it zero: allocated with zeros)
-
-
-def _gemm_workspace(m, n, k, device):
-    need = _lib.lib().fino_gemm_workspace_bytes(m, n, k)
-    if need <= 0:
-        return None, 0
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _gemm_ws.get(key)
-    if ws is None or ws.numel() * 4 < need:
-        ws = _gemm_ws[key] = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
-    return ws, need
+def gemm_plan(m, n):
+    """(rows run as 256-row tiles, tile height of the remaining rows or 0) -- fino_gemm's tiling on this device"""
+    import ctypes
+    r, t = ctypes.c_int64(), ctypes.c_int()
+    _lib.check(_lib.lib().fino_gemm_plan(m, n, ctypes.byref(r), ctypes.byref(t)), "fino_gemm_plan")
+    return r.value, t.value
 
 
 def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None):
@@ -265,9 +258,8 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     if bias is not None:
         assert bias.dtype == a.dtype and bias.is_contiguous()
     ev = _timed("gemm")
-    ws, ws_bytes = _gemm_workspace(m, n, k, a.device)
-    _lib.check(_lib.lib().fino_gemm_ws(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
-                                      ldr, _p(gate), ms, _p(sel), _dt(a), _p(ws), ws_bytes, _stream()), "fino_gemm_ws")
+    _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
+                                   ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
     if ev is not None:
         ev.record()
         KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k

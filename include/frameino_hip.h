@@ -40,9 +40,9 @@ const char* fino_last_error(void);
 /* Tuning knobs for A/B timing of kernel variants inside one process (tools/): results never depend on them.
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
  * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
- * ping-pong one.  FINO_TUNE_GEMM_STREAM_K: 1 = never use stream-K in fino_gemm_ws, 2 = whenever legal.
+ * ping-pong one.  FINO_TUNE_GEMM_TILE_M: 2 .. 7 = one launch of 32 x that many rows per tile, 8 = 256-row tiles only (the round-2 behaviour).
  * FINO_TUNE_ATTN_KERNEL (head_dim 128): 2 = the 4-wave one-wave-per-SIMD kernel instead of the 8-wave ping-pong one. */
-enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_STREAM_K = 3,
+enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_TILE_M = 3,
        FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);
 int fino_tune_get(int key);
@@ -161,21 +161,13 @@ enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EP
 int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
               int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
-/* fino_gemm with a caller-owned workspace of fino_gemm_workspace_bytes(M, N, K) bytes (0 = not needed) for stream-K:
- * when the last round of 256x256 tiles would leave CUs idle for more than ~10 K-tiles of work (or the GEMM has fewer tiles
- * than CUs: the token-shard shapes), the K-tile units of the last one-to-two rounds' tiles are dealt to all CUs in equal
- * contiguous ranges inside the SAME launch; a range's piece that does not start its tile is handed to the block that does
- * through the workspace (fp32, write-through stores behind a flag), which adds it and runs the epilogue.  Same results up
- * to fp32 summation order in the split tiles, deterministic for a given shape.  Workspace contract: 16-byte aligned, its
- * first 64 KiB (the flags) ZERO before the first launch that uses it -- every launch leaves them zero again -- and not
- * shared by launches that may run concurrently (one workspace per stream). */
-int64_t fino_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
-int fino_gemm_ws(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k, int64_t lda,
-                 int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
-                 int64_t mod_stride, const int32_t* sel, int dtype, void* workspace, int64_t workspace_bytes,
-                 void* stream);
-
-
+/* The tiling fino_gemm uses for an M x N problem on the current device: `rows_256` leading rows run as 256 x 256 tiles
+ * (a whole number of rounds of the CUs), the remaining rows as ONE more launch of `tile_rows_rest`-row tiles (64 .. 256
+ * in steps of 32; 0 = no second launch) chosen so that they fit (at most) one more round: 3080 rows x 3072 columns are
+ * 240 tiles of 160 rows in one round instead of 156 tiles of 256 on 256 CUs; 24640 x 3072 are 4 rounds of 256-row tiles
+ * + 216 tiles of 160 rows instead of 4.55 rounds paid as 5.  Results do not depend on the tiling (every output element is
+ * one fp32 dot product over K in the same order).  Diagnostics / tests. */
+int fino_gemm_plan(int64_t m, int64_t n, int64_t* rows_256, int* tile_rows_rest);
 /* Skinny fp32-accurate linear for the conditioning MLPs (M <= 16 rows):
  * y[m,n] = act( sum_k x[m,k] w[n,k] + b[n] ), x/y fp32, w/b fp32 (w_dtype=-1) or T; act: 0 none, 1 SiLU on the INPUT
  * (y = W.silu(x) + b).  transformer_wan.py:175-183 (time_embedder kept fp32 by :393, time_proj). */

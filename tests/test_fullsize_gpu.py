@@ -191,37 +191,3 @@ def test_vae_decode_full_size_chunked_tail_equals_whole_sequence():
     assert torch.equal(whole, chunked)
     print(f"peak activation memory: whole {peak_whole / 2**30:.1f} GiB, chunked {peak_chunked / 2**30:.1f} GiB")
     assert peak_chunked < 0.7 * peak_whole
-
-
-@pytest.mark.parametrize("m,force", [(L, 0), (2 * L, 2)], ids=["B1-default-policy", "B2-forced"])
-def test_gemm_stream_k_tail_full_size(m, force):
-    """FFN-down (N = 3072, K = 14336): with a caller-owned workspace the partial last round of tiles is run stream-K
-    (by default when it fills <= 40 % of the CUs: M = 12320 -> 76 tail tiles; forced here for M = 24640 -> 141).
-    Sampled rows against fp32, and against the whole-tile path: only the fp32 summation order of the split tiles may
-    differ."""
-    from frameino_amd import _lib, ops
-    from tests.test_kernels_gpu import gemm_ref
-    lib = _lib.lib()
-    n, k, epi = D, FF, 3
-    g = torch.Generator(device=DEV).manual_seed(8)
-    a = torch.randn(m, k, device=DEV, generator=g).bfloat16()
-    w = (torch.randn(n, k, device=DEV, generator=g) * 0.02).bfloat16()
-    bias = torch.randn(n, device=DEV, generator=g).bfloat16()
-    res = torch.randn(m, n, device=DEV, generator=g).bfloat16()
-    gate = torch.randn(2, n, device=DEV, generator=g)
-    sel = (torch.arange(m, device=DEV) % L >= 880).to(torch.int32)
-    try:
-        lib.fino_tune_set(3, force)
-        assert lib.fino_gemm_workspace_bytes(m, n, k) > 0
-        out = ops.gemm(a, w, bias, epi, res, gate, sel)
-        lib.fino_tune_set(3, 1)
-        assert lib.fino_gemm_workspace_bytes(m, n, k) == 0
-        whole = ops.gemm(a, w, bias, epi, res, gate, sel)
-    finally:
-        lib.fino_tune_set(3, 0)
-    assert torch.isfinite(out.float()).all()
-    rows = torch.tensor(sorted({0, 255, m - 1, m - 2, m - 257, m - 300} | set(torch.randint(0, m, (40,)).tolist()) |
-                               set(torch.randint(m - 3000, m, (24,)).tolist())), device=DEV)       # the tail tiles are last
-    ref = gemm_ref(a[rows], w, bias, epi, res[rows], gate, sel[rows])
-    assert rel_rms(out[rows], ref.float()) < 2.0 ** -7
-    assert rel_rms(out, whole.float()) < 2.0 ** -9 and not torch.equal(out, whole)      # it did take the other path

@@ -1,0 +1,117 @@
+"""Tile heights of fino_gemm (csrc/fino_gemm.hip: gemm_pp_kernel<..., MI>, plan_tiles): the leading rows run as 256 x 256
+tiles in whole rounds of the CUs, the rest as ONE more launch of 64 .. 256-row tiles that fits one more round -- 3080 rows
+(a 4-way token shard) are 240 tiles of 160 rows instead of 156 of 256 on 256 CUs.
+
+Every output element is one fp32 dot product over K in the same order whatever the tile height, so every tiling must give
+BIT-IDENTICAL results: checked for every forced height against the 256-row path, on all elements, for every epilogue,
+ragged M / N, the token-shard and one-GPU row counts; plus the fp32 reference, the planner's choices, and the two-launch
+form (rows_256 > 0 and a remainder) through strided views and an in-place residual."""
+import pytest
+import torch
+
+from tests.parity import rel_rms
+from tests.test_kernels_gpu import gemm_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D, FF = 3072, 14336
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from frameino_amd import _lib
+    return _lib.lib()
+
+
+def _operands(m, n, k, epi, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = torch.randn(m, k, device=DEV, generator=g).to(dtype)
+    w = (torch.randn(n, k, device=DEV, generator=g) * k ** -0.5).to(dtype)
+    bias = torch.randn(n, device=DEV, generator=g).to(dtype)
+    res = torch.randn(m, n, device=DEV, generator=g).to(dtype) if epi >= 2 else None
+    gate = torch.randn(2, n, device=DEV, generator=g) if epi >= 3 else None
+    sel = (torch.arange(m, device=DEV) % 5 == 0).to(torch.int32) if epi >= 3 else None
+    return a, w, bias, res, gate, sel
+
+
+def _run(lib, ops_, epi, force):
+    from frameino_amd import ops
+    a, w, bias, res, gate, sel = ops_
+    try:
+        lib.fino_tune_set(3, force)
+        return ops.gemm(a, w, bias, epi, res, gate, sel)
+    finally:
+        lib.fino_tune_set(3, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(700, 512, 1024), (300, 256, 192), (257, 264, 512), (2000, 768, 576), (63, 3072, 128),
+                                   (1, 256, 64), (1540, 3072, 3072)])
+def test_every_tile_height_is_bit_identical_to_the_256_row_path(lib, dtype, m, n, k):
+    for epi in (0, 1, 2, 3, 4):
+        ops_ = _operands(m, n, k, epi, seed=epi, dtype=dtype)
+        base = _run(lib, ops_, epi, 8)
+        ref = gemm_ref(*ops_[:3], epi, *ops_[3:])
+        assert rel_rms(base, ref.float()) < (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+        for mi in (2, 3, 4, 5, 6, 7):
+            out = _run(lib, ops_, epi, mi)
+            assert torch.equal(out, base), f"tile height {32 * mi}, epilogue {epi}: differs from the 256-row tiles"
+        assert torch.equal(_run(lib, ops_, epi, 0), base)          # and so does whatever the planner picks
+
+
+@pytest.mark.parametrize("m", [1540, 3080, 6160, 12320, 24640], ids=lambda m: f"rows{m}")
+@pytest.mark.parametrize("n,k,epi", [(D, D, 3), (3 * D, D, 0), (FF, D, 1), (D, FF, 3)], ids=["out", "qkv", "ffn_up", "ffn_down"])
+def test_planned_tiling_at_the_model_shapes(lib, m, n, k, epi):
+    """the block GEMMs of a Wan2.2-5B layer at the one-GPU row counts and the 2- / 4- / 8-way token-shard ones: the planned
+    tiling (possibly two launches) == 256-row tiles, bit for bit, and sampled rows against fp32"""
+    ops_ = _operands(m, n, k, epi, seed=1)
+    planned, base = _run(lib, ops_, epi, 0), _run(lib, ops_, epi, 8)
+    assert torch.equal(planned, base)
+    rows = torch.tensor(sorted({0, 255, 256, m - 1, m - 33, m - 257} | set(torch.randint(0, m, (64,)).tolist())), device=DEV)
+    a, w, bias, res, gate, sel = ops_
+    ref = gemm_ref(a[rows], w, bias, epi, None if res is None else res[rows], gate, None if sel is None else sel[rows])
+    assert rel_rms(planned[rows], ref.float()) < 2.0 ** -7
+
+
+def test_the_planner_fills_rounds(lib):
+    from frameino_amd import ops
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def rounds(m, n):
+        r256, rest = ops.gemm_plan(m, n)
+        tn = -(-n // 256)
+        t1 = (r256 // 256) * tn
+        t2 = -(-(m - r256) // rest) * tn if rest else 0
+        return r256, rest, t1, t2
+
+    # a 4-way shard on 12 tile columns: one launch of 160-row tiles, all of them in one round
+    r256, rest, t1, t2 = rounds(3080, D)
+    assert r256 == 0 and rest and t2 <= cus and rest < 256
+    # both CFG branches on one GPU: whole rounds of 256-row tiles, then one partial round of lower tiles
+    r256, rest, t1, t2 = rounds(24640, D)
+    assert r256 > 0 and t1 % cus <= 12 and 0 < t2 <= cus + 12 and rest < 256
+    # a whole number of rounds stays as it is
+    assert ops.gemm_plan(256 * 16, 256 * 16) == (256 * 16, 0)
+    # the plan never covers fewer rows than there are
+    for m in (1, 255, 256, 257, 1540, 12320, 19126 * 2):
+        for n in (192, 3072, 9216, 14336):
+            r256, rest = ops.gemm_plan(m, n)
+            assert 0 <= r256 <= m and r256 % 256 == 0 or r256 == m
+            assert (rest == 0) == (r256 == m) and rest % 32 == 0 and rest <= 256
+
+
+def test_two_launch_form_on_strided_views_with_an_in_place_residual(lib):
+    """rows_256 > 0 and a remainder: the second launch starts at a row offset of A, C, R and the selector"""
+    from frameino_amd import ops
+    m, d = 24640 // 4 + 70, 512
+    r256, rest = ops.gemm_plan(m, d)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    big = torch.randn(m, 3 * d, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(d, d, device=DEV, generator=g) * 0.05).bfloat16()
+    x = torch.randn(m, d, device=DEV, generator=g).bfloat16()
+    gate = torch.randn(2, d, device=DEV, generator=g)
+    sel = (torch.arange(m, device=DEV) % 3 == 0).to(torch.int32)
+    ref = gemm_ref(big[:, d:2 * d], w, None, 3, x.clone(), gate, sel)
+    ops.gemm(big[:, d:2 * d], w, None, 3, residual=x, gate=gate, sel=sel, out=x)      # C aliases R, A is a column slice
+    assert rel_rms(x, ref.float()) < 2.0 ** -7
+    print(f"plan for {m} x {d}: {r256} rows of 256-row tiles + {rest}-row tiles")

@@ -13,3 +13,16 @@ requirements.txt:12) -- parity for those third-party pieces is therefore "unpinn
 VAE) runs from the reference's own source.
 """
 __version__ = "0.35.0.stub"
+
+
+def __getattr__(name):
+    """`from diffusers import AutoencoderKLCogVideoX, CogVideoXDPMScheduler` (train_code/train_cogvideox_motion_FrameINO.py
+    :45-48, imported by the reference's CogVideoX pipeline at call time)"""
+    if name == "AutoencoderKLCogVideoX":
+        from .models import AutoencoderKLCogVideoX
+        return AutoencoderKLCogVideoX
+    if name in ("CogVideoXDPMScheduler", "CogVideoXDDIMScheduler", "FlowMatchEulerDiscreteScheduler",
+                "UniPCMultistepScheduler"):
+        from . import schedulers
+        return getattr(schedulers, name)
+    raise AttributeError(name)

@@ -111,6 +111,29 @@ class CogVideoXDDIMScheduler(ConfigMixin):
         return (prev, pred_x0)
 
 
+class CogVideoXDPMScheduler(CogVideoXDDIMScheduler):
+    """Stand-in for diffusers.CogVideoXDPMScheduler (third-party, restated: the arithmetic is the builder's ONE
+    restatement, /root/repo/oracle/schedulers.py::CogDPMOracle -- get_variables / get_mult / step of the published
+    SDE-DPM-Solver++(2M) form; UNPINNED).  Interface of the reference's call site
+    (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:915-926)."""
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, eta=0.0,
+             use_clipped_model_output=False, generator=None, variance_noise=None, return_dict=False):
+        import os
+        import sys
+        repo = os.path.abspath(os.path.join(os.path.dirname(__file__), *[".."] * 5))
+        if repo not in sys.path:
+            sys.path.append(repo)
+        from oracle.schedulers import CogDPMOracle
+        o = getattr(self, "_oracle", None)
+        if o is None or o.n != self.num_inference_steps:
+            o = self._oracle = CogDPMOracle(self.config.num_train_timesteps, self.config.beta_start, self.config.beta_end,
+                                            self.config.snr_shift_scale)
+            o.set_timesteps(self.num_inference_steps)
+        tb = None if timestep_back is None else int(timestep_back)
+        return o.step(model_output, old_pred_original_sample, int(timestep), tb, sample, generator=generator)
+
+
 class UniPCMultistepScheduler(ConfigMixin):
     """Stand-in for diffusers.UniPCMultistepScheduler as Wan-AI/Wan2.2-TI2V-5B-Diffusers configures it (third-party,
     restated tensor-op by tensor-op from the published algorithm: flow sigmas, flow_prediction, predict_x0, bh2,

@@ -41,3 +41,10 @@ def replace_example_docstring(doc):
 
 def is_ftfy_available():
     return False
+
+
+def __getattr__(name):      # names only the reference's training script imports (never called on the denoising path)
+    if name.startswith("__"):
+        raise AttributeError(name)
+    from .._inert import Inert
+    return Inert
