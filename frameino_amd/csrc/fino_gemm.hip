@@ -566,39 +566,59 @@ inline int gemm_device_cus() {
 }
 
 // ---- tile-height plan: which rows run as 256-row tiles, which as lower ones ------------------------------------------
-// Every tile of a launch lasts the same time, so a launch costs ceil(tiles / CUs) ROUNDS whatever the last round holds:
-// 1164 tiles (M = 24640, N = 3072) are 4.55 rounds paid as 5; the 156 tiles of a 3080-row token shard keep 100 of the 256
-// CUs idle for the whole GEMM.  Dealing the K-tiles of that last round to all CUs (stream-K) was built and measured in
-// round 3 and loses even with a free hand-off: blocks that start at different K offsets no longer walk K in lock step, and
-// the A / W panels that concurrent tiles share in L2 at every step stop being shared (profiles/r03_gemm_sk_*.txt).  What
-// keeps the lock step is changing the tile HEIGHT: the leading rows run as 256-row tiles in a whole number of rounds, the
-// rest as tiles of 32 * mi rows chosen so that they fill (at most) one more round -- two launches, same kernel family.
-//   cost(launch) = rounds * (kTileFixed + 32 * mi) [row-units]: a tile's time is its rows plus a fixed part (pipeline ramp,
-//   epilogue, W panel traffic that does not shrink with the height); fitted on tools/gemm_tile_ab.py.
+// Every tile of a launch lasts the same time, so a launch costs its ROUNDS of the CUs whatever the last round holds: the 156
+// tiles of a 3080-row token shard (N = 3072) keep 100 of 256 CUs idle for the whole GEMM, 1164 tiles (M = 24640) are 4.55
+// rounds.  Measured in round 3 (profiles/r03_gemm_tiles.md):
+//   * dealing the K-tiles of the last round to all CUs (stream-K, one launch, write-through hand-off) LOSES even with the
+//     hand-off compiled out: blocks that start at different K offsets stop walking K in lock step, and the A / W panels
+//     that concurrent tiles share in L2 at every step stop being shared -- the 256 x 256 x 64 step sits right at what
+//     the L2 -> LDS path delivers per CU (~28 B / clock: 64 KB in ~2300 cycles against 2048 cycles of MFMA).
+//   * what keeps the lock step is the tile HEIGHT.  A full round of (32 mi)-row tiles lasts ~(32 mi + 256) / 512 of a
+//     256-row round (operand delivery: every tile streams its whole W panel whatever its height), a tile alone on its CU
+//     32 mi / 256 of one (MFMA), and a round of n <= CUs tiles max(MFMA, delivery * n / CUs).
+// The plan: leading rows as 256-row tiles, the rest as ONE more launch of lower tiles (two launches of the same kernel
+// family, results bit-identical to any other tiling: one fp32 dot product per element in the same K order), whichever
+// (rows1, height) minimises that model; FINO_TUNE_GEMM_PLAN = 1 minimises the WORK instead (256-row tiles + the lowest
+// tile row that covers the remainder): what a rank wants when another stream's kernels fill the CUs it leaves idle
+// (the interleaved multi-GPU plan).
 struct TilePlan { int64_t rows1; int mi2; };          // rows1 rows as 256-row tiles (may be 0 or M), the rest with mi2
-constexpr int kTileFixed = 40;
-inline double plan_cost(int64_t rows, int mi, int tiles_n, int cus) {
+inline double plan_launch_cost(int64_t rows, int mi, int tiles_n, int cus) {
     if (rows <= 0) return 0.0;
-    const int64_t bm = 32 * mi;
-    const int64_t tiles = ((rows + bm - 1) / bm) * tiles_n;
-    return (double)((tiles + cus - 1) / cus) * (double)(kTileFixed + bm) + 6.0;       // + a launch boundary
+    const double bm = 32.0 * mi;
+    const int64_t tiles = ((rows + 32 * mi - 1) / (32 * mi)) * tiles_n;
+    const double mfma = 0.85 * bm / 256.0, deliver = (bm + 256.0) / 512.0;      // in 256-row full rounds
+    const int64_t full = tiles / cus, rem = tiles % cus;
+    double c = (double)full * (mfma > deliver ? mfma : deliver);
+    if (rem) {
+        const double d = deliver * (double)rem / cus;
+        c += mfma > d ? mfma : d;
+    }
+    return c + 0.07;                                                             // a launch: ~5 us of a 74-us round
 }
 inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus) {
-    const int forced = fino_tune_get(FINO_TUNE_GEMM_TILE_M);          // A/B: 1..7 -> one launch of that height; 8 -> 256 only
+    const int forced = fino_tune_get(FINO_TUNE_GEMM_TILE_M);          // A/B: 2..7 -> one launch of that height; 8 -> 256 only
     if (forced >= 2 && forced <= 7) return TilePlan{0, forced};
     TilePlan best{m, 8};
-    if (forced == 8) return best;
-    double best_c = plan_cost(m, 8, tiles_n, cus);
+    if (forced == 8 || m <= 0) return best;
+    if (fino_tune_get(FINO_TUNE_GEMM_PLAN) == 1) {                     // least work: whole 256-row tile rows + one low row
+        const int64_t rows1 = (m / 256) * 256, rem = m - rows1;
+        if (rem == 0) return best;
+        int mi = (int)((rem + 31) / 32);
+        return TilePlan{rows1, mi < 2 ? 2 : mi};
+    }
+    double best_c = plan_launch_cost(m, 8, tiles_n, cus);
+    const double base_c = best_c;
     const int64_t rows256 = (m + 255) / 256;
-    for (int64_t r1 = 0; r1 <= rows256; ++r1) {
-        const int64_t rows1 = r1 * 256 < m ? r1 * 256 : m;
-        const double c1 = plan_cost(rows1, 8, tiles_n, cus);
-        if (rows1 == m) continue;
+    for (int64_t r1 = 0; r1 < rows256; ++r1) {
+        const int64_t rows1 = r1 * 256;
+        const double c1 = plan_launch_cost(rows1, 8, tiles_n, cus);
         for (int mi = 2; mi <= 8; ++mi) {
-            const double c = c1 + plan_cost(m - rows1, mi, tiles_n, cus);
+            if (rows1 > 0 && mi == 8) continue;
+            const double c = c1 + plan_launch_cost(m - rows1, mi, tiles_n, cus);
             if (c < best_c - 1e-9) { best_c = c; best = TilePlan{rows1, mi}; }
         }
     }
+    if (best_c > 0.985 * base_c) return TilePlan{m, 8};               // not worth a second launch / another code path
     return best;
 }
 

@@ -57,6 +57,11 @@ def test_every_tile_height_is_bit_identical_to_the_256_row_path(lib, dtype, m, n
             out = _run(lib, ops_, epi, mi)
             assert torch.equal(out, base), f"tile height {32 * mi}, epilogue {epi}: differs from the 256-row tiles"
         assert torch.equal(_run(lib, ops_, epi, 0), base)          # and so does whatever the planner picks
+        try:
+            lib.fino_tune_set(5, 1)                                   # ... in the least-work mode too
+            assert torch.equal(_run(lib, ops_, epi, 0), base)
+        finally:
+            lib.fino_tune_set(5, 0)
 
 
 @pytest.mark.parametrize("m", [1540, 3080, 6160, 12320, 24640], ids=lambda m: f"rows{m}")
@@ -73,31 +78,30 @@ def test_planned_tiling_at_the_model_shapes(lib, m, n, k, epi):
     assert rel_rms(planned[rows], ref.float()) < 2.0 ** -7
 
 
-def test_the_planner_fills_rounds(lib):
+def test_the_planner(lib):
     from frameino_amd import ops
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-
-    def rounds(m, n):
-        r256, rest = ops.gemm_plan(m, n)
-        tn = -(-n // 256)
-        t1 = (r256 // 256) * tn
-        t2 = -(-(m - r256) // rest) * tn if rest else 0
-        return r256, rest, t1, t2
-
-    # a 4-way shard on 12 tile columns: one launch of 160-row tiles, all of them in one round
-    r256, rest, t1, t2 = rounds(3080, D)
-    assert r256 == 0 and rest and t2 <= cus and rest < 256
-    # both CFG branches on one GPU: whole rounds of 256-row tiles, then one partial round of lower tiles
-    r256, rest, t1, t2 = rounds(24640, D)
-    assert r256 > 0 and t1 % cus <= 12 and 0 < t2 <= cus + 12 and rest < 256
+    # a 4-way token shard on 12 tile columns: 156 tiles of 256 rows would leave 100 CUs idle -> lower tiles, one launch
+    r256, rest = ops.gemm_plan(3080, D)
+    assert r256 == 0 and 64 <= rest < 256 and -(-3080 // rest) * 12 <= cus
+    # an 8-way shard: 84 tiles -> lower tiles
+    r256, rest = ops.gemm_plan(1540, D)
+    assert r256 == 0 and 64 <= rest < 256
     # a whole number of rounds stays as it is
     assert ops.gemm_plan(256 * 16, 256 * 16) == (256 * 16, 0)
-    # the plan never covers fewer rows than there are
-    for m in (1, 255, 256, 257, 1540, 12320, 19126 * 2):
+    # the plan covers exactly the rows there are, in legal heights
+    for m in (1, 255, 256, 257, 1540, 12320, 24640, 19126 * 2):
         for n in (192, 3072, 9216, 14336):
             r256, rest = ops.gemm_plan(m, n)
-            assert 0 <= r256 <= m and r256 % 256 == 0 or r256 == m
+            assert 0 <= r256 <= m and (r256 % 256 == 0 or r256 == m)
             assert (rest == 0) == (r256 == m) and rest % 32 == 0 and rest <= 256
+    # least-work mode: whole 256-row tile rows + the lowest row of tiles that covers the remainder
+    try:
+        lib.fino_tune_set(5, 1)
+        assert ops.gemm_plan(3080, D) == (3072, 64) and ops.gemm_plan(1540, D) == (1536, 64)
+        assert ops.gemm_plan(12320, D) == (12288, 64) and ops.gemm_plan(12288 + 100, D) == (12288, 128)
+    finally:
+        lib.fino_tune_set(5, 0)
 
 
 def test_two_launch_form_on_strided_views_with_an_in_place_residual(lib):

@@ -336,7 +336,7 @@ class _PlaceholderFinder:
             def __getattr__(self, k):
                 if k.startswith("__"):
                     raise AttributeError(k)
-                return _Inert
+                return _Inert()
 
         m = _Mod(spec.name)
         m.__path__ = []
@@ -351,8 +351,8 @@ COG_PIPE_DIT = dict(num_attention_heads=2, attention_head_dim=64, in_channels=48
                     sample_frames=9, patch_size=2, temporal_compression_ratio=4, max_text_seq_length=8,
                     norm_elementwise_affine=True, norm_eps=1e-5, use_rotary_positional_embeddings=True,
                     use_learned_positional_embeddings=True, use_FrameIn=True)
-COG_PIPE_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(16, 32, 32, 64), latent_channels=16,
-                    layers_per_block=1, norm_eps=1e-6, norm_num_groups=8, temporal_compression_ratio=4,
+COG_PIPE_VAE = dict(in_channels=3, out_channels=3, block_out_channels=(8, 16, 16, 32), latent_channels=16,
+                    layers_per_block=1, norm_eps=1e-6, norm_num_groups=4, temporal_compression_ratio=4,
                     scaling_factor=0.7, invert_scale_latents=False)
 
 
@@ -399,7 +399,7 @@ def gen_cog_pipe():
     lat0 = torch.randn(1, 3, lc, H // 8, W // 8, generator=g)
     steps, gs = 4, 6.0
 
-    def run(sched, seen=None, **kw):
+    def run(sched, seen=None, dit=dit, vae=vae, pe=pe, ne=ne, lat0=lat0, **kw):
         pipe = CogVideoXImageToVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, transformer=dit, scheduler=sched)
         if seen is not None:
             orig_prep, orig_fwd = pipe.prepare_latents, dit.forward
@@ -432,6 +432,16 @@ def gen_cog_pipe():
     out_dpm_dyn = run(CogVideoXDPMScheduler(), output_type="latent", use_dynamic_cfg=True,
                       generator=torch.Generator().manual_seed(11))
     video = run(CogVideoXDDIMScheduler(), output_type="np")
+    # the same calls with every module and the prompt embeddings in bf16 (this pipeline hands the VAE images in the prompt
+    # embeddings' dtype, :786-788, so its modules share one dtype -- test_code/run_cogvideox_FrameIn_mass_evaluation.py
+    # loads them all in fp16): the reference's own reduced-precision arithmetic and, for DPM, its noise drawn in bf16
+    import copy
+    dit_b = copy.deepcopy(dit).to(torch.bfloat16)
+    vae_b = AutoencoderKLCogVideoX(**COG_PIPE_VAE).eval()
+    vae_b.load_flat_state_dict({k: v.bfloat16() for k, v in vae_sd.items()})
+    kwb = dict(dit=dit_b, vae=vae_b, pe=pe.bfloat16(), ne=ne.bfloat16(), lat0=lat0.bfloat16(), output_type="latent")
+    out_ddim_b = run(CogVideoXDDIMScheduler(), **kwb)
+    out_dpm_b = run(CogVideoXDPMScheduler(), generator=torch.Generator().manual_seed(11), **kwb)
     x0 = seen["model_input0"]                                       # [2, 4, 48, 8, 8] = [noisy + ID | first frame + 0 | traj + 0]
     print("placeholder modules served:", sorted(set(_PlaceholderFinder.served)))
     sd = {"dit." + k: v for k, v in dit.state_dict().items()}
@@ -442,7 +452,7 @@ def gen_cog_pipe():
          latents0=lat0, latents_scaled=seen["latents_scaled"], image_latents=seen["image_latents"],
          traj_latents=x0[1:2, :3, 2 * lc:], id_latent=x0[1:2, 3:, :lc], model_input0=x0, rope_cos=seen["rope_cos"],
          rope_sin=seen["rope_sin"], out_ddim=out_ddim, out_ddim_dynamic_cfg=out_dyn, out_dpm=out_dpm,
-         out_dpm_dynamic_cfg=out_dpm_dyn, out_video=video, steps=np.array(steps), guidance=np.array(gs),
+         out_dpm_dynamic_cfg=out_dpm_dyn, out_ddim_bf16=out_ddim_b, out_dpm_bf16=out_dpm_b, out_video=video, steps=np.array(steps), guidance=np.array(gs),
          dpm_generator_seed=np.array(11))
 
 

@@ -69,9 +69,11 @@ def main():
         host_ms[0] = (t1 - t0) / n * 1e3
         return (time.perf_counter() - t0) / n * 1e3
 
-    if os.environ.get("FINO_PLAN_SIM_SK"):          # A/B: 1 = never stream-K, 2 = whenever legal (FINO_TUNE_GEMM_STREAM_K)
-        from frameino_amd import _lib
-        _lib.lib().fino_tune_set(3, int(os.environ["FINO_PLAN_SIM_SK"]))
+    from frameino_amd import _lib
+    if os.environ.get("FINO_PLAN_SIM_TILE_M"):      # A/B: 8 = 256-row GEMM tiles only (round 2), 2..7 = that height everywhere
+        _lib.lib().fino_tune_set(3, int(os.environ["FINO_PLAN_SIM_TILE_M"]))
+    if os.environ.get("FINO_PLAN_SIM_GEMM_PLAN"):   # A/B: 1 = least-work GEMM tiling (FINO_TUNE_GEMM_PLAN)
+        _lib.lib().fino_tune_set(5, int(os.environ["FINO_PLAN_SIM_GEMM_PLAN"]))
     only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. "interleave:8" or "split-heads:4": that plan alone (profiling)
     if only:
         kind, ways = only.split(":")
