@@ -578,9 +578,11 @@ inline int gemm_device_cus() {
 //     32 mi / 256 of one (MFMA), and a round of n <= CUs tiles max(MFMA, delivery * n / CUs).
 // The plan: leading rows as 256-row tiles, the rest as ONE more launch of lower tiles (two launches of the same kernel
 // family, results bit-identical to any other tiling: one fp32 dot product per element in the same K order), whichever
-// (rows1, height) minimises that model; FINO_TUNE_GEMM_PLAN = 1 minimises the WORK instead (256-row tiles + the lowest
-// tile row that covers the remainder): what a rank wants when another stream's kernels fill the CUs it leaves idle
-// (the interleaved multi-GPU plan).
+// (rows1, height) minimises that model.  The model is for a GEMM ALONE on the chip: a rank that runs a second stream of
+// kernels beside it (the interleaved multi-GPU plan) keeps 256-row tiles (FINO_TUNE_GEMM_TILE_M = 8) -- the other stream
+// fills the CUs a partial round leaves idle, and lower tiles only add operand traffic (tools/plan_sim.py: 77.0 vs 78.6 ms
+// per rank at 4 GPUs, 47.0 vs 48.2 at 8).  A SECOND launch for a handful of leftover rows never pays: a launch lasts at
+// least one tile's walk over K (~16 us at K = 3072, ~75 us at K = 14336, however few rows it has): measured +25 %.
 struct TilePlan { int64_t rows1; int mi2; };          // rows1 rows as 256-row tiles (may be 0 or M), the rest with mi2
 inline double plan_launch_cost(int64_t rows, int mi, int tiles_n, int cus) {
     if (rows <= 0) return 0.0;
@@ -600,12 +602,6 @@ inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus) {
     if (forced >= 2 && forced <= 7) return TilePlan{0, forced};
     TilePlan best{m, 8};
     if (forced == 8 || m <= 0) return best;
-    if (fino_tune_get(FINO_TUNE_GEMM_PLAN) == 1) {                     // least work: whole 256-row tile rows + one low row
-        const int64_t rows1 = (m / 256) * 256, rem = m - rows1;
-        if (rem == 0) return best;
-        int mi = (int)((rem + 31) / 32);
-        return TilePlan{rows1, mi < 2 ? 2 : mi};
-    }
     double best_c = plan_launch_cost(m, 8, tiles_n, cus);
     const double base_c = best_c;
     const int64_t rows256 = (m + 255) / 256;
@@ -618,7 +614,7 @@ inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus) {
             if (c < best_c - 1e-9) { best_c = c; best = TilePlan{rows1, mi}; }
         }
     }
-    if (best_c > 0.985 * base_c) return TilePlan{m, 8};               // not worth a second launch / another code path
+    if (best_c > (best.rows1 > 0 ? 0.97 : 0.985) * base_c) return TilePlan{m, 8};      // not worth a second launch / another code path
     return best;
 }
 
@@ -649,6 +645,7 @@ template <typename T>
 int launch_gemm_rows(GemmParams p, int64_t r0, int64_t rows, int mi, int epi, hipStream_t st) {
     p.a += r0 * p.lda;
     p.c += r0 * p.ldc;
+    if (p.c2) p.c2 += r0 * p.ldc2;
     if (p.r) p.r += r0 * p.ldr;
     if (p.sel) p.sel += r0;
     p.m = rows;
@@ -734,14 +731,30 @@ extern "C" int fino_gemm_plan(int64_t m, int64_t n, int64_t* rows_256, int* tile
 extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
                          int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
                          const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream) {
+    return fino_gemm_split_n(a, w, bias, c, m, n, k, lda, ldw, ldc, epilogue, r, ldr, gate, mod_stride, sel, dtype, nullptr,
+                             0, 0, stream);
+}
+
+extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
+                                 int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
+                                 const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* c2,
+                                 int64_t ldc2, int64_t n_split, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm: dtype %d", dtype);
+    if (c2 || n_split) {
+        FINO_CHECK(c2 && n_split > 0 && n_split < n && n_split % BN == 0 && ldc2 % 8 == 0 && ldc2 >= n - n_split &&
+                       fino_aligned16(c2) && k % BK == 0 && epilogue <= FINO_EPI_GELU_TANH,
+                   FINO_ERR_ARG,
+                   "fino_gemm_split_n: needs c2, 0 < n_split < N a multiple of %d, ldc2 >= N - n_split, K %% %d == 0, no "
+                   "residual epilogue", BN, BK);
+        FINO_CHECK(ldc >= n_split, FINO_ERR_ARG, "fino_gemm_split_n: ldc must cover the first n_split columns");
+    }
     FINO_CHECK(a && w && c, FINO_ERR_ARG, "fino_gemm: null pointer");
     FINO_CHECK(m >= 0 && n > 0 && k > 0, FINO_ERR_ARG, "fino_gemm: bad shape M=%lld N=%lld K=%lld", (long long)m,
                (long long)n, (long long)k);
     FINO_CHECK(n % 8 == 0 && k % 8 == 0, FINO_ERR_ARG, "fino_gemm: N=%lld and K=%lld must be multiples of 8",
                (long long)n, (long long)k);
-    FINO_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= k && ldw >= k && ldc >= n, FINO_ERR_ARG,
-               "fino_gemm: leading dimensions must be multiples of 8 and cover the row");
+    FINO_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= k && ldw >= k && ldc >= (n_split > 0 ? n_split : n),
+               FINO_ERR_ARG, "fino_gemm: leading dimensions must be multiples of 8 and cover the row");
     FINO_CHECK(fino_aligned16(a) && fino_aligned16(w) && fino_aligned16(c), FINO_ERR_ARG,
                "fino_gemm: A/W/C must be 16-byte aligned");
     FINO_CHECK(epilogue >= FINO_EPI_NONE && epilogue <= FINO_EPI_GATED_RESIDUAL_STAGED, FINO_ERR_ARG,
@@ -752,6 +765,7 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
         FINO_CHECK(gate && fino_aligned16(gate) && mod_stride % 4 == 0, FINO_ERR_ARG, "fino_gemm: gate operand");
     if (m == 0) return FINO_OK;
     GemmParams p = {};
+    p.c2 = (uint16_t*)c2; p.ldc2 = ldc2; p.n_split = n_split;
     p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.c = (uint16_t*)c;
     p.r = (const uint16_t*)r; p.gate = gate; p.sel = sel;
     p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;

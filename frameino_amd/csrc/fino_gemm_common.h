@@ -22,6 +22,10 @@ struct GemmParams {
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
     int group_m;                     // tile rows per raster group (tile_coords); 0 = default
+    // column split of the output (fino_gemm_split_n): tile columns at n0 >= n_split go to c2 (leading dimension ldc2,
+    // column n_split = its column 0); n_split is a multiple of BN, 0 = one output
+    uint16_t* c2;
+    int64_t ldc2, n_split;
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents
@@ -209,6 +213,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmP
             const uint2 qv = mx_quant8(y, e);
             *reinterpret_cast<uint2*>(p.cq + gm * p.n + gn) = qv;
             if ((ch & 3) == 0) p.cs[mx_scale_index(gm, gn, p.cs_rows_pad)] = (uint8_t)(e + 127);
+        } else if (p.n_split > 0 && n0 >= p.n_split) {
+            *reinterpret_cast<uint4*>(p.c2 + gm * p.ldc2 + (gn - p.n_split)) = yv;
         } else {
             *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
         }

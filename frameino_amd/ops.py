@@ -243,14 +243,26 @@ def gemm_plan(m, n):
     return r.value, t.value
 
 
-def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None):
-    """C = epilogue(A.W^T + bias).  a [M, K] row-strided, w [N, K] (nn.Linear weight)."""
+def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None, out2=None, split=0):
+    """C = epilogue(A.W^T + bias).  a [M, K] row-strided, w [N, K] (nn.Linear weight).
+    `out2`, `split`: columns [split, N) of the product go to out2 [M, N - split], columns [0, split) to out [M, split]
+    (fino_gemm_split_n: the fused q | k | v projection of a token shard, k | v landing in the all-gather's send buffer)."""
     a2, m, k, lda = _rows2d(a)
     assert w.dim() == 2 and w.stride(1) == 1 and w.shape[1] == k and w.dtype == a.dtype
     n = w.shape[0]
     if out is None:
-        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        out = torch.empty((m, split or n), dtype=a.dtype, device=a.device)
     o2, _, _, ldc = _rows2d(out)
+    if out2 is not None:
+        assert 0 < split < n and residual is None
+        c2, _, _, ldc2 = _rows2d(out2)
+        ev = _timed("gemm")
+        _lib.check(_lib.lib().fino_gemm_split_n(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue,
+                                               0, 0, 0, 0, 0, _dt(a), _p(c2), ldc2, split, _stream()), "fino_gemm_split_n")
+        if ev is not None:
+            ev.record()
+            KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
+        return out, out2
     r2, ldr = (None, 0)
     if residual is not None:
         r2, _, _, ldr = _rows2d(residual)

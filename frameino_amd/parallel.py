@@ -54,6 +54,16 @@ class TokenShard:
     def local_first(self):
         return self.ways <= 2 if self.overlap_local == "auto" else bool(self.overlap_local)
 
+    # K|V exchange: project q | k | v in ONE GEMM (k | v written straight into the gather's send buffer) instead of K|V
+    # first and Q under the gather.  "auto": on for the interleaved plan's shards (ParallelPlan sets it) -- there the other
+    # CFG branch's kernels are what the gather overlaps, and two GEMMs of 2 D and D columns cost 185 us where the fused
+    # one costs 139 (3080 rows; profiles/r02_heads_exchange_parts.txt).  A split-plan rank keeps the Q projection as the
+    # only work it can put under its gather.
+    fused_qkv = False
+
+    def fused_qkv_ok(self):
+        return bool(self.fused_qkv)
+
     @property
     def active(self):
         return self.ways > 1 or self.force
@@ -154,6 +164,7 @@ class ParallelPlan:
             # costs (two half-size attention launches: +4-6 % GPU work, tools/plan_sim.py)
             for sh in self.shards:
                 sh.head_groups = 1
+                sh.fused_qkv = True
         self._buf = None
 
     def with_exchange(self, exchange):
@@ -210,6 +221,17 @@ def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False, 
     return ParallelPlan(rank, world, cfg_ways, token_ways, token_group, cfg_group, exchange=exchange)
 
 
+def _set_gemm_tiling(interleaved):
+    """An interleaved rank runs two kernel streams: the other branch fills the CUs a partial round of GEMM tiles leaves
+    idle, so the library's tile-height planner (built for a GEMM alone on the chip) is told to keep 256-row tiles --
+    lower tiles only add operand traffic there (tools/plan_sim.py).  Process-wide: one process per GPU."""
+    try:
+        from . import _lib
+        _lib.lib().fino_tune_set(3, 8 if interleaved else 0)          # FINO_TUNE_GEMM_TILE_M
+    except (RuntimeError, OSError):                                   # CPU-only test runs (gloo): no library, no kernels
+        pass
+
+
 def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None, allow_single=False, exchange="kv"):
     plan = plan or make_plan(rank, world, cfg_parallel, mode, allow_single, exchange)
     heads = getattr(getattr(pipe.transformer, "config", None), "num_attention_heads", None)
@@ -217,6 +239,7 @@ def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None
         raise ValueError(f"the heads exchange needs num_attention_heads ({heads}) divisible by the token shards "
                          f"({plan.token_ways})")
     pipe.parallel = plan
+    _set_gemm_tiling(plan.interleave)
     pipe.parallel_desc = plan.desc
     pipe.token_shards = plan.token_ways
     pipe.transformer.parallel = plan.shard if plan.shard.active else None

@@ -520,12 +520,19 @@ class WanTransformer3DModel(nn.Module):
                         work.wait()
                     a3[:, :, h0 * dh:h1 * dh].copy_(orv[:, :n].permute(1, 0, 2))
             else:
-                # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
-                self._lin(li, "kv", nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n])
-                o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
-                kv_all, work = sh.all_gather_kv(kv_loc)
-                self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
+                if sh.fused_qkv_ok() and not self._fp8:
+                    # ONE q | k | v GEMM whose k | v columns land in the all-gather's send buffer (fino_gemm_split_n): the
+                    # interleaved plan, where the OTHER branch's compute is what the gather flies under
+                    o.gemm(nrm, e.wqkv, e.bqkv, out=q2, out2=kv_loc[:n], split=d)
+                    o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                    kv_all, work = sh.all_gather_kv(kv_loc)
+                else:
+                    # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
+                    self._lin(li, "kv", nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n])
+                    o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                    kv_all, work = sh.all_gather_kv(kv_loc)
+                    self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
                 o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
                 if sh.local_first():
                     # local keys first -- nothing of it waits for the wire -- then what the gather delivered before /

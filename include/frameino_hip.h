@@ -41,11 +41,9 @@ const char* fino_last_error(void);
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
  * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
  * ping-pong one.  FINO_TUNE_GEMM_TILE_M: 2 .. 7 = one launch of 32 x that many rows per tile, 8 = 256-row tiles only (the round-2 behaviour).
- * FINO_TUNE_GEMM_PLAN: 1 = tile the GEMM for least work (256-row tiles + the lowest tile row covering the remainder)
- * instead of least time alone on the chip -- for a rank whose other stream fills the idle CUs.
  * FINO_TUNE_ATTN_KERNEL (head_dim 128): 2 = the 4-wave one-wave-per-SIMD kernel instead of the 8-wave ping-pong one. */
 enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_TILE_M = 3,
-       FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_GEMM_PLAN = 5, FINO_TUNE_COUNT = 8 };
+       FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);
 int fino_tune_get(int key);
 
@@ -163,6 +161,15 @@ enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EP
 int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
               int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
+/* fino_gemm whose output columns [n_split, N) go to a SECOND buffer c2 (leading dimension ldc2; column n_split of the
+ * product = column 0 of c2), columns [0, n_split) to c as usual: the fused q | k | v projection of a token-sharded rank
+ * (transformer_wan.py:60-62 as ONE GEMM) leaves q in its own buffer and k | v contiguous in the buffer the K|V all-gather
+ * sends -- no copy, and one GEMM of 3 D columns instead of a 2 D and a D one.  n_split a multiple of 256, K of 64; the
+ * bias / GELU epilogues only. */
+int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k, int64_t lda,
+                      int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
+                      int64_t mod_stride, const int32_t* sel, int dtype, void* c2, int64_t ldc2, int64_t n_split,
+                      void* stream);
 /* The tiling fino_gemm uses for an M x N problem on the current device: `rows_256` leading rows run as 256 x 256 tiles
  * (a whole number of rounds of the CUs), the remaining rows as ONE more launch of `tile_rows_rest`-row tiles (64 .. 256
  * in steps of 32; 0 = no second launch) chosen so that they fit (at most) one more round: 3080 rows x 3072 columns are

@@ -63,3 +63,36 @@ def cog_denoise_loop(sd, cfg, latents, image_latents, traj_latents, id_latent, p
         cb = a_p ** 0.5 - a_t ** 0.5 * ca
         lat = (ca * lat + cb * x0).to(latents.dtype)
     return lat
+
+
+def cog_conditions(vae_sd, vae_cfg, image, traj, id_tensor, num_frames, dtype=torch.float32, generator=None,
+                   add_id_noise=False):
+    """The three condition encodes of the FrameINO CogVideoX pipeline, through oracle/cog_vae.py:
+    `prepare_latents` (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:350-423: first frame -> posterior sample ->
+    [B, F, C, h, w] x scaling factor, zero frames appended), the trajectory video (:809-817) and the identity reference
+    (:820-822 -> train_code/train_cogvideox_motion_FrameINO.py:515-546).  image [1, 3, H, W] and traj [F, 3, H, W],
+    id_tensor [3, H, W] in [-1, 1].  Posterior samples draw like diffusers' DiagonalGaussianDistribution.sample: the
+    first-frame one from `generator`, the other two from the global RNG.  Pinned by tests/golden/cog_pipe_tiny.npz
+    (recorded from the reference pipeline's own __call__)."""
+    from . import cog_vae as V
+    sf = vae_cfg["scaling_factor"]
+
+    def sample(moments, gen=None):
+        mean, logvar = torch.chunk(moments, 2, dim=1)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        return mean + std * torch.randn(mean.shape, generator=gen, dtype=moments.dtype)
+
+    nlf = (num_frames - 1) // vae_cfg["temporal_compression_ratio"] + 1
+    img = image.unsqueeze(2)                                                           # :387
+    il = sample(V.encode_moments(vae_sd, vae_cfg, img), generator).to(dtype).permute(0, 2, 1, 3, 4)
+    il = (1 / sf if vae_cfg.get("invert_scale_latents") else sf) * il                  # :393-398
+    pad = torch.zeros((il.shape[0], nlf - 1) + tuple(il.shape[2:]), dtype=dtype)
+    image_latents = torch.cat([il, pad], dim=1)                                        # :400-409
+    tv = traj[None].permute(0, 2, 1, 3, 4)                                             # :809-811
+    tl = (sample(V.encode_moments(vae_sd, vae_cfg, tv)) * sf).permute(0, 2, 1, 3, 4).contiguous().float().to(dtype)
+    x = id_tensor.unsqueeze(0).unsqueeze(2)                                            # train_code :519
+    if add_id_noise:                                                                   # :523-526
+        sigma = torch.exp(torch.normal(mean=-3.0, std=0.5, size=(1,))).to(x.dtype)
+        x = x + torch.randn_like(x) * sigma[:, None, None, None, None]
+    idl = (sample(V.encode_moments(vae_sd, vae_cfg, x)) * sf).squeeze(2).contiguous().float()      # :529-543
+    return image_latents, tl, idl.unsqueeze(1).to(dtype)                               # :822

@@ -88,8 +88,13 @@ def attention_merge(parts, batch, lq, heads, head_dim, dtype, out=None):
     return o if out is None else out.copy_(o)
 
 
-def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None):
+def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None, out2=None, split=0):
     y = F.linear(a, w, bias)
+    if out2 is not None:                                  # fino_gemm_split_n: columns [split, N) to a second buffer
+        assert epilogue == EPI_NONE and residual is None
+        out.copy_(y[:, :split])
+        out2.copy_(y[:, split:])
+        return out, out2
     if epilogue == EPI_GELU_TANH:
         y = F.gelu(y, approximate="tanh")
     elif epilogue == EPI_RESIDUAL:

@@ -57,3 +57,23 @@ def smoke_check(device):
     exp = lat + (-0.05) * out[0].float().cpu()
     assert torch.allclose(lat_d.cpu(), exp, atol=1e-5)
     return r
+
+
+def record(test, metric, value, bound, lower_is_better=True):
+    """Append what a parity test MEASURED (not just that it passed) to gpurun_out/parity.jsonl -- one JSON object per
+    line: {test, metric, value, bound, ok} -- so that the numbers behind `parity: green` are on file (the builder copies
+    the file of the round's last full GPU run to profiles/rNN_parity.json).  Never raises: a read-only tree only loses
+    the log."""
+    import json
+    import os
+    ok = (value <= bound) if lower_is_better else (value >= bound)
+    try:
+        root = os.environ.get("FINO_PARITY_LOG_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                    "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+        with open(os.path.join(root, "parity.jsonl"), "a") as f:
+            f.write(json.dumps({"test": test, "metric": metric, "value": float(value), "bound": float(bound),
+                                "ok": bool(ok)}) + "\n")
+    except OSError:
+        pass
+    return ok

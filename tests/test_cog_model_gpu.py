@@ -76,31 +76,107 @@ def test_fused_projections_and_custom_processor(golden):
         m.set_attn_processor({"transformer_blocks.0.attn1.processor": Spy()})
 
 
-def test_cog_denoise_loop_and_rope_prep_vs_golden(golden):
-    """The CFG-batched FrameIn loop (:848-944) on the HIP path vs the loop recorded around the reference transformer."""
+def _cog_pipe(golden, sched=None, with_vae=False, dtype=torch.bfloat16):
+    """the mirror pipeline on the weights of tests/golden/cog_pipe_tiny.npz (a run of the reference pipeline's own __call__)"""
     from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
     from frameino_amd.schedulers import CogVideoXDDIMScheduler
-    cfg, sd, a = golden("cog_loop_tiny")
-    cfg = _cog_cfg(cfg)
-    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
-    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
-    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDDIMScheduler())
-    # rotary tables built by the pipeline == the reference's get_3d_rotary_pos_embed + first-frame extension
+    from tests.test_oracle_golden import cog_pipe_fixture
+    dit_cfg, dit_sd, vae_cfg, vae_sd, a = cog_pipe_fixture(golden)
+    m = CogVideoXTransformer3DModel(**dit_cfg).to(DEV)
+    m.load_reference_state_dict(dit_sd, dtype=dtype)
+    vae = None
+    if with_vae:
+        from frameino_amd.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+        vae = AutoencoderKLCogVideoX(**vae_cfg).to(DEV)
+        vae.load_reference_state_dict(vae_sd, dtype=dtype)
+    pipe = CogVideoXImageToVideoPipeline(vae=vae, transformer=m.eval(), scheduler=sched or CogVideoXDDIMScheduler())
+    return pipe, a, (dit_cfg, dit_sd, vae_cfg, vae_sd)
+
+
+def test_cog_denoise_loop_and_rope_prep_vs_the_reference_pipeline_run(golden):
+    """The CFG-batched FrameIn loop (:848-944) on the HIP path vs the latents the REFERENCE pipeline's own `__call__`
+    returned (fp32 run, and its bf16 run: the reference's own reduced-precision arithmetic), DDIM with and without
+    `use_dynamic_cfg`; RoPE tables incl. the first-frame extension (:834-839) vs what the reference handed its model."""
+    from tests.parity import record
+    pipe, a, _ = _cog_pipe(golden)
     cos, sin = pipe._prepare_rotary_positional_embeddings(64, 64, 3, "cpu")
-    torch.testing.assert_close(cos, a["cos"], atol=1e-6, rtol=1e-6)
-    torch.testing.assert_close(sin, a["sin"], atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(cos, a["rope_cos"], atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(sin, a["rope_sin"], atol=1e-6, rtol=1e-6)
     d = lambda k: a[k].to(DEV)          # noqa: E731
-    for dyn, key in ((False, "out"), (True, "out_dyn")):
-        out = pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+    ref_bf16_vs_fp32 = rel_rms(a["out_ddim_bf16"], a["out_ddim"])
+    for dyn, key in ((False, "out_ddim"), (True, "out_ddim_dynamic_cfg")):
+        out = pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
                            d("negative_embeds"), float(a["guidance"]), int(a["steps"]), use_dynamic_cfg=dyn)
         r = rel_rms(out, a[key])
+        record(f"cog_loop[{key}]", "rel_rms hip bf16 vs reference fp32 run (reference's own bf16 run: "
+               f"{ref_bf16_vs_fp32:.4f})", r, 6e-2)
         assert out.shape == a[key].shape and r < 6e-2, (key, r)
+    out = pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+                       d("negative_embeds"), float(a["guidance"]), int(a["steps"]))
+    rb = rel_rms(out, a["out_ddim_bf16"])
+    record("cog_loop[out_ddim_bf16]", "rel_rms hip bf16 vs reference bf16 run", rb, 6e-2)
+    assert rb < 6e-2, rb
+
+
+def test_cog_dpm_loop_vs_the_reference_pipeline_bf16_run(golden):
+    """CogVideoXDPMScheduler branch (:915-926) vs the reference pipeline's own bf16 run: same generator, noise drawn in
+    bf16 on the generator's device as diffusers' randn_tensor does, the first-frame posterior sample drawn first (:389)"""
+    from frameino_amd.schedulers import CogVideoXDPMScheduler
+    from tests.parity import record
+    pipe, a, _ = _cog_pipe(golden, CogVideoXDPMScheduler())
+    d = lambda k: a[k].to(DEV)          # noqa: E731
+    g = torch.Generator().manual_seed(int(a["dpm_generator_seed"]))
+    torch.randn((1, 16, 1, 8, 8), generator=g, dtype=torch.bfloat16)           # the draw prepare_latents makes (:389)
+    out = pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+                       d("negative_embeds"), float(a["guidance"]), int(a["steps"]), generator=g)
+    r = rel_rms(out, a["out_dpm_bf16"])
+    record("cog_loop[out_dpm_bf16]", "rel_rms hip bf16 vs reference bf16 run (DPM, same noise stream)", r, 8e-2)
+    assert out.shape == a["out_dpm_bf16"].shape and torch.isfinite(out.float()).all() and r < 8e-2, r
+
+
+def test_cog_full_call_vs_the_reference_pipeline_run(golden):
+    """`__call__` (:604-957) end to end on the HIP path -- PIL preprocess, `prepare_latents` (:350-423), trajectory and
+    identity encodes through the HIP AutoencoderKLCogVideoX (:803-826), the loop, decode, post-processing -- against the
+    recorded run of the reference pipeline's own `__call__` on the same weights and inputs."""
+    import PIL.Image
+    from tests.parity import record
+    pipe, a, _ = _cog_pipe(golden, with_vae=True)
+    seen = {}
+    orig = pipe.denoise
+
+    def spy(latents, image_latents, traj_latents, id_latent, *rest, **kw):
+        seen.update(latents=latents, image_latents=image_latents, traj_latents=traj_latents, id_latent=id_latent)
+        return orig(latents, image_latents, traj_latents, id_latent, *rest, **kw)
+
+    pipe.denoise = spy
+    H, W = a["image"].shape[:2]
+    kw = dict(image=PIL.Image.fromarray(a["image"].numpy()), traj_tensor=a["traj"].to(DEV), ID_tensor=a["id_tensor"].to(DEV),
+              prompt_embeds=a["prompt_embeds"].to(DEV).bfloat16(), negative_prompt_embeds=a["negative_embeds"].to(DEV).bfloat16(),
+              height=H, width=W, num_frames=a["traj"].shape[0], num_inference_steps=int(a["steps"]),
+              guidance_scale=float(a["guidance"]), add_ID_reference_augment_noise=False, latents=a["latents0"].to(DEV))
+    torch.manual_seed(7)
+    lat = pipe(output_type="latent", **kw).frames
+    for key in ("image_latents", "traj_latents", "id_latent"):
+        r = rel_rms(seen[key], a[key])
+        record(f"cog_call[{key}]", "rel_rms hip bf16 VAE encode vs reference run (fp32)", r, 4e-2)
+        assert seen[key].shape == a[key].shape and r < 4e-2, (key, r)
+    assert float(seen["image_latents"][:, 1:].abs().max()) == 0.0                      # the zero frames (:400-409)
+    r = rel_rms(lat, a["out_ddim"])
+    record("cog_call[out_ddim]", "rel_rms hip bf16 __call__ latents vs reference fp32 run", r, 8e-2)
+    assert lat.shape == a["out_ddim"].shape and r < 8e-2, r
+    torch.manual_seed(7)
+    vid = pipe(output_type="np", **kw).frames
+    ref = a["out_video"].numpy()
+    mse = float(((vid - ref) ** 2).mean())
+    psnr = 10 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20))).item()
+    record("cog_call[out_video]", "PSNR dB hip bf16 video vs reference fp32 run (higher is better)", psnr, 22.0, lower_is_better=False)
+    assert vid.shape == ref.shape and psnr > 22.0, psnr
 
 
 def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):
     """Stage-1 pipeline (pipelines/pipeline_cogvideox_i2v_motion.py): no ID frame, RoPE of exactly F frames, on the
-    use_FrameIn=False weights recorded from the reference; against the oracle loop (itself pinned by cog_loop_tiny)."""
+    use_FrameIn=False weights recorded from the reference; against the oracle loop (itself pinned by cog_pipe_tiny)."""
     from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.pipeline_cogvideox_i2v_motion import CogVideoXImageToVideoPipeline
     from frameino_amd.schedulers import CogVideoXDDIMScheduler
@@ -126,33 +202,28 @@ def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):
 
 def test_cog_dpm_scheduler_loop_vs_oracle_loop(golden):
     """CogVideoXDPMScheduler branch of the loop (:915-926; the scheduler the CogVideoX-5B-I2V repo ships): the fused
-    fino_cfg_dpm_step path vs the oracle loop that calls the op-by-op restatement of the published step, same seeded
-    CPU generator on both sides (one draw on first-order steps, two on second-order ones).  bf16 latents."""
-    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
-    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    fino_cfg_dpm_step path vs the oracle loop (pinned to the reference run's DPM trajectory by tests/test_oracle_golden.py)
+    run in bf16 with the same seeded noise stream, over 5 steps (first-order start, second-order middle, first-order end)."""
     from frameino_amd.schedulers import CogVideoXDPMScheduler
     from oracle.cog_pipeline import cog_denoise_loop
-    cfg, sd, a = golden("cog_loop_tiny")
-    cfg = _cog_cfg(cfg)
-    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
-    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
-    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDPMScheduler())
+    pipe, a, (cfg, sd, _, _) = _cog_pipe(golden, CogVideoXDPMScheduler())
     d = lambda k: a[k].to(DEV)          # noqa: E731
     steps = 5
-    out = pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+    out = pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
                        d("negative_embeds"), float(a["guidance"]), steps, generator=torch.Generator().manual_seed(5))
     sdb = {k: v.bfloat16() for k, v in sd.items()}
     b = lambda k: a[k].bfloat16()       # noqa: E731
-    ref = cog_denoise_loop(sdb, cfg, b("latents"), b("image_latents"), b("traj_latents"), b("id_latent"),
-                           b("prompt_embeds"), b("negative_embeds"), (a["cos"], a["sin"]), float(a["guidance"]), steps,
-                           use_dpm=True, dpm_generator=torch.Generator().manual_seed(5))
+    ref = cog_denoise_loop(sdb, cfg, b("latents0"), b("image_latents"), b("traj_latents"), b("id_latent"),
+                           b("prompt_embeds"), b("negative_embeds"), (a["rope_cos"], a["rope_sin"]), float(a["guidance"]),
+                           steps, use_dpm=True, dpm_generator=torch.Generator().manual_seed(5))
     r = rel_rms(out, ref)
-    print(f"DPM loop, {steps} steps: hip vs bf16 oracle loop rel-RMS {r:.4f}")
+    from tests.parity import record
+    record("cog_dpm_loop_5_steps", "rel_rms hip vs bf16 oracle loop", r, 6e-2)
     assert out.shape == ref.shape and torch.isfinite(out.float()).all() and r < 6e-2, r
     # and the sampler is what differs from DDIM: same inputs, other update, other result
     from frameino_amd.schedulers import CogVideoXDDIMScheduler
     pipe.scheduler = CogVideoXDDIMScheduler()
-    out_ddim = pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+    out_ddim = pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
                             d("negative_embeds"), float(a["guidance"]), steps)
     assert rel_rms(out, out_ddim) > 1e-2
 
@@ -223,22 +294,19 @@ class _FakeCogVAE(torch.nn.Module):
 def test_cog_full_call_plumbing_with_a_stand_in_vae(golden):
     """`__call__` (:604-957): condition encodes (first frame, trajectory video, ID frame), scaling factors, layout
     permutes, the loop, decode + post-processing -- equal to `denoise()` fed with hand-made conditions."""
-    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
     from frameino_amd.schedulers import CogVideoXDDIMScheduler
-    cfg, sd, a = golden("cog_loop_tiny")
-    cfg = _cog_cfg(cfg)
-    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
-    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
-    vae = _FakeCogVAE(c_lat=2).to(DEV)
-    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(), scheduler=CogVideoXDDIMScheduler(), vae=vae)
+    pipe0, a, _ = _cog_pipe(golden)
+    m = pipe0.transformer
+    vae = _FakeCogVAE(c_lat=16).to(DEV)
+    pipe = CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler(), vae=vae)
     g = torch.Generator().manual_seed(11)
     H = W = 64
     frames = 9                                                      # 3 latent frames
     image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
     traj = torch.rand(frames, 3, H, W, generator=g) * 2 - 1
     ident = torch.rand(3, H, W, generator=g) * 2 - 1
-    lat0 = torch.randn(1, 3, 2, 8, 8, generator=g)
+    lat0 = torch.randn(1, 3, 16, 8, 8, generator=g)
     pe, ne = a["prompt_embeds"].to(DEV).bfloat16(), a["negative_embeds"].to(DEV).bfloat16()
     kw = dict(image=image.to(DEV), traj_tensor=traj.to(DEV), ID_tensor=ident.to(DEV), height=H, width=W,
               num_frames=frames, num_inference_steps=3, guidance_scale=6.0, add_ID_reference_augment_noise=False,
@@ -247,7 +315,7 @@ def test_cog_full_call_plumbing_with_a_stand_in_vae(golden):
     # the same conditions by hand
     dt = torch.bfloat16
     img_lat = 0.7 * vae.encode(image.to(DEV).to(dt).unsqueeze(2)).latent_dist.sample().to(dt).permute(0, 2, 1, 3, 4)   # :389-392
-    img_lat = torch.cat([img_lat, torch.zeros(1, 2, 2, 8, 8, device=DEV, dtype=dt)], dim=1)
+    img_lat = torch.cat([img_lat, torch.zeros(1, 2, 16, 8, 8, device=DEV, dtype=dt)], dim=1)
     trj_lat = (vae.encode(traj.to(DEV)[None].permute(0, 2, 1, 3, 4)).latent_dist.sample() * 0.7) \
         .permute(0, 2, 1, 3, 4).contiguous().float().to(dt)
     id_lat = (vae.encode(ident.to(DEV)[None, :, None]).latent_dist.sample() * 0.7).squeeze(2).float().unsqueeze(1).to(dt)
@@ -297,19 +365,12 @@ def test_baseline_config1_shape_full_width_two_layers_vs_oracle():
 def test_cog_loop_hip_graph_replay_equals_eager(golden, sched):
     """The CogVideoX step on static buffers (only the noisy channels of the generated frames are rewritten per step)
     captured once and replayed: bit-identical to the eager loop, for both samplers."""
-    from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
-    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
     from frameino_amd.schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler
-    cfg, sd, a = golden("cog_loop_tiny")
-    cfg = _cog_cfg(cfg)
-    m = CogVideoXTransformer3DModel(**cfg).to(DEV)
-    m.load_reference_state_dict(sd, dtype=torch.bfloat16)
-    pipe = CogVideoXImageToVideoPipeline(transformer=m.eval(),
-                                         scheduler=CogVideoXDPMScheduler() if sched == "dpm" else CogVideoXDDIMScheduler())
+    pipe, a, _ = _cog_pipe(golden, CogVideoXDPMScheduler() if sched == "dpm" else CogVideoXDDIMScheduler())
     d = lambda k: a[k].to(DEV)          # noqa: E731
 
     def run():
-        return pipe.denoise(d("latents"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
+        return pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
                             d("negative_embeds"), float(a["guidance"]), 5, generator=torch.Generator().manual_seed(3))
 
     eager = run()

@@ -106,10 +106,9 @@ def test_cog_pipeline_call_end_to_end_with_the_hip_vae_and_dpm_scheduler(golden)
     from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
     from frameino_amd.schedulers import CogVideoXDPMScheduler
-    from tests.test_oracle_golden import _cog_cfg
-    vae = AutoencoderKLCogVideoX(**dict(TINY, latent_channels=2)).random_init_(seed=5, device=DEV)
-    cfg, sd, a = golden("cog_loop_tiny")                 # in_channels 6 = 3 x 2 latent channels, sample 8x8 latents
-    cfg = _cog_cfg(cfg)
+    from tests.test_oracle_golden import cog_pipe_fixture
+    vae = AutoencoderKLCogVideoX(**dict(TINY, latent_channels=16)).random_init_(seed=5, device=DEV)
+    cfg, sd, _, _, a = cog_pipe_fixture(golden)           # in_channels 48 = 3 x 16 latent channels, sample 8x8 latents
     m = CogVideoXTransformer3DModel(**cfg).to(DEV)
     m.load_reference_state_dict(sd, dtype=torch.bfloat16)
     pipe = CogVideoXImageToVideoPipeline(vae=vae, transformer=m.eval(), scheduler=CogVideoXDPMScheduler())

@@ -57,11 +57,6 @@ def test_every_tile_height_is_bit_identical_to_the_256_row_path(lib, dtype, m, n
             out = _run(lib, ops_, epi, mi)
             assert torch.equal(out, base), f"tile height {32 * mi}, epilogue {epi}: differs from the 256-row tiles"
         assert torch.equal(_run(lib, ops_, epi, 0), base)          # and so does whatever the planner picks
-        try:
-            lib.fino_tune_set(5, 1)                                   # ... in the least-work mode too
-            assert torch.equal(_run(lib, ops_, epi, 0), base)
-        finally:
-            lib.fino_tune_set(5, 0)
 
 
 @pytest.mark.parametrize("m", [1540, 3080, 6160, 12320, 24640], ids=lambda m: f"rows{m}")
@@ -95,13 +90,6 @@ def test_the_planner(lib):
             r256, rest = ops.gemm_plan(m, n)
             assert 0 <= r256 <= m and (r256 % 256 == 0 or r256 == m)
             assert (rest == 0) == (r256 == m) and rest % 32 == 0 and rest <= 256
-    # least-work mode: whole 256-row tile rows + the lowest row of tiles that covers the remainder
-    try:
-        lib.fino_tune_set(5, 1)
-        assert ops.gemm_plan(3080, D) == (3072, 64) and ops.gemm_plan(1540, D) == (1536, 64)
-        assert ops.gemm_plan(12320, D) == (12288, 64) and ops.gemm_plan(12288 + 100, D) == (12288, 128)
-    finally:
-        lib.fino_tune_set(5, 0)
 
 
 def test_two_launch_form_on_strided_views_with_an_in_place_residual(lib):
@@ -119,3 +107,20 @@ def test_two_launch_form_on_strided_views_with_an_in_place_residual(lib):
     ops.gemm(big[:, d:2 * d], w, None, 3, residual=x, gate=gate, sel=sel, out=x)      # C aliases R, A is a column slice
     assert rel_rms(x, ref.float()) < 2.0 ** -7
     print(f"plan for {m} x {d}: {r256} rows of 256-row tiles + {rest}-row tiles")
+
+
+@pytest.mark.parametrize("m", [1540, 3080, 700])
+def test_split_n_output_equals_the_column_slices_of_one_output(lib, m):
+    """fino_gemm_split_n (the fused q | k | v projection of a token shard: q to its buffer, k | v to the gather's send
+    buffer, row-strided destinations): bit-equal to the slices of the ordinary GEMM"""
+    from frameino_amd import ops
+    d = 512
+    a, w, bias, _, _, _ = _operands(m, 3 * d, 1024, 0, seed=9)
+    whole = ops.gemm(a, w, bias)
+    q = torch.zeros(m + 3, d, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(m + 5, 2 * d + 64, device=DEV, dtype=torch.bfloat16)          # padded rows: a strided destination
+    ops.gemm(a, w, bias, out=q[:m], out2=kv[:m, :2 * d], split=d)
+    assert torch.equal(q[:m], whole[:, :d]) and torch.equal(kv[:m, :2 * d], whole[:, d:])
+    assert float(q[m:].abs().max()) == 0.0 and float(kv[m:].abs().max()) == 0.0 and float(kv[:, 2 * d:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="n_split"):
+        ops.gemm(a, w, bias, out=q[:m], out2=kv[:m, :2 * d], split=d + 8)

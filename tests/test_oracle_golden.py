@@ -1,5 +1,7 @@
 """The oracle (CPU restatement) against the golden vectors recorded from the reference's own
 model files (tools/golden/make_golden.py).  fp32, so the bar is tight: 1e-5 abs / 1e-5 rel."""
+import numpy as np
+import pytest
 import torch
 
 from oracle import wan_dit as W
@@ -143,18 +145,68 @@ def test_cog_forward_stage1_no_frame_in(golden):
         torch.testing.assert_close(out, a[f"y_{tag}"], atol=5e-5, rtol=5e-5)
 
 
-def test_cog_denoise_loop_restatement(golden):
-    from oracle.cog_pipeline import cog_denoise_loop, ddim_tables
-    cfg, sd, a = golden("cog_loop_tiny")
-    cfg = _cog_cfg(cfg)
-    ac, ts = ddim_tables(int(a["steps"]))
-    assert ts.tolist() == a["timesteps"].tolist()
-    torch.testing.assert_close(ac.float(), a["alphas_cumprod"], atol=1e-7, rtol=1e-6)
-    for dyn, key in ((False, "out"), (True, "out_dyn")):
-        out = cog_denoise_loop(sd, cfg, a["latents"], a["image_latents"], a["traj_latents"], a["id_latent"],
-                               a["prompt_embeds"], a["negative_embeds"], (a["cos"], a["sin"]), float(a["guidance"]),
-                               int(a["steps"]), dynamic_cfg=dyn)
-        torch.testing.assert_close(out, a[key], atol=1e-4, rtol=1e-4)
+def cog_pipe_fixture(golden):
+    """tests/golden/cog_pipe_tiny.npz: a run of the REFERENCE CogVideoX FrameINO pipeline's own `__call__`
+    (tools/golden/make_golden.py::gen_cog_pipe) -> (dit cfg, dit sd, vae cfg, vae sd, arrays)"""
+    cfg, sd, a = golden("cog_pipe_tiny")
+    vae_cfg = {k[4:]: v for k, v in cfg.items() if k.startswith("vae_")}
+    vae_cfg["block_out_channels"] = tuple(vae_cfg["block_out_channels"])
+    vae_cfg["invert_scale_latents"] = bool(vae_cfg["invert_scale_latents"])
+    dit_cfg = _cog_cfg({k: v for k, v in cfg.items() if not k.startswith("vae_")})
+    return (dit_cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}, vae_cfg,
+            {k[4:]: v for k, v in sd.items() if k.startswith("vae.")}, a)
+
+
+def test_cog_conditions_restatement_vs_the_reference_pipeline_run(golden):
+    """a13: `prepare_latents` (:350-423), the trajectory encode (:809-817), the identity-reference encode (:820-822 ->
+    train_code :515-546) and the RoPE extension (:834-839) as the reference's own __call__ computed them"""
+    import PIL.Image
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import get_3d_rotary_pos_embed
+    from oracle.cog_pipeline import cog_conditions
+    dit_cfg, dit_sd, vae_cfg, vae_sd, a = cog_pipe_fixture(golden)
+    H, W, F = a["image"].shape[0], a["image"].shape[1], a["traj"].shape[0]
+    pil = PIL.Image.fromarray(a["image"].numpy()).resize((W, H), resample=PIL.Image.LANCZOS)
+    img = 2.0 * torch.from_numpy(np.asarray(pil).astype("float32").transpose(2, 0, 1).copy() / 255.0)[None] - 1.0
+    torch.manual_seed(7)
+    il, tl, idl = cog_conditions(vae_sd, vae_cfg, img, a["traj"], a["id_tensor"], F)
+    torch.testing.assert_close(il, a["image_latents"], atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(tl, a["traj_latents"], atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(idl, a["id_latent"], atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(a["latents_scaled"], a["latents0"])                 # init_noise_sigma = 1 (:421)
+    # the first step's model input [noisy + ID | first frame + 0 | trajectory + 0] (:866-880), both CFG rows equal
+    x0 = a["model_input0"]
+    C = il.shape[2]
+    assert torch.equal(x0[0], x0[1]) and x0.shape[1] == il.shape[1] + 1 and x0.shape[2] == 3 * C
+    torch.testing.assert_close(x0[:1, :3, :C], a["latents0"])
+    assert float(x0[:, 3:, C:].abs().max()) == 0.0 and float(x0[:, 1:3, C:2 * C].abs().max()) == 0.0
+    nlf = il.shape[1]
+    cos, sin = get_3d_rotary_pos_embed(dit_cfg["attention_head_dim"], ((0, 0), (H // 16, W // 16)), (H // 16, W // 16), nlf)
+    n1 = cos.shape[0] // nlf
+    torch.testing.assert_close(torch.cat([cos, cos[:n1]]), a["rope_cos"], atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(torch.cat([sin, sin[:n1]]), a["rope_sin"], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("key,dyn,dpm", [("out_ddim", False, False), ("out_ddim_dynamic_cfg", True, False),
+                                         ("out_dpm", False, True), ("out_dpm_dynamic_cfg", True, True)])
+def test_cog_denoise_loop_restatement_vs_the_reference_pipeline_run(golden, key, dyn, dpm):
+    """the loop (:848-944) with DDIM / DPM and `use_dynamic_cfg`, against the latents the reference's __call__ returned"""
+    from oracle.cog_pipeline import cog_denoise_loop
+    dit_cfg, dit_sd, vae_cfg, vae_sd, a = cog_pipe_fixture(golden)
+    g = torch.Generator().manual_seed(int(a["dpm_generator_seed"]))
+    torch.randn(a["image_latents"][:, :1].permute(0, 2, 1, 3, 4).shape, generator=g)      # the first-frame posterior sample
+    out = cog_denoise_loop(dit_sd, dit_cfg, a["latents0"], a["image_latents"], a["traj_latents"], a["id_latent"],  # (:389)
+                           a["prompt_embeds"], a["negative_embeds"], (a["rope_cos"], a["rope_sin"]), float(a["guidance"]),
+                           int(a["steps"]), dynamic_cfg=dyn, use_dpm=dpm, dpm_generator=g)
+    torch.testing.assert_close(out, a[key], atol=2e-4, rtol=2e-4)
+
+
+def test_cog_decode_and_postprocess_vs_the_reference_pipeline_run(golden):
+    """decode_latents (:426-431) + postprocess_video (third-party, restated) of the DDIM run's latents"""
+    from oracle import cog_vae as V
+    dit_cfg, dit_sd, vae_cfg, vae_sd, a = cog_pipe_fixture(golden)
+    frames = V.decode(vae_sd, vae_cfg, a["out_ddim"].permute(0, 2, 1, 3, 4) / vae_cfg["scaling_factor"])
+    vid = (frames / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 4, 1)
+    torch.testing.assert_close(vid, a["out_video"], atol=2e-5, rtol=2e-5)
 
 
 def test_product_and_oracle_configs_agree():

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from frameino_amd.parallel import TokenShard  # noqa: E402
+from frameino_amd.parallel import TokenShard, _set_gemm_tiling  # noqa: E402
 
 
 class FakeShard(TokenShard):
@@ -72,8 +72,12 @@ def main():
     from frameino_amd import _lib
     if os.environ.get("FINO_PLAN_SIM_TILE_M"):      # A/B: 8 = 256-row GEMM tiles only (round 2), 2..7 = that height everywhere
         _lib.lib().fino_tune_set(3, int(os.environ["FINO_PLAN_SIM_TILE_M"]))
-    if os.environ.get("FINO_PLAN_SIM_GEMM_PLAN"):   # A/B: 1 = least-work GEMM tiling (FINO_TUNE_GEMM_PLAN)
-        _lib.lib().fino_tune_set(5, int(os.environ["FINO_PLAN_SIM_GEMM_PLAN"]))
+    forced_tile = bool(os.environ.get("FINO_PLAN_SIM_TILE_M"))
+
+    def set_tiling(interleaved):          # what shard_pipeline does for a real plan (unless the A/B knob above is set)
+        if not forced_tile:
+            _set_gemm_tiling(interleaved)
+
     only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. "interleave:8" or "split-heads:4": that plan alone (profiling)
     if only:
         kind, ways = only.split(":")
@@ -82,12 +86,15 @@ def main():
         if kind.startswith("interleave"):
             pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                             shards=(FakeShard(0, ways, exchange=ex), FakeShard(0, ways, exchange=ex)))
+            set_tiling(True)
             for sh in pipe.parallel.shards:
                 sh.head_groups = 1
+                sh.fused_qkv = not os.environ.get("FINO_PLAN_SIM_NO_FUSED_QKV")      # as ParallelPlan sets it
             model.parallel = pipe.parallel.shards[0]
         else:
             pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
                                             exchange_cfg=lambda mine: (mine, mine))
+            set_tiling(False)
             model.parallel = FakeShard(0, ways, exchange=ex) if ways > 1 else None
         print(f"{only}: {timed(3):.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
         return
@@ -97,11 +104,15 @@ def main():
         sh = FakeShard(0, ways)
         pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
                                         exchange_cfg=lambda mine: (mine, mine))
+        set_tiling(False)
         model.parallel = sh if ways > 1 else None
         print(f"split      N={n_gpus}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
     for ways in (2, 4, 8):          # interleaved plans: both branches per rank, token_ways = N
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways), FakeShard(0, ways)))
+        set_tiling(True)
+        for sh in pipe.parallel.shards:
+            sh.fused_qkv = True                 # as ParallelPlan sets it for the interleaved plan
         model.parallel = pipe.parallel.shards[0]
         print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
     # the same plans with the heads exchange (all-to-all instead of the K|V all-gather; attention over H/ways heads x all tokens)
@@ -109,11 +120,13 @@ def main():
         sh = FakeShard(0, ways, exchange="heads")
         pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
                                         exchange_cfg=lambda mine: (mine, mine))
+        set_tiling(False)
         model.parallel = sh
         print(f"split-heads      N={2 * ways}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
     for ways in (2, 4, 8):
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways, exchange="heads"), FakeShard(0, ways, exchange="heads")))
+        set_tiling(True)
         for sh in pipe.parallel.shards:
             sh.head_groups = 1                  # as ParallelPlan sets it for the interleaved plan
         model.parallel = pipe.parallel.shards[0]
