@@ -20,6 +20,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
+from .loading import FromPretrainedMixin
 from .autoencoder_kl_wan import DiagonalGaussianDistribution, _Config, cpad
 
 
@@ -90,7 +91,9 @@ def frame_batches(num_frames, batch):
     return [(batch * i + (0 if i == 0 else rem), batch * (i + 1) + rem) for i in range(nb)]
 
 
-class AutoencoderKLCogVideoX:
+class AutoencoderKLCogVideoX(FromPretrainedMixin):
+    _loader_name = "load_cogvideox_vae"
+
     num_latent_frames_batch_size = 2
     num_sample_frames_batch_size = 8
 
@@ -120,6 +123,23 @@ class AutoencoderKLCogVideoX:
 
     def eval(self):
         return self
+
+    # ---- diffusers' memory switches (test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96) ----
+    def enable_slicing(self):
+        """accepted: one video of the batch at a time is what this mirror does anyway (same results)"""
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def enable_tiling(self, *tile_args, **tile_kwargs):
+        """diffusers' tiling blends overlapping spatial tiles (a memory saver that changes the result); this mirror already
+        walks the video in diffusers' own frame batches (8 sample / 2 latent frames with conv caches: 12 GiB at
+        49 f 480x720), so the switch is accepted and the result stays the untiled one."""
+        self.use_tiling = True
+
+    def disable_tiling(self):
+        self.use_tiling = False
 
     def to(self, device=None, dtype=None):
         if isinstance(device, torch.dtype):

@@ -19,6 +19,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
+from .loading import FromPretrainedMixin
 
 
 def cpad(c):
@@ -110,7 +111,9 @@ def wan_vae_param_shapes(cfg):
     return s
 
 
-class AutoencoderKLWan:
+class AutoencoderKLWan(FromPretrainedMixin):
+    _loader_name = "load_wan_vae"
+
     def __init__(self, base_dim=96, decoder_base_dim=None, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
                  attn_scales=(), temperal_downsample=(False, True, True), dropout=0.0, latents_mean=None,
                  latents_std=None, is_residual=False, in_channels=3, out_channels=3, patch_size=None,
@@ -126,7 +129,8 @@ class AutoencoderKLWan:
                               scale_factor_temporal=scale_factor_temporal, scale_factor_spatial=scale_factor_spatial)
         self._sd = None
         self._pk = None
-        self._dtype = torch.bfloat16
+        self._dtype = torch.bfloat16           # compute dtype of the convolutions (bf16 | fp16)
+        self._io_dtype = None                  # what `.dtype` reports when fp32 was asked for (reference app.py:157)
         self._device = torch.device("cpu")
         self.use_slicing = self.use_tiling = False
         # frames per time chunk of the decoder's tail: results do not depend on it.  0 / None: whole sequence (fastest:
@@ -138,7 +142,7 @@ class AutoencoderKLWan:
     # ---- module-like surface ----
     @property
     def dtype(self):
-        return self._dtype
+        return self._io_dtype or self._dtype
 
     @property
     def device(self):
@@ -147,11 +151,42 @@ class AutoencoderKLWan:
     def eval(self):
         return self
 
+    def _set_dtype(self, dtype):
+        """fp32 (the precision the reference app runs this VAE in, app.py:157) is accepted as the INTERFACE dtype: master
+        weights stay fp32, inputs / outputs are fp32, `.dtype` says fp32 -- and the convolutions compute in bf16 with fp32
+        accumulation (MFMA has no fp32 path worth the name: 157 TFLOP/s against 2.5 P)."""
+        if dtype == torch.float32:
+            self._io_dtype, self._dtype = torch.float32, torch.bfloat16
+        else:
+            self._io_dtype, self._dtype = None, dtype
+
+    # ---- diffusers' memory switches (architecture/autoencoder_kl_wan.py:1084-1133) ----
+    def enable_slicing(self):
+        """accepted: this mirror already encodes / decodes one video of the batch at a time (same results)"""
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_sample_stride_height=None,
+                      tile_sample_stride_width=None):
+        """The reference's tiling (:1270-1397) cuts the frame into overlapping spatial tiles and BLENDS them: a memory
+        saver that changes the result.  With 288 GB of HBM the memory saver this mirror offers instead is result-IDENTICAL:
+        the decoder's tail runs in time chunks of 8 frames with the causal convs' two carried frames
+        (`decode_chunk_frames`, tests/test_fullsize_gpu.py: torch.equal to the whole-sequence decode, 36 -> 20 GiB at
+        49 f 704x1280).  The tile arguments are accepted and ignored."""
+        self.use_tiling = True
+        self.decode_chunk_frames = 8
+
+    def disable_tiling(self):
+        self.use_tiling = False
+        self.decode_chunk_frames = "auto"
+
     def to(self, device=None, dtype=None):
         if isinstance(device, torch.dtype):
             device, dtype = None, device
         if dtype is not None:
-            self._dtype = dtype
+            self._set_dtype(dtype)
         if device is not None:
             self._device = torch.device(device)
         if self._sd is not None:
@@ -171,7 +206,7 @@ class AutoencoderKLWan:
             if tuple(sd[k].shape) != tuple(shp):
                 raise ValueError(f"{k}: expected {shp}, got {tuple(sd[k].shape)}")
         self._sd = {k: sd[k].detach().to(self._device).float() for k in shapes}
-        self._dtype = dtype
+        self._set_dtype(dtype)
         self._pk = None
         return self
 

@@ -20,6 +20,7 @@ from torch import nn
 
 from . import ops
 from .attention_processor import Attention, MI355CogVideoXAttnProcessor, MI355FusedCogVideoXAttnProcessor
+from .loading import FromPretrainedMixin
 from .transformer_wan import FeedForward, _Config, _MLP2
 
 
@@ -76,7 +77,9 @@ def cog_sincos_pos_embed(embed_dim, pw, ph, frames, spatial_scale, temporal_scal
     return torch.cat([temporal, spatial], dim=-1).flatten(0, 1)
 
 
-class CogVideoXTransformer3DModel(nn.Module):
+class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
+    _loader_name = "load_cogvideox_transformer"
+
     def __init__(self, num_attention_heads=30, attention_head_dim=64, in_channels=16, out_channels=16,
                  flip_sin_to_cos=True, freq_shift=0, time_embed_dim=512, ofs_embed_dim=None, text_embed_dim=4096,
                  num_layers=30, dropout=0.0, attention_bias=True, sample_width=90, sample_height=60, sample_frames=49,

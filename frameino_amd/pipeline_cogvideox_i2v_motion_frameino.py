@@ -96,6 +96,31 @@ class CogVideoXImageToVideoPipeline:
     def enable_model_cpu_offload(self, *a, **k):
         return self
 
+    def to(self, device):
+        for m in (self.transformer, self.vae, self.text_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(device)
+        return self
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, **kwargs):
+        """`CogVideoXImageToVideoPipeline.from_pretrained(base_folder, text_encoder=, transformer=, vae=, torch_dtype=)`
+        (reference test_code/run_cogvideox_FrameIn_mass_evaluation.py:101-107): components handed in are used as they are,
+        the others come from the sub-folders of a LOCAL copy of zai-org/CogVideoX-5b-I2V that exist."""
+        from . import loading
+        from .autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+        from .cogvideox_transformer_3d import CogVideoXTransformer3DModel
+        comps = {"transformer": lambda f, dt: CogVideoXTransformer3DModel.from_pretrained(f, torch_dtype=dt),
+                 "vae": lambda f, dt: AutoencoderKLCogVideoX.from_pretrained(f, torch_dtype=dt),
+                 "scheduler": lambda f, dt: loading.load_scheduler(f),
+                 "text_encoder": loading._load_text_encoder, "tokenizer": loading._load_tokenizer}
+        parts, index, rest = loading._pipeline_from_pretrained(cls, pretrained_model_name_or_path, comps, torch_dtype,
+                                                               **kwargs)
+        if rest:
+            raise TypeError(f"{cls.__name__}.from_pretrained: unexpected keyword arguments {sorted(rest)}")
+        return cls(tokenizer=parts["tokenizer"], text_encoder=parts["text_encoder"], vae=parts["vae"],
+                   transformer=parts["transformer"], scheduler=parts["scheduler"])
+
     @property
     def interrupt(self):
         return self._interrupt

@@ -107,6 +107,30 @@ class WanImageToVideoPipeline:
     def enable_model_cpu_offload(self, *a, **k):      # reference app.py:163 -- unnecessary with 288 GB of HBM
         return self
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, **kwargs):
+        """`WanImageToVideoPipeline.from_pretrained(base_folder, transformer=transformer, vae=vae, torch_dtype=...)`
+        (reference app.py:161; train_code/train_wan_motion_FrameINO.py builds it the same way): components handed in are
+        used as they are, the others are loaded from the sub-folders of a LOCAL copy of Wan-AI/Wan2.2-TI2V-5B-Diffusers
+        that exist (transformer/, vae/, scheduler/ by the class its config names, text_encoder/ + tokenizer/ through
+        `transformers`); `expand_timesteps` from model_index.json (true for TI2V-5B, the only path FrameINO runs)."""
+        from . import loading
+        from .autoencoder_kl_wan import AutoencoderKLWan
+        from .transformer_wan import WanTransformer3DModel
+        comps = {"transformer": lambda f, dt: WanTransformer3DModel.from_pretrained(f, torch_dtype=dt),
+                 "vae": lambda f, dt: AutoencoderKLWan.from_pretrained(f, torch_dtype=dt),
+                 "scheduler": lambda f, dt: loading.load_scheduler(f),
+                 "text_encoder": loading._load_text_encoder, "tokenizer": loading._load_tokenizer}
+        parts, index, rest = loading._pipeline_from_pretrained(cls, pretrained_model_name_or_path, comps, torch_dtype,
+                                                               **kwargs)
+        for k in ("image_encoder", "image_processor", "transformer_2", "boundary_ratio"):
+            rest.pop(k, None)
+        if rest:
+            raise TypeError(f"{cls.__name__}.from_pretrained: unexpected keyword arguments {sorted(rest)}")
+        return cls(tokenizer=parts["tokenizer"], text_encoder=parts["text_encoder"], vae=parts["vae"],
+                   scheduler=parts["scheduler"], transformer=parts["transformer"],
+                   expand_timesteps=bool(index.get("expand_timesteps", True)))
+
     def maybe_free_model_hooks(self):
         pass
 

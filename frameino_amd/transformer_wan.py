@@ -23,6 +23,7 @@ from torch import nn
 
 from . import ops
 from .attention_processor import Attention, MI355WanAttnProcessor
+from .loading import FromPretrainedMixin
 
 
 class _Config(dict):
@@ -108,7 +109,8 @@ class WanTransformerBlock(nn.Module):
         self.scale_shift_table = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
 
 
-class WanTransformer3DModel(nn.Module):
+class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
+    _loader_name = "load_wan_transformer"
     _keep_in_fp32_modules = ["time_embedder", "scale_shift_table", "norm1", "norm2", "norm3"]   # reference :393
 
     def __init__(self, patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16,
