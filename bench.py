@@ -362,7 +362,7 @@ def main():
         ms_step = elapsed / a.steps * 1e3
         # FLOPs actually issued: on one GPU the two CFG branches are one batch-2 forward whose branch-invariant prefix
         # runs once (the N > 1 plans run two whole batch-1 forwards)
-        shared = world == 1 and getattr(model, "dedup_shared_prefix", False) and not getattr(pipe, "cfg_streams", False)
+        shared = world == 1 and getattr(model, "dedup_shared_prefix", False) and not a.cfg_streams
         flops_step = 2 * wan_flops_per_forward(L, cfg) - (wan_flops_shared_prefix(L, cfg) if shared else 0)
         out = {
             "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
@@ -576,14 +576,15 @@ def measured_mfma_peak(dev, achieved_tflops):
 
 def cpu_config1(budget_s=12.0):
     """BASELINE config 1 (CogVideoX-I2V-5B stage-1 pipeline, 13 frames 256x256, 10 steps, fp32 on
-    the host) through the oracle.  All of it is ~2.5e14 FLOP -- an hour on host cores -- so the timed SAMPLE is three
-    denoise steps (B = 2 forward + CFG + DDIM each) of the full-width model with 2 of its 42 layers; `config1_s` extrapolates
+    the host) through the oracle.  All of it is ~2.5e14 FLOP -- an hour on host cores -- so the timed SAMPLE is one
+    denoise step (B = 2 forward + CFG + DDIM) of the full-width model with 2 of its 42 layers; `config1_s` extrapolates
     it by layers and steps and says so."""
     from oracle import cog_pipeline as CP
     from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
     from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG as COG5B
     from frameino_amd.pipeline_cogvideox_i2v_motion import CogVideoXImageToVideoPipeline
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(os.cpu_count() or 1, 64)           # L = 1250 rows: more threads than that only fight over the caches
+    torch.set_num_threads(threads)
     cfg = dict(COG5B, use_FrameIn=False, num_layers=2)
     g = torch.Generator().manual_seed(1)
     m = CogVideoXTransformer3DModel(**cfg)                 # the mirror only as a container of reference-keyed parameters
@@ -601,13 +602,13 @@ def cpu_config1(budget_s=12.0):
     trj = torch.randn(1, F_, C_, h, w, generator=g)
     pe, ne = torch.randn(1, 226, 4096, generator=g), torch.randn(1, 226, 4096, generator=g)
     t0 = time.time()
-    nst = 3
+    nst = 1
     CP.cog_denoise_loop(sd, cfg, lat, img, trj, None, pe, ne, rot, 6.0, nst)
     t_step2 = (time.time() - t0) / nst
     layers = COG5B["num_layers"]
     return {"config1_s": t_step2 * layers / 2 * 10,
             "config1_sample": f"oracle stage-1 CogVideoX pipeline, fp32, 13 f 256x256 (L = 226 + 1024, B = 2), full width, "
-                              f"{nst} steps with 2 of {layers} layers: {t_step2:.2f} s per step; extrapolated "
+                              f"{nst} step with 2 of {layers} layers on {threads} threads: {t_step2:.2f} s; extrapolated "
                               f"x {layers // 2} (layers) x 10 (steps)"}
 
 

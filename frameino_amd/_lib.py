@@ -41,6 +41,9 @@ SIGNATURES = {
     "fino_attn_fwd_ws": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 12 +
                         [c_float, c_int, c_void_p, c_i64, c_void_p],
     "fino_attn_workspace_bytes": [c_int, c_int, c_i64, c_i64, c_int],
+    "fino_attn_fp8_kv_bytes": [c_int, c_int, c_i64, c_int],
+    "fino_attn_fwd_fp8": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 8 + [c_float, c_int, c_void_p, c_i64,
+                                                                                           c_void_p],
     "fino_attn_partial_bytes": [c_int, c_int, c_i64, c_int],
     "fino_attn_partial": [c_void_p] * 3 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 9 + [c_float, c_int, c_void_p,
                                                                                                c_i64, c_void_p],
@@ -80,7 +83,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_i64, "fino_mxfp8_scale_bytes": c_i64,
              "fino_groupnorm_workspace_bytes": c_i64,
-             "fino_attn_partial_bytes": c_i64}
+             "fino_attn_partial_bytes": c_i64, "fino_attn_fp8_kv_bytes": c_i64}
 
 
 def declared_symbols(header_path=HEADER_PATH):

@@ -201,6 +201,40 @@ def attention(q, k, v, heads, out=None, scale=None):
     return out
 
 
+_attn_fp8_ws = {}     # (device index, stream) -> byte workspace of the quantised K / V images of attention_fp8
+
+
+def attention_fp8(q, k, v, heads, out=None, scale=None):
+    """attention() with fp8 (e4m3) matrix operands, head_dim 64: K / V quantised per call (block-scaled, V transposed), Q and
+    P in registers, both products on the block-scaled fp8 MFMA, softmax and accumulation in fp32 (fino_attn_fwd_fp8)."""
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
+    b, lq, hd = q.shape
+    lk = k.shape[1]
+    dh = hd // heads
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.is_cuda
+    if out is None:
+        out = torch.empty((b, lq, hd), dtype=q.dtype, device=q.device)
+    scale = dh ** -0.5 if scale is None else scale
+    need = _lib.lib().fino_attn_fp8_kv_bytes(b, heads, lk, dh)
+    if need <= 0:
+        raise RuntimeError(f"attention_fp8: head_dim {dh} is not supported (built for 64)")
+    key = (q.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _attn_fp8_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _attn_fp8_ws[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    ev = _timed("attn_self" if lk > 1024 else "attn_cross")
+    _lib.check(_lib.lib().fino_attn_fwd_fp8(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh, q.stride(0), q.stride(1),
+                                           k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                           float(scale), _dt(q), _p(ws), need, _stream()), "fino_attn_fwd_fp8")
+    if ev is not None:
+        ev.record()
+        kt_ = KernelTimer.active
+        nm = "attn_self" if lk > 1024 else "attn_cross"
+        kt_.flops[nm] = kt_.flops.get(nm, 0.0) + 4.0 * b * lq * lk * hd
+    return out
+
+
 def attention_partial_floats(batch, heads, lq, head_dim):
     return _lib.lib().fino_attn_partial_bytes(batch, heads, lq, head_dim) // 4
 

@@ -21,12 +21,43 @@ import torch
 import torch.nn.functional as F
 
 
+def _conv3d(xp, w, b, stride=(1, 1, 1)):
+    """F.conv3d(xp, w, b, stride) on an already padded input.  On the host: the library call.  On a GPU in fp32 (the
+    full-size checks of tests/test_wan_vae_gpu.py run this oracle on the device): the same sum written as one matrix
+    product per kernel tap, out += W[:, :, tap] @ x[tap-shifted] -- the vendor library's fp32 3-D convolution takes
+    minutes per layer at 704x1280, a matmul does not; only the fp32 summation order differs."""
+    if not (xp.is_cuda and xp.dtype == torch.float32):
+        return F.conv3d(xp, w, b, stride=stride)
+    bsz, ci, tp, hp, wp = xp.shape
+    co, _, kt, kh, kw = w.shape
+    st, sh, sw = stride
+    to, ho, wo = (tp - kt) // st + 1, (hp - kh) // sh + 1, (wp - kw) // sw + 1
+    out = torch.zeros(bsz, co, to * ho * wo, dtype=xp.dtype, device=xp.device)
+    for dt in range(kt):
+        for dh in range(kh):
+            for dw in range(kw):
+                xs = xp[:, :, dt:dt + st * (to - 1) + 1:st, dh:dh + sh * (ho - 1) + 1:sh, dw:dw + sw * (wo - 1) + 1:sw]
+                out.baddbmm_(w[None, :, :, dt, dh, dw].expand(bsz, -1, -1), xs.reshape(bsz, ci, -1))
+    out = out.view(bsz, co, to, ho, wo)
+    return out if b is None else out + b.view(1, -1, 1, 1, 1)
+
+
+def _conv2d(x, w, b, stride=1, padding=0):
+    """F.conv2d on [N, C, H, W] (frames as the batch) through the same switch"""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return F.conv2d(x, w, b, stride=stride, padding=padding)
+    xp = F.pad(x, (padding, padding, padding, padding)) if padding else x
+    s = stride if isinstance(stride, int) else stride[0]
+    y = _conv3d(xp.permute(1, 0, 2, 3)[None], w[:, :, None], b, (1, s, s))           # frames on the (stride-1) time axis
+    return y[0].permute(1, 0, 2, 3)
+
+
 def causal_conv3d(x, w, b, stride=(1, 1, 1)):
     """WanCausalConv3d.forward (:169-176) over a whole sequence: pad (kw//2, kh//2) spatially as the module was built
     (padding = k//2 for the 3x3x3 convs, 0 for 1x1x1 and for the strided time_conv), 2*pad_t zeros at the front."""
     kt, kh, kw = w.shape[2:]
-    return F.conv3d(F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, 0, 0)), w, b, stride=stride) if kt == 1 else \
-        F.conv3d(F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0)), w, b, stride=stride)
+    return _conv3d(F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, 0, 0)), w, b, stride) if kt == 1 else \
+        _conv3d(F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0)), w, b, stride)
 
 
 def rms_norm(x, gamma, channel_dim=1):
@@ -51,12 +82,12 @@ def attention_block(sd, p, x):
     b, c, t, h, w = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
     y = rms_norm(y, sd[p + ".norm.gamma"])
-    qkv = F.conv2d(y, sd[p + ".to_qkv.weight"], sd[p + ".to_qkv.bias"])
+    qkv = _conv2d(y, sd[p + ".to_qkv.weight"], sd[p + ".to_qkv.bias"])
     qkv = qkv.reshape(b * t, 1, c * 3, -1).permute(0, 1, 3, 2).contiguous()
     q, k, v = qkv.chunk(3, dim=-1)
     y = F.scaled_dot_product_attention(q, k, v)
     y = y.squeeze(1).permute(0, 2, 1).reshape(b * t, c, h, w)
-    y = F.conv2d(y, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
+    y = _conv2d(y, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
     return y.view(b, t, c, h, w).permute(0, 2, 1, 3, 4) + x
 
 
@@ -68,7 +99,7 @@ def mid_block(sd, p, x):
 
 def _per_frame_conv2d(x, w, b, **kw):
     bsz, c, t, h, ww = x.shape
-    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(bsz * t, c, h, ww), w, b, **kw)
+    y = _conv2d(x.permute(0, 2, 1, 3, 4).reshape(bsz * t, c, h, ww), w, b, **kw)
     return y.view(bsz, t, *y.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
@@ -84,7 +115,7 @@ def upsample(sd, p, x, temporal):
     b, c, t, h, w = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
     y = F.interpolate(y.float(), scale_factor=(2.0, 2.0), mode="nearest-exact").type_as(y)     # :216-217
-    y = F.conv2d(y, sd[p + ".resample.1.weight"], sd[p + ".resample.1.bias"], padding=1)
+    y = _conv2d(y, sd[p + ".resample.1.weight"], sd[p + ".resample.1.bias"], padding=1)
     return y.view(b, t, *y.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
@@ -93,7 +124,7 @@ def downsample(sd, p, x, temporal):
     y = _per_frame_conv2d(F.pad(x, (0, 1, 0, 1)), sd[p + ".resample.1.weight"], sd[p + ".resample.1.bias"], stride=2)
     if temporal and y.shape[2] > 1:
         # out[k] = conv(f[2k-2], f[2k-1], f[2k]), k >= 1  == stride-2 conv over the sequence without extra padding
-        z = F.conv3d(y, sd[p + ".time_conv.weight"], sd[p + ".time_conv.bias"], stride=(2, 1, 1))
+        z = _conv3d(y, sd[p + ".time_conv.weight"], sd[p + ".time_conv.bias"], (2, 1, 1))
         y = torch.cat([y[:, :, :1], z], dim=2)
     return y
 

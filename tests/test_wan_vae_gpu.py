@@ -163,3 +163,30 @@ def test_time_chunked_decoder_tail_is_bit_identical_to_whole_sequence(chunk):
     chunked = vae.decode(z, return_dict=False)[0]
     assert whole.shape == chunked.shape == (1, 3, 13, 48, 80)
     assert torch.equal(whole, chunked)
+
+
+def test_full_size_decode_vs_oracle_fp32_on_device():
+    """the reference app runs this VAE in fp32 (app.py:157), the mirror's convolutions compute in bf16 -- the
+    number at SIZE: 5 latent frames at 704x1280 (latent 44x80 -> 17 frames of 704x1280), the real Wan2.2 VAE widths, seeded
+    random weights, against oracle/wan_vae.py executed in fp32 on the device."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    from oracle import wan_vae as V
+    from tests.parity import record
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=7, device=DEV)
+    sd = {k: v.float() for k, v in vae._sd.items()}
+    z = torch.randn(1, 48, 5, 44, 80, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    with torch.no_grad():
+        out = vae.decode(z, return_dict=False)[0]
+        ref = V.wan_vae_decode(sd, dict(WAN22_VAE_CFG), z)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape == (1, 3, 17, 704, 1280) and torch.isfinite(out).all()
+    p = psnr(out, ref)
+    r = rel_rms(out, ref)
+    inside = ref.abs() < 0.98                                       # where the [-1, 1] clamp (:1221) is not active
+    r_in = rel_rms(out[inside], ref[inside])
+    record("wan_vae_decode_full_size_5_latent_frames_704x1280", "PSNR dB hip bf16 vs oracle fp32 on device (higher is better)",
+           p, 38.0, lower_is_better=False)
+    record("wan_vae_decode_full_size_5_latent_frames_704x1280", "rel_rms (all pixels / unclamped pixels: "
+           f"{r_in:.4f})", r, 2.5e-2)
+    assert p > 38.0 and r < 2.5e-2, (p, r)
