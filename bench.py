@@ -686,7 +686,8 @@ def other_workload_ms_per_step(pipe, make_inputs, cfg, dev, workload, steps=2):
 def config5_ms_per_step(dev, steps=2):
     """BASELINE config 5: CogVideoX-5B FrameINO, 49 f 480x720 -> model input [2, 14, 48, 60, 90], L = 226 + 18900, 42
     layers, 48 heads x 64; one step = the B=2 forward + guidance + v-prediction DDIM update
-    (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944).  bf16, then MXFP8 linears (+ bf16 attention)."""
+    (pipelines/pipeline_cogvideox_i2v_motion_FrameINO.py:848-944).  bf16, then MXFP8 linears (+ bf16 attention), then MXFP8
+    linears + fp8 (e4m3) attention operands: the "fp8 MFMA path" end to end."""
     from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG as COG5B
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
     from frameino_amd.random_init import random_cog_model
@@ -704,9 +705,12 @@ def config5_ms_per_step(dev, steps=2):
     L, d, nl = 226 + 14 * 30 * 45, 3072, COG5B["num_layers"]
     flops = 2 * nl * (8 * L * d * d + 4 * L * L * d + 16 * L * d * d)          # B=2: proj + SDPA + FFN (4x)
     out = {}
-    for key, fp8 in (("config5_cogvideox5b_480x720_bf16", False), ("config5_cogvideox5b_480x720_mxfp8_linears", True)):
+    for key, fp8, fp8_attn in (("config5_cogvideox5b_480x720_bf16", False, False),
+                               ("config5_cogvideox5b_480x720_mxfp8_linears", True, False),
+                               ("config5_cogvideox5b_480x720_mxfp8_linears_fp8_attention", True, True)):
         if fp8:
             m.enable_mxfp8_linears()
+        m.enable_fp8_attention(fp8_attn)
         seen = []
 
         def cb(p, i, t, kw):

@@ -126,6 +126,7 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
         self._pos_cache = {}
         self._fp8 = {}
         self._fp8_pending = False
+        self.fp8_attention = False           # see enable_fp8_attention
         # q leaves its LayerNorm + RoPE kernel multiplied by head_dim**-0.5 * log2(e) and the attention kernels take q.k as
         # the exp2 argument (FINO_ATTN_SCALE_FOLDED): at head_dim 64 that selects the 4-wave kernel with the running maximum
         # folded into its MFMAs (-5 % per step).  Video rows: one rounding of q.c instead of q; the 226 text rows (LayerNorm
@@ -216,6 +217,16 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
             for key, w in (("qkv", e.wqkv), ("out", blk.attn1.to_out[0].weight), ("ff1", blk.ff.net[0].proj.weight),
                            ("ff2", blk.ff.net[2].weight)):
                 self._fp8[(li, key)] = ops.quantize_mxfp8(w.detach().contiguous())
+        return self
+
+    def enable_fp8_attention(self, enabled=True):
+        """The joint text + video self-attention (attention_processor.py:2863 of the reference, head_dim 64: 55 % of the
+        CogVideoX-5B step) with fp8 e4m3 matrix operands -- K / V quantised per call with one scale per 32 elements, Q and
+        P in registers, both products on the block-scaled fp8 MFMA, fp32 softmax and accumulation
+        (`fino_attn_fwd_fp8`).  With `enable_mxfp8_linears()` this is BASELINE config 5's "fp8 MFMA path" end to end.
+        No reference counterpart: tolerance stated in tests/test_attention_fp8_gpu.py and
+        tests/test_fullsize_oracle_gpu.py against fp32 and against this model's own bf16 forward."""
+        self.fp8_attention = bool(enabled)
         return self
 
     def _lin(self, li, key, x, w, b, epi=0, **kw):
@@ -347,7 +358,8 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
                 nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
                 ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt, **qfold)
                 ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
-                att = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads, **afold)
+                attend = ops.attention_fp8 if (self.fp8_attention and dh == 64) else ops.attention
+                att = attend(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads, **afold)
                 self._lin(li, "out", att.view(b * L, d), blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
                           ops.EPI_GATED_RESIDUAL_STAGED, residual=x2, gate=t1[:, 2], sel=sel, out=x2)
             else:

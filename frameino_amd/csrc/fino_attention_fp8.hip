@@ -34,7 +34,6 @@ constexpr int kD8 = 64;                      // head_dim
 constexpr int kPShift = 6;                   // P8 = e4m3(p * 2^6), block scale 2^-6
 constexpr float kThr8 = 2.0f;                // deferred-rescale threshold (log2): p <= 4 between rescales, P8 <= 256
 constexpr int kTileK8 = kKV * kD8;           // 4096 B: K8 tile / V8T tile
-constexpr int kStage8 = 2 * kTileK8 + 256;   // + 128 B K scales + 128 B V scales
 // Which 32 of the 64 K-elements of its row lane group g (= lane >> 5) holds, as two 16-byte chunks of the row:
 // chunk c0 = g, c1 = 2 + g  (k = 16 g .. 16 g + 15 and 32 + 16 g .. 32 + 16 g + 15), and the scale operand of lane group g
 // is the scale of K-block g (k in [32 g, 32 g + 32)) -- the 16x16x128 form's rule, re-probed for 32x32x64.
@@ -137,16 +136,30 @@ struct Fp8AttnParams {
     int nt;
 };
 
+// LDS: K8 ring (2 x 4 KiB) | V8T ring (2 x 4 KiB) | K scale ring (2 x 128 B) | V scale ring (2 x 128 B)
+constexpr int kLdsK = 0, kLdsV = 2 * kTileK8, kLdsKS = 4 * kTileK8, kLdsVS = 4 * kTileK8 + 256;
+constexpr int kSmem8 = 4 * kTileK8 + 512;
+
+// PING-PONG (the structure of attn_pp_kernel, fino_attention.hip): the two waves of a SIMD (w, w + 4) run one phase apart --
+// one in its SOFTMAX phase (exp2, e4m3 packing of P(t), the rescale decision, its share of the K / V staging), the other in
+// its MATRIX phase (S(t+1) = -m + K(t+1).Q^T, O^T += V(t)^T.P(t)^T, l^T += 1.P(t)^T, row maximum of S(t+1) in the MFMAs'
+// shadow); two s_barrier per tile.  The running maximum rides into S as one more product on the matrix pipe ("ones" x (-m),
+// a bf16 MFMA into the same accumulator: m is kept bf16-representable so the product is exact), so the softmax is a bare
+// exp2 + pack.  Staging: K(w + 1) and V(w) may be written during phases 2w - 1 and 2w (their ring slots are free from
+// 2w - 1, they are first read in phase 2w + 1): group g writes its half of both in its softmax phase of tile t = w - g.
 template <typename T, int VAR>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnParams& p = fp.a;
     constexpr int kDT = kD8 / 32;            // 2 d-tiles of O^T
+    typedef typename T::vec8 vec8;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 31;
     const int g = lane >> 5;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int tg = tid & 255;                // thread in its group
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -179,10 +192,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
     uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
     const int64_t tile0 = (int64_t)hb * fp.nt + t_begin;
-    const uint8_t* k8 = fp.k8 + tile0 * kTileK8;
-    const uint8_t* v8 = fp.v8t + tile0 * kTileK8;
-    const uint8_t* ksp = fp.ks + tile0 * 128;
-    const uint8_t* vsp = fp.vs + tile0 * 128;
     const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;
     const int nt = t_end - t_begin;
 
@@ -229,114 +238,192 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         q_scale = g == 0 ? sbyte[0] : sbyte[1];
     }
 
-    // ---- staging: a stage = K8 tile | V8T tile | K scales | V scales; 512 threads x 16 B cover the two tiles ----
-    const int st_off = tid * 16;                                      // tid < 256: K8, else V8T (contiguous in the stage)
-    const uint8_t* st_src = tid < 256 ? k8 + st_off : v8 + (st_off - kTileK8);
-    auto load_tile = [&](int t) -> uint4 { return *reinterpret_cast<const uint4*>(st_src + (int64_t)t * kTileK8); };
-    auto load_scales = [&](int t) -> uint32_t {                        // threads 0..31: K scales, 32..63: V scales (4 B each)
-        const uint8_t* s = (tid < 32 ? ksp + tid * 4 : vsp + (tid - 32) * 4) + (int64_t)t * 128;
-        return tid < 64 ? *reinterpret_cast<const uint32_t*>(s) : 0u;
-    };
-    {
-        const uint4 v0 = load_tile(0);
-        const uint32_t s0 = load_scales(0);
-        *reinterpret_cast<uint4*>(smem + st_off) = v0;
-        if (tid < 64) *reinterpret_cast<uint32_t*>(smem + 2 * kTileK8 + tid * 4) = s0;
+    // ---- staging roles: threads 0..127 of a group move chunk (128 grp + i) of a K8 tile, 128..255 of a V8T tile (16 B
+    //      each); the first 16 of either set also dword (16 grp + i) of that tile's 128 scale bytes ----
+    const bool st_k = tg < 128;
+    const int st_c = grp * 128 + (tg & 127);
+    const bool st_s = (tg & 127) < 16;
+    const uint8_t* st_src = (st_k ? fp.k8 : fp.v8t) + tile0 * kTileK8 + st_c * 16;
+    const uint8_t* st_ssrc = (st_k ? fp.ks : fp.vs) + tile0 * 128 + (grp * 16 + (tg & 15)) * 4;
+    const int st_dst = (st_k ? kLdsK : kLdsV) + st_c * 16;
+    const int st_sdst = (st_k ? kLdsKS : kLdsVS) + (grp * 16 + (tg & 15)) * 4;
+    const int st_add = st_k ? 1 : 0;         // K runs one tile ahead of V
+    uint4 st_reg = make_uint4(0, 0, 0, 0);
+    uint32_t st_sreg = 0;
+#define F8_LOAD(W_)                                                                                          \
+    {                                                                                                        \
+        int tt_ = (W_) + st_add;                                                                             \
+        tt_ = tt_ < nt ? tt_ : nt - 1;               /* past the last tile: a harmless re-read */            \
+        st_reg = *reinterpret_cast<const uint4*>(st_src + (int64_t)tt_ * kTileK8);                           \
+        if (st_s) st_sreg = *reinterpret_cast<const uint32_t*>(st_ssrc + (int64_t)tt_ * 128);                \
     }
+#define F8_WRITE(W_)                                                                                         \
+    {                                                                                                        \
+        const int sl_ = ((W_) + st_add) & 1;                                                                 \
+        *reinterpret_cast<uint4*>(smem + st_dst + sl_ * kTileK8) = st_reg;                                   \
+        if (st_s) *reinterpret_cast<uint32_t*>(smem + st_sdst + sl_ * 128) = st_sreg;                        \
+    }
+    // ---- prologue: K(0), V(0), K(1) whole (both groups, each its halves) ----
+    {
+        const uint8_t* k8 = fp.k8 + tile0 * kTileK8;
+        const uint8_t* v8 = fp.v8t + tile0 * kTileK8;
+        const int c = tid;                                   // 512 threads: K(0) = chunks 0..255, V(0) = 256..511
+        const uint4 a0 = *reinterpret_cast<const uint4*>((c < 256 ? k8 : v8) + (c & 255) * 16);
+        *reinterpret_cast<uint4*>(smem + (c < 256 ? kLdsK : kLdsV) + (c & 255) * 16) = a0;
+        if (c < 256) {
+            const int t1 = nt > 1 ? 1 : 0;
+            const uint4 a1 = *reinterpret_cast<const uint4*>(k8 + (int64_t)t1 * kTileK8 + c * 16);
+            *reinterpret_cast<uint4*>(smem + kLdsK + kTileK8 + c * 16) = a1;
+        }
+        if (tid < 32) *reinterpret_cast<uint32_t*>(smem + kLdsKS + tid * 4) =
+            *reinterpret_cast<const uint32_t*>(fp.ks + tile0 * 128 + tid * 4);
+        else if (tid < 64) *reinterpret_cast<uint32_t*>(smem + kLdsVS + (tid - 32) * 4) =
+            *reinterpret_cast<const uint32_t*>(fp.vs + tile0 * 128 + (tid - 32) * 4);
+        else if (tid < 96 && nt > 1) *reinterpret_cast<uint32_t*>(smem + kLdsKS + 128 + (tid - 64) * 4) =
+            *reinterpret_cast<const uint32_t*>(fp.ks + (tile0 + 1) * 128 + (tid - 64) * 4);
+    }
+    if (grp == 1) { F8_LOAD(1) }             // group 1 writes {K(2), V(1)} in its first softmax phase
     __syncthreads();
 
     f32x16_t o[kDT], lacc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { o[0][j] = 0.f; o[1][j] = 0.f; lacc[j] = 0.f; }
-    float m_run = -INFINITY;                  // running maximum of s (log2 domain), MINUS kPShift
     const i32x8_t ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
     constexpr int kOne = 127, kPs = 127 - kPShift;
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // "ones" x (-m): A[key][k = 0] = 1 (k = 0 lives in element 0 of the g = 0 lanes), B[k = 0][q] = -m[q]
+    uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
+    asm volatile("" : "+v"(ones_u.x));
+
+    // K(tile in slot KS_) . Q^T (+ C_) -> two 32-key halves
+#define F8_QK(KS_, C0_, C1_, S0_, S1_)                                                                       \
+    {                                                                                                        \
+        const char* kb_ = smem + kLdsK + (KS_) * kTileK8;                                                    \
+        const i32x4_t a00_ = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk0(g));               \
+        const i32x4_t a01_ = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk1(g));               \
+        const i32x4_t a10_ = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk0(g));        \
+        const i32x4_t a11_ = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk1(g));        \
+        const int ks0_ = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + r * 2 + g);         \
+        const int ks1_ = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + (32 + r) * 2 + g);  \
+        const i32x8_t k0_ = __builtin_shufflevector(a00_, a01_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        const i32x8_t k1_ = __builtin_shufflevector(a10_, a11_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        S0_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0_, qf, C0_, 0, 0, 0, ks0_, 0, q_scale);      \
+        S1_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1_, qf, C1_, 0, 0, 0, ks1_, 0, q_scale);      \
+    }
+    // keys past lk (zero rows of a ragged last tile): out of the maximum, p = exp2(-inf) = 0
+#define F8_MASK(T_, S0_, S1_)                                                                                \
+    if (__builtin_expect((T_) == nt - 1 && (lk & (kKV - 1)), 0)) {                                           \
+        int rem_ = lk - (T_) * kKV - 4 * g;                                                                  \
+        asm volatile("" : "+v"(rem_));      /* opaque: keeps this a BRANCH (if-converted it is 62 selects per tile) */ \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                  \
+            const int key_ = (j_ & 3) + 8 * (j_ >> 2);                                                       \
+            if (key_ >= rem_) S0_[j_] = -INFINITY;                                                           \
+            if (key_ + 32 >= rem_) S1_[j_] = -INFINITY;                                                      \
+        }                                                                                                    \
+    }
+#define F8_MAX8(S_, O_) vmax2(vmax3(vmax3(S_[O_], S_[O_ + 1], S_[O_ + 2]), vmax3(S_[O_ + 3], S_[O_ + 4], S_[O_ + 5]), \
+                                    S_[O_ + 6]), S_[O_ + 7])
+#define F8_SWAPMAX(MX_, OUT_)                                                                                \
+    {                                                                                                        \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(MX_), __float_as_uint(MX_), false, false); \
+        OUT_ = vmax2(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                      \
+    }
+
+    // ---- S(0) unpipelined; m_run = the value SUBTRACTED from s (running maximum minus kPShift, T-representable) ----
+    f32x16_t s0, s1;
+    F8_QK(0, zero16, zero16, s0, s1)
+    F8_MASK(0, s0, s1)
+    float m_run;
+    {
+        float mx = vmax2(vmax3(F8_MAX8(s0, 0), F8_MAX8(s0, 8), F8_MAX8(s1, 0)), F8_MAX8(s1, 8));
+        float mxx;
+        F8_SWAPMAX(mx, mxx)
+        m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s0[j] -= m_run; s1[j] -= m_run; }
+    }
+    float ex_next = 0.f;                      // max over the tile of (s - m_run): what may exceed 8
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
 
     for (int t = 0; t < nt; ++t) {
-        const char* sb = smem + (t & 1) * kStage8;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        uint32_t nxs = 0;
-        if (t + 1 < nt) {
-            nxt = load_tile(t + 1);
-            nxs = load_scales(t + 1);
-        }
-        // ---- S^T = K . Q^T: two 32-key halves ----
-        f32x16_t s0, s1;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+        // ================= softmax phase =================
+        const int w = t + grp;
+        if (w >= 1) { F8_WRITE(w) }
         {
-            const i32x4_t a00 = *reinterpret_cast<const i32x4_t*>(sb + r * 64 + 16 * chunk0(g));
-            const i32x4_t a01 = *reinterpret_cast<const i32x4_t*>(sb + r * 64 + 16 * chunk1(g));
-            const i32x4_t a10 = *reinterpret_cast<const i32x4_t*>(sb + (32 + r) * 64 + 16 * chunk0(g));
-            const i32x4_t a11 = *reinterpret_cast<const i32x4_t*>(sb + (32 + r) * 64 + 16 * chunk1(g));
-            const int ks0 = *reinterpret_cast<const uint8_t*>(sb + 2 * kTileK8 + r * 2 + g);
-            const int ks1 = *reinterpret_cast<const uint8_t*>(sb + 2 * kTileK8 + (32 + r) * 2 + g);
-            const i32x8_t k0 = __builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7);
-            const i32x8_t k1 = __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7);
-            s0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0, qf, s0, 0, 0, 0, ks0, 0, q_scale);
-            s1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1, qf, s1, 0, 0, 0, ks1, 0, q_scale);
-        }
-        if (t == nt - 1 && (lk & (kKV - 1))) {            // keys past lk: out of the maximum, p = 0
-            const int rem = lk - t * kKV - 4 * g;
+            // deferred rescale: s already carries -m_run; move m only when P8 would pass 2^(kPShift + kThr8) = 256
+            if (__any(ex_next > (float)kPShift + kThr8)) {
+                const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
+                const float dm = mn - m_run;
+                m_run = mn;
+                const float alpha = __builtin_amdgcn_exp2f(-dm);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int key = (j & 3) + 8 * (j >> 2);
-                if (key >= rem) s0[j] = -INFINITY;
-                if (key + 32 >= rem) s1[j] = -INFINITY;
+                for (int j = 0; j < 16; ++j) {
+                    s0[j] -= dm; s1[j] -= dm;
+                    o[0][j] *= alpha; o[1][j] *= alpha; lacc[j] *= alpha;
+                }
             }
         }
-        // ---- row maximum, deferred rescale ----
-        float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        {
-            const float m_cand = fmaxf(m_run, mx - (float)kPShift);
-            if (__any((m_cand - m_run) > kThr8)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
-                m_run = m_cand;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { o[0][j] *= alpha; o[1][j] *= alpha; lacc[j] *= alpha; }
-            }
-        }
-        // ---- P8 = e4m3(exp2(s - m)): k-position 16 g + j of half 0 <- s0[j], 32 + 16 g + j <- s1[j] ----
         i32x8_t pf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i] - m_run), __builtin_amdgcn_exp2f(s0[4 * i + 1] - m_run),
-                                   __builtin_amdgcn_exp2f(s0[4 * i + 2] - m_run), __builtin_amdgcn_exp2f(s0[4 * i + 3] - m_run));
-            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i] - m_run), __builtin_amdgcn_exp2f(s1[4 * i + 1] - m_run),
-                                       __builtin_amdgcn_exp2f(s1[4 * i + 2] - m_run), __builtin_amdgcn_exp2f(s1[4 * i + 3] - m_run));
+            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i]), __builtin_amdgcn_exp2f(s0[4 * i + 1]),
+                                   __builtin_amdgcn_exp2f(s0[4 * i + 2]), __builtin_amdgcn_exp2f(s0[4 * i + 3]));
+            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i]), __builtin_amdgcn_exp2f(s1[4 * i + 1]),
+                                       __builtin_amdgcn_exp2f(s1[4 * i + 2]), __builtin_amdgcn_exp2f(s1[4 * i + 3]));
         }
-        // ---- O^T += V^T . P^T (two 32-channel d-tiles) and l^T += ones . P^T ----
+        F8_LOAD(w + 1)
+        {   // the softmax belongs to THIS phase: pin its results here (pure arithmetic otherwise sinks past the barrier)
+            asm volatile("" : "+v"(pf));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= matrix phase =================
+        __builtin_amdgcn_s_setprio(1);
+        if (t + 1 < nt) {
+            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
+            const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
+            f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
+            f32x16_t c1 = T::mfma32(onesv, mnegv, zero16);
+            F8_QK((t + 1) & 1, c0, c1, s0, s1)
+        }
         {
-            const char* vb = sb + kTileK8;
+            const char* vb = smem + kLdsV + (t & 1) * kTileK8;
+            const char* vsb = smem + kLdsVS + (t & 1) * 128;
 #pragma unroll
             for (int dt = 0; dt < kDT; ++dt) {
                 const i32x4_t v0 = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk0(g));
                 const i32x4_t v1 = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk1(g));
-                const int vsb = *reinterpret_cast<const uint8_t*>(sb + 2 * kTileK8 + 128 + (32 * dt + r) * 2 + g);
+                const int vs_ = *reinterpret_cast<const uint8_t*>(vsb + (32 * dt + r) * 2 + g);
                 const i32x8_t vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv, pf, o[dt], 0, 0, 0, vsb, 0, kPs);
+                o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv, pf, o[dt], 0, 0, 0, vs_, 0, kPs);
             }
             lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
         }
-        // ---- stage tile t + 1 ----
         if (t + 1 < nt) {
-            char* nb = smem + ((t + 1) & 1) * kStage8;
-            *reinterpret_cast<uint4*>(nb + st_off) = nxt;
-            if (tid < 64) *reinterpret_cast<uint32_t*>(nb + 2 * kTileK8 + tid * 4) = nxs;
+            F8_MASK(t + 1, s0, s1)
+            const float mx = vmax2(vmax3(F8_MAX8(s0, 0), F8_MAX8(s0, 8), F8_MAX8(s1, 0)), F8_MAX8(s1, 8));
+            F8_SWAPMAX(mx, ex_next)
         }
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef F8_LOAD
+#undef F8_WRITE
+#undef F8_QK
+#undef F8_MASK
+#undef F8_MAX8
+#undef F8_SWAPMAX
 
     // ---- epilogue: every register of lacc holds l of this lane's query (all rows of the ones tile are equal) ----
     float l_run = lacc[0];
     if (part >= 0) {
-        // partial in the 8-wave bf16 kernel's layout: m in the log2 domain WITHOUT the shift (O and l carry 2^kPShift alike)
+        // partial in the bf16 kernels' layout; m, O and l share the 2^kPShift offset, which cancels in the merge
         float* w = p.ws + (int64_t)part * partial_floats<kD8>();
 #pragma unroll
         for (int dt = 0; dt < kDT; ++dt)
@@ -417,7 +504,7 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     p.full_x = groups * p.nqb_v; p.rem_x = 0; p.nwg = 0; p.per = 1;
     fp.k8 = qp.k8; fp.ks = qp.ks; fp.v8t = qp.v8t; fp.vs = qp.vs; fp.nt = nt;
     const dim3 grid((unsigned)(8 * p.full_x));
-    constexpr int smem = 2 * kStage8;
+    constexpr int smem = kSmem8;
     if (dtype == FINO_BF16) attn_fp8_kernel<BF16, 0><<<grid, kWaves * 64, smem, st>>>(fp);
     else attn_fp8_kernel<F16, 0><<<grid, kWaves * 64, smem, st>>>(fp);
     FINO_LAUNCH_CHECK();

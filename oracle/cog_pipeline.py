@@ -45,7 +45,7 @@ def cog_denoise_loop(sd, cfg, latents, image_latents, traj_latents, id_latent, p
             x = torch.cat([x, lid], dim=1)                                         # :868
             img, trj = torch.cat([img, pad], dim=1), torch.cat([trj, pad], dim=1)
         x = torch.cat([x, img, trj], dim=2)                                        # :880
-        pred = cog_forward(sd, cfg, x, prompt, torch.full((2,), float(t)), rotary).float()[:, :nlf]
+        pred = cog_forward(sd, cfg, x, prompt, torch.full((2,), float(t), device=x.device), rotary).float()[:, :nlf]
         g = guidance
         if dynamic_cfg:
             g = 1 + guidance * ((1 - math.cos(math.pi * ((steps - t) / steps) ** 5.0)) / 2)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--mxfp8", action="store_true", help="QKV / out / FFN linears on the MXFP8 path (config 5)")
+    ap.add_argument("--fp8-attention", action="store_true", help="fp8 (e4m3) attention operands (fino_attn_fwd_fp8)")
     ap.add_argument("--w4", action="store_true", help="4-wave head_dim-64 attention kernel with the softmax scale folded into q")
     a = ap.parse_args()
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
@@ -33,6 +34,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1)
     if a.mxfp8:
         m.enable_mxfp8_linears()
+    m.enable_fp8_attention(a.fp8_attention)
     if a.w4:
         from frameino_amd import _lib
         _lib.lib().fino_tune_set(4, 2)
@@ -57,7 +59,7 @@ def main():
     dt = (seen[-1] - seen[a.warmup - 1]) / a.steps if a.warmup else (seen[-1] - seen[0]) / (a.steps - 1)
     L, d, nl = 226 + 14 * 30 * 45, 3072, cfg["num_layers"]
     flops = 2 * nl * (8 * L * d * d + 4 * L * L * d + 16 * L * d * d)          # B=2: proj + SDPA + FFN (4x)
-    print(f"CogVideoX-5B FrameINO 49f 480x720 {'mxfp8 linears + bf16 attention' if a.mxfp8 else 'bf16'}{' + 4-wave folded attention' if a.w4 else ''}: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
+    print(f"CogVideoX-5B FrameINO 49f 480x720 {'mxfp8 linears + bf16 attention' if a.mxfp8 else 'bf16'}{' + 4-wave folded attention' if a.w4 else ''}{' + fp8 attention operands' if a.fp8_attention else ''}: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
           f"{flops / dt / 1e12:.0f} TFLOP/s model ({nl} layers, L={L})")
 
 
