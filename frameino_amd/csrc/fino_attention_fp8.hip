@@ -136,17 +136,54 @@ struct Fp8AttnParams {
     int nt;
 };
 
-// LDS: K8 ring (2 x 4 KiB) | V8T ring (2 x 4 KiB) | K scale ring (2 x 128 B) | V scale ring (2 x 128 B)
-constexpr int kLdsK = 0, kLdsV = 2 * kTileK8, kLdsKS = 4 * kTileK8, kLdsVS = 4 * kTileK8 + 256;
-constexpr int kSmem8 = 4 * kTileK8 + 512;
+// LDS: K8 ring (8 x 4 KiB) | V8T ring (8 x 4 KiB) | K scale ring (8 x 128 B) | V scale ring (8 x 128 B)
+constexpr int kRing8 = 8;
+#ifndef F8_READS_IN_MATRIX
+#define F8_READS_IN_MATRIX 1      // 0: K(t+1) / V(t) fragments are read in the softmax phase, 1: in the matrix phase, 2: K / V split
+#endif
+constexpr int kLdsK = 0, kLdsV = kRing8 * kTileK8, kLdsKS = 2 * kRing8 * kTileK8, kLdsVS = kLdsKS + kRing8 * 128;
+constexpr int kSmem8 = kLdsVS + kRing8 * 128;
 
 // PING-PONG (the structure of attn_pp_kernel, fino_attention.hip): the two waves of a SIMD (w, w + 4) run one phase apart --
 // one in its SOFTMAX phase (exp2, e4m3 packing of P(t), the rescale decision, its share of the K / V staging), the other in
 // its MATRIX phase (S(t+1) = -m + K(t+1).Q^T, O^T += V(t)^T.P(t)^T, l^T += 1.P(t)^T, row maximum of S(t+1) in the MFMAs'
 // shadow); two s_barrier per tile.  The running maximum rides into S as one more product on the matrix pipe ("ones" x (-m),
 // a bf16 MFMA into the same accumulator: m is kept bf16-representable so the product is exact), so the softmax is a bare
-// exp2 + pack.  Staging: K(w + 1) and V(w) may be written during phases 2w - 1 and 2w (their ring slots are free from
-// 2w - 1, they are first read in phase 2w + 1): group g writes its half of both in its softmax phase of tile t = w - g.
+// exp2 + pack.  Staging: rings of eight tiles filled by LDS-DMA; in its softmax phase of tile t a group issues its half of
+// K(t+4) and V(t+4) and, before the barrier, waits for its half of t+3 (issued a whole tile earlier: an L2 hit takes about
+// one phase, anything further more -- with registers and one phase of distance the wait was 450 cycles per tile).  With two
+// tiles of slack the operands of the COMING
+// matrix phase (K(t+1) and V(t) fragments, their scale bytes: 12 LDS reads) are read at the top of the softmax phase and land
+// under the exp2 work: the matrix phase opens with its MFMAs instead of an LDS round trip.
+#ifdef F8_X_STAMP   // s_memtime stamps around the segments of both phases (tools/attn_fp8_stamp.py; experiment build only)
+__device__ unsigned long long fino_attn_f8_dbg[64];
+extern "C" int fino_attn_f8_debug_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_attn_f8_dbg), sizeof(unsigned long long) * 64);
+}
+#define F8STAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define F8STAMP(V_)
+#endif
+
+// max of the 16 registers of an S accumulator, ordered BEHIND the MFMA that produced `behind` (an input the asm never reads:
+// the data dependence is what keeps the compiler from hoisting the statement above that MFMA).  Plain fmaxf on MFMA results
+// costs a canonicalising v_max per input; v_max3 through asm is what the bf16 kernels use as well.
+__device__ __forceinline__ float max16_behind(const f32x16_t& s, float behind) {
+    float a, b;
+    asm("v_max3_f32 %0, %2, %3, %4\n\t"
+        "v_max3_f32 %1, %5, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %1, %1, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %1, %1, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17\n\t"
+        "v_max_f32 %0, %0, %1"
+        : "=&v"(a), "=&v"(b)
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]),
+          "v"(s[10]), "v"(s[11]), "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]), "v"(behind));
+    return a;
+}
+
 template <typename T, int VAR>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,7 +196,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     const int r = lane & 31;
     const int g = lane >> 5;
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    const int tg = tid & 255;                // thread in its group
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -238,51 +274,50 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         q_scale = g == 0 ? sbyte[0] : sbyte[1];
     }
 
-    // ---- staging roles: threads 0..127 of a group move chunk (128 grp + i) of a K8 tile, 128..255 of a V8T tile (16 B
-    //      each); the first 16 of either set also dword (16 grp + i) of that tile's 128 scale bytes ----
-    const bool st_k = tg < 128;
-    const int st_c = grp * 128 + (tg & 127);
-    const bool st_s = (tg & 127) < 16;
-    const uint8_t* st_src = (st_k ? fp.k8 : fp.v8t) + tile0 * kTileK8 + st_c * 16;
-    const uint8_t* st_ssrc = (st_k ? fp.ks : fp.vs) + tile0 * 128 + (grp * 16 + (tg & 15)) * 4;
-    const int st_dst = (st_k ? kLdsK : kLdsV) + st_c * 16;
-    const int st_sdst = (st_k ? kLdsKS : kLdsVS) + (grp * 16 + (tg & 15)) * 4;
-    const int st_add = st_k ? 1 : 0;         // K runs one tile ahead of V
-    uint4 st_reg = make_uint4(0, 0, 0, 0);
-    uint32_t st_sreg = 0;
-#define F8_LOAD(W_)                                                                                          \
+    // ---- staging roles (LDS-DMA, no register round trip): of a group's four waves, 0 / 1 move the group's half of a K8 tile
+    //      (64 lanes x 16 B each), 2 / 3 of the V8T tile; lanes 0..15 of each also the group's half of that tile's 128 scale
+    //      bytes (waves 0 / 1 and 2 / 3 write the same bytes: one vmcnt per wave and tile, whichever wave it is) ----
+    const int wl = __builtin_amdgcn_readfirstlane(wave & 3);
+    const bool st_k = wl < 2;
+    const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((st_k ? fp.k8 : fp.v8t) + tile0 * kTileK8), 0, nt * kTileK8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((st_k ? fp.ks : fp.vs) + tile0 * 128), 0, nt * 128, 0x00020000);
+    const uint32_t st_voff = (uint32_t)((grp * 128 + (wl & 1) * 64 + lane) * 16);
+    const uint32_t st_svoff = (uint32_t)((grp * 16 + (lane & 15)) * 4);
+    const int st_lds = (st_k ? kLdsK : kLdsV) + (grp * 128 + (wl & 1) * 64) * 16;
+    const int st_slds = (st_k ? kLdsKS : kLdsVS) + grp * 64;
+    // tile U_ -> its ring slot; past the last tile: a harmless re-read.  Two vector-memory operations per wave.
+#define F8_DMA(U_)                                                                                           \
     {                                                                                                        \
-        int tt_ = (W_) + st_add;                                                                             \
-        tt_ = tt_ < nt ? tt_ : nt - 1;               /* past the last tile: a harmless re-read */            \
-        st_reg = *reinterpret_cast<const uint4*>(st_src + (int64_t)tt_ * kTileK8);                           \
-        if (st_s) st_sreg = *reinterpret_cast<const uint32_t*>(st_ssrc + (int64_t)tt_ * 128);                \
+        const int tt_ = (U_) < nt ? (U_) : nt - 1;                                                           \
+        const int sl_ = (U_) & (kRing8 - 1);                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st_rsrc, (FINO_LDS void*)(smem + st_lds + sl_ * kTileK8), 16, st_voff, \
+                                                 tt_ * kTileK8, 0, 0);                                       \
+        if (lane < 16)                                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_srsrc, (FINO_LDS void*)(smem + st_slds + sl_ * 128), 4, st_svoff, \
+                                                     tt_ * 128, 0, 0);                                       \
     }
-#define F8_WRITE(W_)                                                                                         \
-    {                                                                                                        \
-        const int sl_ = ((W_) + st_add) & 1;                                                                 \
-        *reinterpret_cast<uint4*>(smem + st_dst + sl_ * kTileK8) = st_reg;                                   \
-        if (st_s) *reinterpret_cast<uint32_t*>(smem + st_sdst + sl_ * 128) = st_sreg;                        \
-    }
-    // ---- prologue: K(0), V(0), K(1) whole (both groups, each its halves) ----
+    // ---- prologue: tiles 0 and 1 whole (512 threads x 16 B = the K8 and V8T tile of one key tile), tile 2 into the
+    //      staging registers ----
     {
-        const uint8_t* k8 = fp.k8 + tile0 * kTileK8;
-        const uint8_t* v8 = fp.v8t + tile0 * kTileK8;
-        const int c = tid;                                   // 512 threads: K(0) = chunks 0..255, V(0) = 256..511
-        const uint4 a0 = *reinterpret_cast<const uint4*>((c < 256 ? k8 : v8) + (c & 255) * 16);
-        *reinterpret_cast<uint4*>(smem + (c < 256 ? kLdsK : kLdsV) + (c & 255) * 16) = a0;
-        if (c < 256) {
-            const int t1 = nt > 1 ? 1 : 0;
-            const uint4 a1 = *reinterpret_cast<const uint4*>(k8 + (int64_t)t1 * kTileK8 + c * 16);
-            *reinterpret_cast<uint4*>(smem + kLdsK + kTileK8 + c * 16) = a1;
+        const int c = tid;                                   // K = chunks 0..255, V = 256..511
+        const int t1 = nt > 1 ? 1 : 0;
+        const uint8_t* src = (c < 256 ? fp.k8 : fp.v8t) + tile0 * kTileK8 + (c & 255) * 16;
+        char* dst = smem + (c < 256 ? kLdsK : kLdsV) + (c & 255) * 16;
+        const uint4 a0 = *reinterpret_cast<const uint4*>(src);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(src + (int64_t)t1 * kTileK8);
+        *reinterpret_cast<uint4*>(dst) = a0;
+        *reinterpret_cast<uint4*>(dst + kTileK8) = a1;
+        if (tid < 128) {                                     // scale bytes: 32 dwords each of KS(0), VS(0), KS(1), VS(1)
+            const int which = tid >> 5, i = tid & 31;
+            const uint8_t* ss = ((which & 1) ? fp.vs : fp.ks) + (tile0 + ((which >> 1) ? t1 : 0)) * 128 + i * 4;
+            *reinterpret_cast<uint32_t*>(smem + ((which & 1) ? kLdsVS : kLdsKS) + (which >> 1) * 128 + i * 4) =
+                *reinterpret_cast<const uint32_t*>(ss);
         }
-        if (tid < 32) *reinterpret_cast<uint32_t*>(smem + kLdsKS + tid * 4) =
-            *reinterpret_cast<const uint32_t*>(fp.ks + tile0 * 128 + tid * 4);
-        else if (tid < 64) *reinterpret_cast<uint32_t*>(smem + kLdsVS + (tid - 32) * 4) =
-            *reinterpret_cast<const uint32_t*>(fp.vs + tile0 * 128 + (tid - 32) * 4);
-        else if (tid < 96 && nt > 1) *reinterpret_cast<uint32_t*>(smem + kLdsKS + 128 + (tid - 64) * 4) =
-            *reinterpret_cast<const uint32_t*>(fp.ks + (tile0 + 1) * 128 + (tid - 64) * 4);
     }
-    if (grp == 1) { F8_LOAD(1) }             // group 1 writes {K(2), V(1)} in its first softmax phase
+    { F8_DMA(2) }
+    { F8_DMA(3) }
     __syncthreads();
 
     f32x16_t o[kDT], lacc;
@@ -295,20 +330,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
     asm volatile("" : "+v"(ones_u.x));
 
-    // K(tile in slot KS_) . Q^T (+ C_) -> two 32-key halves
-#define F8_QK(KS_, C0_, C1_, S0_, S1_)                                                                       \
+    // K(tile in slot KS_) fragments -> registers; K . Q^T (+ C_) -> two 32-key halves
+    i32x4_t ka00, ka01, ka10, ka11;
+    int ks0r, ks1r;
+#define F8_KREAD(KS_)                                                                                        \
     {                                                                                                        \
         const char* kb_ = smem + kLdsK + (KS_) * kTileK8;                                                    \
-        const i32x4_t a00_ = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk0(g));               \
-        const i32x4_t a01_ = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk1(g));               \
-        const i32x4_t a10_ = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk0(g));        \
-        const i32x4_t a11_ = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk1(g));        \
-        const int ks0_ = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + r * 2 + g);         \
-        const int ks1_ = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + (32 + r) * 2 + g);  \
-        const i32x8_t k0_ = __builtin_shufflevector(a00_, a01_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
-        const i32x8_t k1_ = __builtin_shufflevector(a10_, a11_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
-        S0_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0_, qf, C0_, 0, 0, 0, ks0_, 0, q_scale);      \
-        S1_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1_, qf, C1_, 0, 0, 0, ks1_, 0, q_scale);      \
+        ka00 = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk0(g));                             \
+        ka01 = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk1(g));                             \
+        ka10 = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk0(g));                      \
+        ka11 = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk1(g));                      \
+        ks0r = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + r * 2 + g);                   \
+        ks1r = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + (32 + r) * 2 + g);            \
+    }
+#define F8_QK(C0_, C1_, S0_, S1_)                                                                            \
+    {                                                                                                        \
+        const i32x8_t k0_ = __builtin_shufflevector(ka00, ka01, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        const i32x8_t k1_ = __builtin_shufflevector(ka10, ka11, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        S0_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0_, qf, C0_, 0, 0, 0, ks0r, 0, q_scale);      \
+        S1_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1_, qf, C1_, 0, 0, 0, ks1r, 0, q_scale);      \
     }
     // keys past lk (zero rows of a ragged last tile): out of the maximum, p = exp2(-inf) = 0
 #define F8_MASK(T_, S0_, S1_)                                                                                \
@@ -331,11 +371,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
 
     // ---- S(0) unpipelined; m_run = the value SUBTRACTED from s (running maximum minus kPShift, T-representable) ----
     f32x16_t s0, s1;
-    F8_QK(0, zero16, zero16, s0, s1)
+    F8_KREAD(0)
+    F8_QK(zero16, zero16, s0, s1)
     F8_MASK(0, s0, s1)
     float m_run;
     {
-        float mx = vmax2(vmax3(F8_MAX8(s0, 0), F8_MAX8(s0, 8), F8_MAX8(s1, 0)), F8_MAX8(s1, 8));
+        // fmaxf here, not the asm v_max3 of F8_MAX8: the compiler places the MFMA -> VALU wait states for what it can see;
+        // an asm reading an accumulator right behind its MFMA gets none (and reads the register before the write-back)
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
         float mxx;
         F8_SWAPMAX(mx, mxx)
         m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
@@ -345,10 +390,39 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     float ex_next = 0.f;                      // max over the tile of (s - m_run): what may exceed 8
     if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
 
+#if defined(F8_X_NOBAR)
+#define F8_BARRIER() asm volatile("" ::: "memory")
+#else
+#define F8_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef F8_X_STAMP
+    unsigned long long ts0 = 0, tsa = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa[6] = {0, 0, 0, 0, 0, 0};
+#endif
     for (int t = 0; t < nt; ++t) {
+        F8STAMP(ts0)
         // ================= softmax phase =================
-        const int w = t + grp;
-        if (w >= 1) { F8_WRITE(w) }
+        // operands of the coming matrix phase first (they land under the exp2 work), then this group's half of tile t + 2
+        i32x4_t vf0[kDT], vf1[kDT];
+        int vsr[kDT];
+#define F8_PREFETCH_K() { F8_KREAD((t + 1) & (kRing8 - 1)) }
+#define F8_PREFETCH_V()                                                                                      \
+        {                                                                                                    \
+            const char* vb = smem + kLdsV + (t & (kRing8 - 1)) * kTileK8;                                    \
+            const char* vsb = smem + kLdsVS + (t & (kRing8 - 1)) * 128;                                      \
+            _Pragma("unroll") for (int dt = 0; dt < kDT; ++dt) {                                             \
+                vf0[dt] = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk0(g));       \
+                vf1[dt] = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk1(g));       \
+                vsr[dt] = *reinterpret_cast<const uint8_t*>(vsb + (32 * dt + r) * 2 + g);                    \
+            }                                                                                                \
+        }
+#if F8_READS_IN_MATRIX == 0
+        F8_PREFETCH_K()
+        F8_PREFETCH_V()
+#elif F8_READS_IN_MATRIX == 2
+        F8_PREFETCH_K()
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        F8STAMP(tsa)
         {
             // deferred rescale: s already carries -m_run; move m only when P8 would pass 2^(kPShift + kThr8) = 256
             if (__any(ex_next > (float)kPShift + kThr8)) {
@@ -364,58 +438,116 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
             }
         }
         i32x8_t pf;
+#if defined(F8_X_NOEXP)                       // timing experiments (wrong results; fino_common.h ties them to FINO_EXPERIMENT)
+#define F8_EXP(X_) (X_)
+#else
+#define F8_EXP(X_) __builtin_amdgcn_exp2f(X_)
+#endif
+#if defined(F8_X_NOPACK)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i]), __builtin_amdgcn_exp2f(s0[4 * i + 1]),
-                                   __builtin_amdgcn_exp2f(s0[4 * i + 2]), __builtin_amdgcn_exp2f(s0[4 * i + 3]));
-            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i]), __builtin_amdgcn_exp2f(s1[4 * i + 1]),
-                                       __builtin_amdgcn_exp2f(s1[4 * i + 2]), __builtin_amdgcn_exp2f(s1[4 * i + 3]));
+            float e0 = F8_EXP(s0[4 * i]) + F8_EXP(s0[4 * i + 1]), e1 = F8_EXP(s0[4 * i + 2]) + F8_EXP(s0[4 * i + 3]);
+            float e2 = F8_EXP(s1[4 * i]) + F8_EXP(s1[4 * i + 1]), e3 = F8_EXP(s1[4 * i + 2]) + F8_EXP(s1[4 * i + 3]);
+            asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+            pf[i] = 0x38383838; pf[4 + i] = 0x38383838;
         }
-        F8_LOAD(w + 1)
+#else
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pf[i] = (int)pack4_fp8(F8_EXP(s0[4 * i]), F8_EXP(s0[4 * i + 1]), F8_EXP(s0[4 * i + 2]), F8_EXP(s0[4 * i + 3]));
+            pf[4 + i] = (int)pack4_fp8(F8_EXP(s1[4 * i]), F8_EXP(s1[4 * i + 1]), F8_EXP(s1[4 * i + 2]), F8_EXP(s1[4 * i + 3]));
+        }
+#endif
+#undef F8_EXP
+#if !defined(F8_X_NOSTAGE)
+        F8_DMA(t + 4)
+#endif
         {   // the softmax belongs to THIS phase: pin its results here (pure arithmetic otherwise sinks past the barrier)
             asm volatile("" : "+v"(pf));
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        F8STAMP(ts1)
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");     // tile t + 3 (issued a tile ago) has landed
+        F8_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
+        F8STAMP(ts2)
         // ================= matrix phase =================
+        // S(t+1) is computed for every t (past the last tile the K ring holds an older tile and the result is dropped).
+        // The row maximum of S(t+1) runs in the shadow of the P.V MFMAs and only BEHIND them in program order
+        // (max16_behind): v_max3 through asm gets no MFMA -> VALU wait states from the compiler, so each half is read
+        // after a LATER MFMA has issued (the pipe is in order: by then the half has been written back).
         __builtin_amdgcn_s_setprio(1);
-        if (t + 1 < nt) {
+#if F8_READS_IN_MATRIX == 1
+        F8_PREFETCH_K()
+        F8_PREFETCH_V()
+#elif F8_READS_IN_MATRIX == 2
+        F8_PREFETCH_V()
+#endif
+        {
             uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
             const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
-            f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
-            f32x16_t c1 = T::mfma32(onesv, mnegv, zero16);
-            F8_QK((t + 1) & 1, c0, c1, s0, s1)
+#if defined(F8_X_NOOPENER)
+            asm volatile("" :: "v"(mnegv), "v"(onesv));
+            const f32x16_t c0 = zero16;
+#else
+            const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
+#endif
+#if !defined(F8_X_NOQK)
+            F8_QK(c0, c0, s0, s1)
+#else
+            s0 = c0; s1 = c0;
+#endif
         }
-        {
-            const char* vb = smem + kLdsV + (t & 1) * kTileK8;
-            const char* vsb = smem + kLdsVS + (t & 1) * 128;
-#pragma unroll
-            for (int dt = 0; dt < kDT; ++dt) {
-                const i32x4_t v0 = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk0(g));
-                const i32x4_t v1 = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk1(g));
-                const int vs_ = *reinterpret_cast<const uint8_t*>(vsb + (32 * dt + r) * 2 + g);
-                const i32x8_t vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv, pf, o[dt], 0, 0, 0, vs_, 0, kPs);
-            }
-            lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
+#define F8_PV(DT_)                                                                                           \
+        {                                                                                                    \
+            const i32x8_t vv_ = __builtin_shufflevector(vf0[DT_], vf1[DT_], 0, 1, 2, 3, 4, 5, 6, 7);         \
+            o[DT_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv_, pf, o[DT_], 0, 0, 0, vsr[DT_], 0, kPs); \
         }
-        if (t + 1 < nt) {
-            F8_MASK(t + 1, s0, s1)
-            const float mx = vmax2(vmax3(F8_MAX8(s0, 0), F8_MAX8(s0, 8), F8_MAX8(s1, 0)), F8_MAX8(s1, 8));
-            F8_SWAPMAX(mx, ex_next)
-        }
+#if defined(F8_X_NOPV)
+        asm volatile("" :: "v"(vf0[0]), "v"(vf1[0]), "v"(vf0[1]), "v"(vf1[1]), "v"(vsr[0]), "v"(vsr[1]), "v"(pf));
+        F8_MASK(t + 1, s0, s1)
+        float mxa = max16_behind(s0, s1[0]);
+        const float mxb = max16_behind(s1, mxa);
+#elif defined(F8_X_NOMAX)
+        F8_PV(0)
+        F8_PV(1)
+        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
+        float mxa = s0[0], mxb = s1[0];
+#else
+        F8_PV(0)
+        F8_MASK(t + 1, s0, s1)
+        float mxa = max16_behind(s0, o[0][0]);          // behind P.V (d-tile 0): S0 was written back two MFMAs ago
+        F8_PV(1)
+        const float mxb = max16_behind(s1, o[1][0]);    // behind P.V (d-tile 1)
+        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
+#endif
+        mxa = vmax2(mxa, mxb);
+        F8_SWAPMAX(mxa, ex_next)
+#undef F8_PV
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        F8STAMP(ts3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        F8_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef F8_X_STAMP
+        F8STAMP(ts4)
+        sa[0] += tsa - ts0; sa[1] += ts1 - tsa; sa[2] += ts2 - ts1; sa[3] += ts3 - ts2; sa[4] += ts4 - ts3;
+#endif
     }
+#ifdef F8_X_STAMP
+    if (blockIdx.x == 40 && lane == 0) {
+        for (int i = 0; i < 5; ++i) fino_attn_f8_dbg[wave * 8 + i] = sa[i];
+        fino_attn_f8_dbg[wave * 8 + 5] = (unsigned long long)nt;
+    }
+#endif
     if (grp == 0) __builtin_amdgcn_s_barrier();
-#undef F8_LOAD
-#undef F8_WRITE
+#undef F8_DMA
+#undef F8_PREFETCH_K
+#undef F8_PREFETCH_V
 #undef F8_QK
+#undef F8_KREAD
+#undef F8_BARRIER
 #undef F8_MASK
 #undef F8_MAX8
 #undef F8_SWAPMAX
@@ -505,6 +637,13 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     fp.k8 = qp.k8; fp.ks = qp.ks; fp.v8t = qp.v8t; fp.vs = qp.vs; fp.nt = nt;
     const dim3 grid((unsigned)(8 * p.full_x));
     constexpr int smem = kSmem8;
+    {   // 66 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
+        static FinoPerDeviceOnce once_bf16, once_f16;
+        const int rc = dtype == FINO_BF16
+            ? fino_max_smem_once(once_bf16, (const void*)attn_fp8_kernel<BF16, 0>, smem, "fino_attn_fwd_fp8")
+            : fino_max_smem_once(once_f16, (const void*)attn_fp8_kernel<F16, 0>, smem, "fino_attn_fwd_fp8");
+        if (rc != FINO_OK) return rc;
+    }
     if (dtype == FINO_BF16) attn_fp8_kernel<BF16, 0><<<grid, kWaves * 64, smem, st>>>(fp);
     else attn_fp8_kernel<F16, 0><<<grid, kWaves * 64, smem, st>>>(fp);
     FINO_LAUNCH_CHECK();

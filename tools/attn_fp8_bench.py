@@ -19,6 +19,8 @@ o = torch.empty_like(q)
 runs = {"bf16 8-wave": lambda: ops.attention(q, k, v, heads, out=o),
         "bf16 4-wave folded": lambda: ops.attention(qs, k, v, heads, out=o, scale=ops.SCALE_FOLDED),
         "fp8 operands": lambda: ops.attention_fp8(q, k, v, heads, out=o)}
+if os.environ.get("FINO_FP8_ONLY"):           # timing-experiment builds (tools/attn_fp8_variants.sh): that kernel alone
+    runs = {"fp8 operands": runs["fp8 operands"]}
 rows = torch.tensor(sorted(set(torch.randint(0, L, (24,)).tolist()) | {0, L - 1}), device=dev)
 qh = q[0, rows].float().view(len(rows), heads, 64).transpose(0, 1)
 kh, vh = k[0].float().view(L, heads, 64).transpose(0, 1), v[0].float().view(L, heads, 64).transpose(0, 1)
