@@ -39,6 +39,10 @@ constexpr int kTileK8 = kKV * kD8;           // 4096 B: K8 tile / V8T tile
 // is the scale of K-block g (k in [32 g, 32 g + 32)) -- the 16x16x128 form's rule, re-probed for 32x32x64.
 __device__ __forceinline__ int chunk0(int g) { return g; }
 __device__ __forceinline__ int chunk1(int g) { return 2 + g; }
+// LDS image of a K8 / V8T tile: 64 rows of 64 bytes.  A ds_read_b128 serves 16 lanes at a time (one 16-byte chunk of 16
+// consecutive rows here): rows r and r + 4 share their banks (4 x 64 B = the 256-byte bank line), a 4-way conflict unless
+// the chunk position is permuted by the row: position = chunk ^ swz8(row).  (Rows 32 + r: the same permutation as r.)
+__device__ __forceinline__ int swz8(int row) { return (row >> 2) & 3; }
 
 // key of k-position kappa (0..63) of a V8T row / of P's B operand: kappa = 32 * half + 16 * g + j
 __host__ __device__ __forceinline__ int slot_key(int kappa) {
@@ -283,7 +287,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         (void*)((st_k ? fp.k8 : fp.v8t) + tile0 * kTileK8), 0, nt * kTileK8, 0x00020000);
     const __amdgpu_buffer_rsrc_t st_srsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((st_k ? fp.ks : fp.vs) + tile0 * 128), 0, nt * 128, 0x00020000);
-    const uint32_t st_voff = (uint32_t)((grp * 128 + (wl & 1) * 64 + lane) * 16);
+    // LDS position P (16-byte slot of the tile image; row = P >> 2) receives chunk (P & 3) ^ swz(row) of that row: the DMA
+    // writes lane-linear, so the permutation is applied to the SOURCE offset (swz8 below: 64-byte rows, conflict-free reads)
+    const int st_pos = grp * 128 + (wl & 1) * 64 + lane;
+    const uint32_t st_voff = (uint32_t)((st_pos >> 2) * 64 + (((st_pos & 3) ^ swz8(st_pos >> 2)) << 4));
     const uint32_t st_svoff = (uint32_t)((grp * 16 + (lane & 15)) * 4);
     const int st_lds = (st_k ? kLdsK : kLdsV) + (grp * 128 + (wl & 1) * 64) * 16;
     const int st_slds = (st_k ? kLdsKS : kLdsVS) + grp * 64;
@@ -298,26 +305,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
             __builtin_amdgcn_raw_ptr_buffer_load_lds(st_srsrc, (FINO_LDS void*)(smem + st_slds + sl_ * 128), 4, st_svoff, \
                                                      tt_ * 128, 0, 0);                                       \
     }
-    // ---- prologue: tiles 0 and 1 whole (512 threads x 16 B = the K8 and V8T tile of one key tile), tile 2 into the
-    //      staging registers ----
-    {
-        const int c = tid;                                   // K = chunks 0..255, V = 256..511
-        const int t1 = nt > 1 ? 1 : 0;
-        const uint8_t* src = (c < 256 ? fp.k8 : fp.v8t) + tile0 * kTileK8 + (c & 255) * 16;
-        char* dst = smem + (c < 256 ? kLdsK : kLdsV) + (c & 255) * 16;
-        const uint4 a0 = *reinterpret_cast<const uint4*>(src);
-        const uint4 a1 = *reinterpret_cast<const uint4*>(src + (int64_t)t1 * kTileK8);
-        *reinterpret_cast<uint4*>(dst) = a0;
-        *reinterpret_cast<uint4*>(dst + kTileK8) = a1;
-        if (tid < 128) {                                     // scale bytes: 32 dwords each of KS(0), VS(0), KS(1), VS(1)
-            const int which = tid >> 5, i = tid & 31;
-            const uint8_t* ss = ((which & 1) ? fp.vs : fp.ks) + (tile0 + ((which >> 1) ? t1 : 0)) * 128 + i * 4;
-            *reinterpret_cast<uint32_t*>(smem + ((which & 1) ? kLdsVS : kLdsKS) + (which >> 1) * 128 + i * 4) =
-                *reinterpret_cast<const uint32_t*>(ss);
-        }
-    }
+    // ---- prologue: tiles 0 .. 3 by the same DMA (each group its halves); 0 and 1 must have landed before the loop ----
+    { F8_DMA(0) }
+    { F8_DMA(1) }
     { F8_DMA(2) }
     { F8_DMA(3) }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
 
     f32x16_t o[kDT], lacc;
@@ -336,10 +329,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
 #define F8_KREAD(KS_)                                                                                        \
     {                                                                                                        \
         const char* kb_ = smem + kLdsK + (KS_) * kTileK8;                                                    \
-        ka00 = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk0(g));                             \
-        ka01 = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * chunk1(g));                             \
-        ka10 = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk0(g));                      \
-        ka11 = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * chunk1(g));                      \
+        ka00 = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * (chunk0(g) ^ swz8(r)));                             \
+        ka01 = *reinterpret_cast<const i32x4_t*>(kb_ + r * 64 + 16 * (chunk1(g) ^ swz8(r)));                             \
+        ka10 = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * (chunk0(g) ^ swz8(r)));                      \
+        ka11 = *reinterpret_cast<const i32x4_t*>(kb_ + (32 + r) * 64 + 16 * (chunk1(g) ^ swz8(r)));                      \
         ks0r = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + r * 2 + g);                   \
         ks1r = *reinterpret_cast<const uint8_t*>(smem + kLdsKS + (KS_) * 128 + (32 + r) * 2 + g);            \
     }
@@ -410,8 +403,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
             const char* vb = smem + kLdsV + (t & (kRing8 - 1)) * kTileK8;                                    \
             const char* vsb = smem + kLdsVS + (t & (kRing8 - 1)) * 128;                                      \
             _Pragma("unroll") for (int dt = 0; dt < kDT; ++dt) {                                             \
-                vf0[dt] = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk0(g));       \
-                vf1[dt] = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * chunk1(g));       \
+                vf0[dt] = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * (chunk0(g) ^ swz8(r)));       \
+                vf1[dt] = *reinterpret_cast<const i32x4_t*>(vb + (32 * dt + r) * 64 + 16 * (chunk1(g) ^ swz8(r)));       \
                 vsr[dt] = *reinterpret_cast<const uint8_t*>(vsb + (32 * dt + r) * 2 + g);                    \
             }                                                                                                \
         }
