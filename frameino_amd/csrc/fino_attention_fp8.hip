@@ -159,6 +159,51 @@ constexpr int kSmem8 = kLdsVS + kRing8 * 128;
 // tiles of slack the operands of the COMING
 // matrix phase (K(t+1) and V(t) fragments, their scale bytes: 12 LDS reads) are read at the top of the softmax phase and land
 // under the exp2 work: the matrix phase opens with its MFMAs instead of an LDS round trip.
+// Q row -> e4m3 B operand: lane (row r, group g) holds channels 16 g .. 16 g + 15 and 32 + 16 g .. + 15, pre-scaled, with
+// one scale per 32-channel block (block b = channels [32 b, 32 b + 32): half of it sits in the partner lane); q_scale =
+// the scale byte of block g (the operand this lane group supplies).  Rows past lq: zeros.
+template <typename T>
+__device__ __forceinline__ void load_q_fp8(const AttnParams& p, const uint16_t* qp, int qrow, int g, i32x8_t& qf,
+                                           int& q_scale) {
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+    {
+        float x[2][16];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = c == 0 ? chunk0(g) : chunk1(g);
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ch + 8 * hlf);
+                if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);
+                float f[8];
+                unpack8<T>(u, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c][8 * hlf + e] = f[e] * p.scale_log2;
+            }
+        }
+        float am[2] = {0.f, 0.f};             // my share of block 0 (chunk c = 0) and block 1 (c = 1)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) am[c] = fmaxf(am[c], fabsf(x[c][e]));
+        int sbyte[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(am[c]), __float_as_uint(am[c]), false, false);
+            sbyte[c] = e8m0_of_amax(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float inv = __builtin_amdgcn_ldexpf(1.0f, 127 - sbyte[c]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                qf[4 * c + i] = (int)pack4_fp8(x[c][4 * i] * inv, x[c][4 * i + 1] * inv, x[c][4 * i + 2] * inv,
+                                               x[c][4 * i + 3] * inv);
+        }
+        q_scale = g == 0 ? sbyte[0] : sbyte[1];
+    }
+}
+
 #ifdef F8_X_STAMP   // s_memtime stamps around the segments of both phases (tools/attn_fp8_stamp.py; experiment build only)
 __device__ unsigned long long fino_attn_f8_dbg[64];
 extern "C" int fino_attn_f8_debug_read(unsigned long long* out) {
@@ -238,45 +283,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     // ---- Q: lane (row r, group g) holds channels 16 g .. 16 g + 15 and 32 + 16 g .. + 15, pre-scaled, as e4m3 with one
     //      scale per 32-channel block (block b = channels [32 b, 32 b + 32): half of it sits in the partner lane) ----
     const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
-    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
     i32x8_t qf;
-    int q_scale;                              // scale byte of block g (the operand this lane group supplies)
-    {
-        float x[2][16];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int ch = c == 0 ? chunk0(g) : chunk1(g);
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ch + 8 * hlf);
-                if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);
-                float f[8];
-                unpack8<T>(u, f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[c][8 * hlf + e] = f[e] * p.scale_log2;
-            }
-        }
-        float am[2] = {0.f, 0.f};             // my share of block 0 (chunk c = 0) and block 1 (c = 1)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) am[c] = fmaxf(am[c], fabsf(x[c][e]));
-        int sbyte[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(am[c]), __float_as_uint(am[c]), false, false);
-            sbyte[c] = e8m0_of_amax(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float inv = __builtin_amdgcn_ldexpf(1.0f, 127 - sbyte[c]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                qf[4 * c + i] = (int)pack4_fp8(x[c][4 * i] * inv, x[c][4 * i + 1] * inv, x[c][4 * i + 2] * inv,
-                                               x[c][4 * i + 3] * inv);
-        }
-        q_scale = g == 0 ? sbyte[0] : sbyte[1];
-    }
+    int q_scale;
+    load_q_fp8<T>(p, qp, qrow, g, qf, q_scale);
 
     // ---- staging roles (LDS-DMA, no register round trip): of a group's four waves, 0 / 1 move the group's half of a K8 tile
     //      (64 lanes x 16 B each), 2 / 3 of the V8T tile; lanes 0..15 of each also the group's half of that tile's 128 scale
@@ -577,6 +586,233 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
   }   // piece
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// FREE-RUNNING variant: 4 waves x 32 query rows per workgroup, THREE workgroups per CU (<= 168 registers), one barrier per
+// key tile.  A wave of this loop is bound by its own issue rate (tools/ubench/valu_rate.hip: one vector instruction per
+// ~4.9 cycles, v_exp_f32 and v_cvt_pk_fp8_f32 ~8.9, whatever the other waves of the SIMD do) and by the latencies in its
+// dependency chain (S -> max -> exp2 -> pack -> P.V), not by a pipe: three waves per SIMD that drift apart freely fill each
+// other's gaps, where the ping-pong kernel's two waves wait for each other at two barriers per tile.
+// Staging: rings of four tiles by LDS-DMA, three operations per wave and tile (its quarter of K8, of V8T, one of the two
+// scale blocks), issued three tiles ahead, awaited one tile later.
+constexpr int kFrWaves = 4;
+constexpr int kFrQBlock = kFrWaves * kQRowsPerWave;     // 128
+constexpr int kFrRing = 4;
+constexpr int kFrLdsK = 0, kFrLdsV = kFrRing * kTileK8, kFrLdsKS = 2 * kFrRing * kTileK8, kFrLdsVS = kFrLdsKS + kFrRing * 128;
+constexpr int kFrSmem = kFrLdsVS + kFrRing * 128;       // 33 KiB
+
+template <typename T>
+__global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8AttnParams fp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AttnParams& p = fp.a;
+    constexpr int kDT = kD8 / 32;
+    typedef typename T::vec8 vec8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int g = lane >> 5;
+    const int xcd = blockIdx.x & 7;
+    const int bx = blockIdx.x >> 3;
+    int hb, qb;
+    if (!attn_map_block(p, xcd, bx, hb, qb)) return;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    const int64_t tile0 = (int64_t)hb * fp.nt;
+    const int nt = fp.nt;
+    const int lk = p.lk;
+
+    const int qrow = qb * kFrQBlock + wave * kQRowsPerWave + r;
+    i32x8_t qf;
+    int q_scale;
+    load_q_fp8<T>(p, qp, qrow, g, qf, q_scale);
+
+    // ---- staging: wave w moves LDS positions 64 w .. 64 w + 63 (16-byte slots) of the K8 and of the V8T image, and (lanes
+    //      0..31) the K scales (waves 0, 2) or the V scales (waves 1, 3): three vector-memory operations per wave and tile ----
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.k8 + tile0 * kTileK8), 0, nt * kTileK8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(fp.v8t + tile0 * kTileK8), 0, nt * kTileK8, 0x00020000);
+    const bool sc_k = (wave & 1) == 0;
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((sc_k ? fp.ks : fp.vs) + tile0 * 128), 0, nt * 128, 0x00020000);
+    const int st_pos = wave * 64 + lane;
+    const uint32_t st_voff = (uint32_t)((st_pos >> 2) * 64 + (((st_pos & 3) ^ swz8(st_pos >> 2)) << 4));
+    const int st_slds = sc_k ? kFrLdsKS : kFrLdsVS;
+#define FR_DMA(U_)                                                                                           \
+    {                                                                                                        \
+        const int tt_ = (U_) < nt ? (U_) : nt - 1;                                                           \
+        const int sl_ = (U_) & (kFrRing - 1);                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (FINO_LDS void*)(smem + kFrLdsK + sl_ * kTileK8 + wave * 1024), 16, \
+                                                 st_voff, tt_ * kTileK8, 0, 0);                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (FINO_LDS void*)(smem + kFrLdsV + sl_ * kTileK8 + wave * 1024), 16, \
+                                                 st_voff, tt_ * kTileK8, 0, 0);                              \
+        if (lane < 32) {   /* dword (lane) of the scale block; the offset is rebuilt here, not kept in a register */ \
+            uint32_t sv_;                                                                                    \
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0" : "=v"(sv_));                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (FINO_LDS void*)(smem + st_slds + sl_ * 128), 4, sv_ << 2, \
+                                                     tt_ * 128, 0, 0);                                       \
+        }                                                                                                    \
+    }
+    { FR_DMA(0) }
+    { FR_DMA(1) }
+    { FR_DMA(2) }
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");          // tiles 0 and 1
+    __syncthreads();
+
+    f32x16_t o[kDT], lacc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { o[0][j] = 0.f; o[1][j] = 0.f; lacc[j] = 0.f; }
+    i32x8_t ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+    constexpr int kOne = 127, kPs = 127 - kPShift;
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
+    asm volatile("" : "+v"(ones_u.x));
+
+    // per-lane byte offsets of the two 16-byte chunks of row r inside a tile image (rows 32 + r: + 2048)
+    const int la0 = r * 64 + 16 * (chunk0(g) ^ swz8(r));
+    const int la1 = r * 64 + 16 * (chunk1(g) ^ swz8(r));
+    const int ls0 = r * 2 + g;                               // scale byte of row r (rows 32 + r: + 64)
+    i32x4_t ka00, ka01, ka10, ka11;
+    int ks0r, ks1r;
+#define FR_KREAD(SL_)                                                                                        \
+    {                                                                                                        \
+        const char* kb_ = smem + kFrLdsK + (SL_) * kTileK8;                                                  \
+        ka00 = *reinterpret_cast<const i32x4_t*>(kb_ + la0);                                                 \
+        ka01 = *reinterpret_cast<const i32x4_t*>(kb_ + la1);                                                 \
+        ka10 = *reinterpret_cast<const i32x4_t*>(kb_ + 2048 + la0);                                          \
+        ka11 = *reinterpret_cast<const i32x4_t*>(kb_ + 2048 + la1);                                          \
+        ks0r = *reinterpret_cast<const uint8_t*>(smem + kFrLdsKS + (SL_) * 128 + ls0);                       \
+        ks1r = *reinterpret_cast<const uint8_t*>(smem + kFrLdsKS + (SL_) * 128 + 64 + ls0);                  \
+    }
+#define FR_QK(C0_, C1_, S0_, S1_)                                                                            \
+    {                                                                                                        \
+        const i32x8_t k0_ = __builtin_shufflevector(ka00, ka01, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        const i32x8_t k1_ = __builtin_shufflevector(ka10, ka11, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        S0_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0_, qf, C0_, 0, 0, 0, ks0r, 0, q_scale);      \
+        S1_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1_, qf, C1_, 0, 0, 0, ks1r, 0, q_scale);      \
+    }
+#define FR_MASK(T_, S0_, S1_)                                                                                \
+    if (__builtin_expect((T_) == nt - 1 && (lk & (kKV - 1)), 0)) {                                           \
+        int rem_ = lk - (T_) * kKV - 4 * g;                                                                  \
+        asm volatile("" : "+v"(rem_));                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                  \
+            const int key_ = (j_ & 3) + 8 * (j_ >> 2);                                                       \
+            if (key_ >= rem_) S0_[j_] = -INFINITY;                                                           \
+            if (key_ + 32 >= rem_) S1_[j_] = -INFINITY;                                                      \
+        }                                                                                                    \
+    }
+#define FR_SWAPMAX(MX_, OUT_)                                                                                \
+    {                                                                                                        \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(MX_), __float_as_uint(MX_), false, false); \
+        OUT_ = vmax2(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                      \
+    }
+
+    // ---- S(0) unpipelined ----
+    f32x16_t s0, s1;
+    FR_KREAD(0)
+    FR_QK(zero16, zero16, s0, s1)
+    FR_MASK(0, s0, s1)
+    float m_run;
+    {
+        float mx = fmaxf(s0[0], s1[0]);                       // fmaxf: see the ping-pong kernel (MFMA -> VALU wait states)
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
+        float mxx;
+        FR_SWAPMAX(mx, mxx)
+        m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s0[j] -= m_run; s1[j] -= m_run; }
+    }
+    float ex_next = 0.f;
+
+    for (int t = 0; t < nt; ++t) {
+        // tile t + 3 into the slot tile t - 1 left (its last reads ended before the previous barrier)
+        FR_DMA(t + 3)
+        // K fragments of S(t+1): they land under the exp2 work
+        FR_KREAD((t + 1) & (kFrRing - 1))
+        if (__any(ex_next > (float)kPShift + kThr8)) {        // deferred rescale (see the ping-pong kernel)
+            const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
+            const float dm = mn - m_run;
+            m_run = mn;
+            const float alpha = __builtin_amdgcn_exp2f(-dm);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                s0[j] -= dm; s1[j] -= dm;
+                o[0][j] *= alpha; o[1][j] *= alpha; lacc[j] *= alpha;
+            }
+        }
+        i32x8_t pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i]), __builtin_amdgcn_exp2f(s0[4 * i + 1]),
+                                   __builtin_amdgcn_exp2f(s0[4 * i + 2]), __builtin_amdgcn_exp2f(s0[4 * i + 3]));
+            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i]), __builtin_amdgcn_exp2f(s1[4 * i + 1]),
+                                       __builtin_amdgcn_exp2f(s1[4 * i + 2]), __builtin_amdgcn_exp2f(s1[4 * i + 3]));
+        }
+        {
+            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
+            const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
+            const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
+            FR_QK(c0, c0, s0, s1)
+        }
+        // V fragments only now: they take the registers the K fragments leave (168 registers per wave is the whole budget
+        // of three waves per SIMD) and land under the two S MFMAs and the other waves' work
+        __builtin_amdgcn_sched_barrier(0);
+        i32x4_t vf0[kDT], vf1[kDT];
+        int vsr[kDT];
+        {
+            const char* vb = smem + kFrLdsV + (t & (kFrRing - 1)) * kTileK8;
+            const char* vsb = smem + kFrLdsVS + (t & (kFrRing - 1)) * 128;
+#pragma unroll
+            for (int dt = 0; dt < kDT; ++dt) {
+                vf0[dt] = *reinterpret_cast<const i32x4_t*>(vb + dt * 2048 + la0);
+                vf1[dt] = *reinterpret_cast<const i32x4_t*>(vb + dt * 2048 + la1);
+                vsr[dt] = *reinterpret_cast<const uint8_t*>(vsb + dt * 64 + ls0);
+            }
+        }
+#define FR_PV(DT_)                                                                                           \
+        {                                                                                                    \
+            const i32x8_t vv_ = __builtin_shufflevector(vf0[DT_], vf1[DT_], 0, 1, 2, 3, 4, 5, 6, 7);         \
+            o[DT_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv_, pf, o[DT_], 0, 0, 0, vsr[DT_], 0, kPs); \
+        }
+        FR_PV(0)
+        FR_MASK(t + 1, s0, s1)
+        float mxa = max16_behind(s0, o[0][0]);
+        FR_PV(1)
+        const float mxb = max16_behind(s1, o[1][0]);
+        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
+        mxa = vmax2(mxa, mxb);
+        FR_SWAPMAX(mxa, ex_next)
+#undef FR_PV
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     // tile t + 2 has landed (t + 3 may be in flight)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FR_DMA
+#undef FR_KREAD
+#undef FR_QK
+#undef FR_MASK
+#undef FR_SWAPMAX
+
+    const float inv = 1.0f / lacc[0];
+    if (qrow < p.lq) {
+        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = dt * 32 + 8 * gq + 4 * g;
+                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * gq + 0] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * gq + 1] * inv) << 16);
+                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * gq + 2] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * gq + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t fino_attn_fp8_kv_bytes(int batch, int heads, int64_t lk, int head_dim) {
@@ -622,13 +858,21 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = head_dim; p.k_bs = p.k_rs = p.k_hs = p.v_bs = p.v_rs = p.v_hs = 0;
     p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = head_dim;
     p.scale_log2 = scale == FINO_ATTN_SCALE_FOLDED ? 1.0f : scale * 1.4426950408889634f;
-    p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
+    const bool free_running = fino_tune_get(FINO_TUNE_ATTN_FP8_KERNEL) != 1;       // default: the free-running kernel
+    const int qblock = free_running ? kFrQBlock : kQBlock;
+    p.nqb = (int)((lq + qblock - 1) / qblock);
     p.ws = nullptr; p.all_partial = 0;
     attn_virtual_heads(p.batch, p.heads, p.nqb, p.vsplit, p.nqb_v);
     const int groups = (p.batch * p.heads * p.vsplit + 7) / 8;
     p.full_x = groups * p.nqb_v; p.rem_x = 0; p.nwg = 0; p.per = 1;
     fp.k8 = qp.k8; fp.ks = qp.ks; fp.v8t = qp.v8t; fp.vs = qp.vs; fp.nt = nt;
     const dim3 grid((unsigned)(8 * p.full_x));
+    if (free_running) {
+        if (dtype == FINO_BF16) attn_fp8_fr_kernel<BF16><<<grid, kFrWaves * 64, kFrSmem, st>>>(fp);
+        else attn_fp8_fr_kernel<F16><<<grid, kFrWaves * 64, kFrSmem, st>>>(fp);
+        FINO_LAUNCH_CHECK();
+        return FINO_OK;
+    }
     constexpr int smem = kSmem8;
     {   // 66 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
         static FinoPerDeviceOnce once_bf16, once_f16;

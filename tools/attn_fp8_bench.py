@@ -19,6 +19,9 @@ o = torch.empty_like(q)
 runs = {"bf16 8-wave": lambda: ops.attention(q, k, v, heads, out=o),
         "bf16 4-wave folded": lambda: ops.attention(qs, k, v, heads, out=o, scale=ops.SCALE_FOLDED),
         "fp8 operands": lambda: ops.attention_fp8(q, k, v, heads, out=o)}
+if os.environ.get("FINO_FP8_KERNEL"):         # 1: the 8-wave ping-pong kernel instead of the free-running 4-wave one
+    from frameino_amd import _lib
+    _lib.lib().fino_tune_set(5, int(os.environ["FINO_FP8_KERNEL"]))
 if os.environ.get("FINO_FP8_ONLY"):           # timing-experiment builds (tools/attn_fp8_variants.sh): that kernel alone
     runs = {"fp8 operands": runs["fp8 operands"]}
 rows = torch.tensor(sorted(set(torch.randint(0, L, (24,)).tolist()) | {0, L - 1}), device=dev)
