@@ -18,8 +18,12 @@
 //   * P = exp2(s - m + 6) is rounded to e4m3 with a fixed block scale 2^-6: between rescales p <= 2^kThr, so P8 <= 2^8 <
 //     448, and what underflows (p < 2^-15 of the running maximum) carries no weight.  l sums the ROUNDED P on the matrix
 //     pipe (a ones row appended to V^T), so numerator and denominator see the same numbers.
-//   * 8 waves x 32 query rows per workgroup, K/V tiles double-buffered in LDS (9 KB per stage), one barrier per tile; the
-//     same (O, m, l) partial layout, tail split and combine kernels as fino_attention.hip.
+//   * Two main kernels.  Default: attn_fp8_fr_kernel -- 4 waves x 32 query rows per workgroup, three workgroups per CU that
+//     drift apart freely, one barrier per key tile (a wave of this loop is bound by its own issue rate and dependency chain,
+//     not by a pipe: tools/ubench/valu_rate.hip).  FINO_TUNE_ATTN_FP8_KERNEL = 1: attn_fp8_kernel -- 8 waves, the two waves of
+//     a SIMD one phase apart (softmax / matrix), two barriers per tile; it also carries the (O, m, l) partial layout of
+//     fino_attention.hip.  K8 / V8T tiles travel global -> LDS by DMA into rings, XOR-swizzled through the source offsets.
+//     Measurements: DESIGN.md section 4.2, profiles/r03_attn_fp8_*.
 #include <stdlib.h>
 
 #include "fino_attention_common.h"
@@ -148,17 +152,6 @@ constexpr int kRing8 = 8;
 constexpr int kLdsK = 0, kLdsV = kRing8 * kTileK8, kLdsKS = 2 * kRing8 * kTileK8, kLdsVS = kLdsKS + kRing8 * 128;
 constexpr int kSmem8 = kLdsVS + kRing8 * 128;
 
-// PING-PONG (the structure of attn_pp_kernel, fino_attention.hip): the two waves of a SIMD (w, w + 4) run one phase apart --
-// one in its SOFTMAX phase (exp2, e4m3 packing of P(t), the rescale decision, its share of the K / V staging), the other in
-// its MATRIX phase (S(t+1) = -m + K(t+1).Q^T, O^T += V(t)^T.P(t)^T, l^T += 1.P(t)^T, row maximum of S(t+1) in the MFMAs'
-// shadow); two s_barrier per tile.  The running maximum rides into S as one more product on the matrix pipe ("ones" x (-m),
-// a bf16 MFMA into the same accumulator: m is kept bf16-representable so the product is exact), so the softmax is a bare
-// exp2 + pack.  Staging: rings of eight tiles filled by LDS-DMA; in its softmax phase of tile t a group issues its half of
-// K(t+4) and V(t+4) and, before the barrier, waits for its half of t+3 (issued a whole tile earlier: an L2 hit takes about
-// one phase, anything further more -- with registers and one phase of distance the wait was 450 cycles per tile).  With two
-// tiles of slack the operands of the COMING
-// matrix phase (K(t+1) and V(t) fragments, their scale bytes: 12 LDS reads) are read at the top of the softmax phase and land
-// under the exp2 work: the matrix phase opens with its MFMAs instead of an LDS round trip.
 // Q row -> e4m3 B operand: lane (row r, group g) holds channels 16 g .. 16 g + 15 and 32 + 16 g .. + 15, pre-scaled, with
 // one scale per 32-channel block (block b = channels [32 b, 32 b + 32): half of it sits in the partner lane); q_scale =
 // the scale byte of block g (the operand this lane group supplies).  Rows past lq: zeros.
@@ -233,6 +226,16 @@ __device__ __forceinline__ float max16_behind(const f32x16_t& s, float behind) {
     return a;
 }
 
+// PING-PONG (the structure of attn_pp_kernel, fino_attention.hip): the two waves of a SIMD (w, w + 4) run one phase apart --
+// one in its SOFTMAX phase (exp2, e4m3 packing of P(t), the rescale decision, its share of the K / V staging), the other in
+// its MATRIX phase (S(t+1) = -m + K(t+1).Q^T, O^T += V(t)^T.P(t)^T, l^T += 1.P(t)^T, row maximum of S(t+1) in the MFMAs'
+// shadow); two s_barrier per tile.  The running maximum rides into S as one more product on the matrix pipe ("ones" x (-m),
+// a bf16 MFMA into the same accumulator: m is kept bf16-representable so the product is exact), so the softmax is a bare
+// exp2 + pack.  Staging: rings of eight tiles filled by LDS-DMA; in its softmax phase of tile t a group issues its half of
+// K(t+4) and V(t+4) and, before the barrier, waits for its half of t+3 (issued a whole tile earlier: an L2 hit takes about
+// one phase, anything further more -- with registers and one phase of distance the wait was 450 cycles per tile).  The
+// operands of a matrix phase (K(t+1) and V(t) fragments, their scale bytes: 12 LDS reads) are read at its top
+// (F8_READS_IN_MATRIX = 1): read in the softmax phase instead they lengthen the longer phase (1034 vs 1216 TFLOP/s-eq.).
 template <typename T, int VAR>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -19,6 +19,15 @@ DEV = "cuda"
 LOG2E = 1.4426950408889634
 
 
+@pytest.fixture(params=[0, 1], ids=["free-running", "ping-pong"], autouse=True)
+def fp8_kernel(request):
+    """both main kernels of fino_attn_fwd_fp8: the default (4 waves, three workgroups per CU) and FINO_TUNE_ATTN_FP8_KERNEL = 1"""
+    from frameino_amd import _lib
+    _lib.lib().fino_tune_set(5, request.param)
+    yield request.param
+    _lib.lib().fino_tune_set(5, 0)
+
+
 def _mxq(x, dim=-1, block=32):
     x = x.transpose(dim, -1)
     shp = x.shape
