@@ -59,7 +59,7 @@ def main():
     dt = (seen[-1] - seen[a.warmup - 1]) / a.steps if a.warmup else (seen[-1] - seen[0]) / (a.steps - 1)
     L, d, nl = 226 + 14 * 30 * 45, 3072, cfg["num_layers"]
     flops = 2 * nl * (8 * L * d * d + 4 * L * L * d + 16 * L * d * d)          # B=2: proj + SDPA + FFN (4x)
-    print(f"CogVideoX-5B FrameINO 49f 480x720 {'mxfp8 linears + bf16 attention' if a.mxfp8 else 'bf16'}{' + 4-wave folded attention' if a.w4 else ''}{' + fp8 attention operands' if a.fp8_attention else ''}: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
+    print(f"CogVideoX-5B FrameINO 49f 480x720 {('mxfp8 linears + ' + ('fp8-operand' if a.fp8_attention else 'bf16') + ' attention') if a.mxfp8 else ('bf16 linears + fp8-operand attention' if a.fp8_attention else 'bf16')}{' + 4-wave folded attention' if a.w4 else ''}: {dt * 1e3:.1f} ms/step, {1 / dt:.3f} denoise-steps/s, "
           f"{flops / dt / 1e12:.0f} TFLOP/s model ({nl} layers, L={L})")
 
 
