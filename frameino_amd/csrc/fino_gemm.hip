@@ -588,7 +588,11 @@ inline double plan_launch_cost(int64_t rows, int mi, int tiles_n, int cus) {
     if (rows <= 0) return 0.0;
     const double bm = 32.0 * mi;
     const int64_t tiles = ((rows + 32 * mi - 1) / (32 * mi)) * tiles_n;
-    const double mfma = 0.85 * bm / 256.0, deliver = (bm + 256.0) / 512.0;      // in 256-row full rounds
+    // in 256-row full rounds.  The 0.80 floor: a tile's walk over K cannot go faster than its DMA -> LDS -> fragment
+    // latency chain (~1 us per K-step), however few rows it has -- one-round launches of 64 .. 128-row tiles all take 0.84
+    // of the 256-row one (profiles/r03_gemm_tile_heights.txt); without it the planner bought second launches of a few tile
+    // rows at a third of their real price (the N = 8 shard's K|V projection: 77 + 49 us where one launch takes 107)
+    const double mfma_raw = 0.85 * bm / 256.0, mfma = mfma_raw > 0.80 ? mfma_raw : 0.80, deliver = (bm + 256.0) / 512.0;
     const int64_t full = tiles / cus, rem = tiles % cus;
     double c = (double)full * (mfma > deliver ? mfma : deliver);
     if (rem) {

@@ -39,13 +39,16 @@ lib = _lib.lib()
 settings = {"r01 (group_m 4, no dedup, 8-wave attention)": (4, False, 1, False),
             "group_m per shape": (0, False, 1, False), "+ shared prefix once": (0, True, 1, False),
             "+ 4-wave attention kernel": (0, True, 0, False), "+ softmax scale folded into q (MFMA fold)": (0, True, 0, True)}
+if "--tiles" in sys.argv:      # round 3: GEMM tile heights (FINO_TUNE_GEMM_TILE_M: 8 = 256-row tiles only, 0 = planned), default kernels otherwise
+    settings = {"256-row GEMM tiles only": (0, True, 1, False, 8), "planned GEMM tile heights": (0, True, 1, False, 0)}
 res = {k: [] for k in settings}
 
 
 attn = {}
 
 
-def run(gm, dedup, attn_k, fold, steps):
+def run(gm, dedup, attn_k, fold, steps, tile_m=0):
+    lib.fino_tune_set(3, tile_m)
     lib.fino_tune_set(0, gm)
     lib.fino_tune_set(4, attn_k)
     model.fold_softmax_scale = fold
@@ -56,17 +59,18 @@ def run(gm, dedup, attn_k, fold, steps):
             pipe._step(st)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    attn.setdefault((gm, dedup, attn_k, fold), []).append(kt.summary()["attn_self"]["total_ms"] / steps)
+    attn.setdefault((gm, dedup, attn_k, fold, tile_m)[:len(next(iter(settings.values())))], []).append(kt.summary()["attn_self"]["total_ms"] / steps)
     return ms
 
 
 for k, a in settings.items():
-    run(*a, 2)
+    run(*a[:4], 2, *a[4:])
 for rnd in range(5):
     for k, a in settings.items():
-        res[k].append(run(*a, 3))
+        res[k].append(run(*a[:4], 3, *a[4:]))
 lib.fino_tune_set(0, 0)
 lib.fino_tune_set(4, 0)
+lib.fino_tune_set(3, 0)
 for k, v in res.items():
     a_ms = statistics.median(attn[settings[k]][1:])
     print(f"    self-attention launches {a_ms:7.2f} ms/step, everything else {statistics.median(v) - a_ms:7.2f}")
