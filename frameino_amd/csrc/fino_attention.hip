@@ -24,9 +24,9 @@
 #include "fino_common.h"
 
 #ifdef FINO_ATTN_STAMP
-__device__ unsigned long long fino_attn_dbg[64];
+__device__ unsigned long long fino_attn_dbg[128];   // [64 ..): whole-workgroup stamps of attn_pp_kernel (entry, Q loaded, tiles staged, loop start, loop end, stored)
 extern "C" int fino_attn_debug_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_attn_dbg), sizeof(unsigned long long) * 64);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_attn_dbg), sizeof(unsigned long long) * 128);
 }
 #define ASTAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -360,6 +360,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     constexpr int kDT = D / 32;                                             // d-tiles of O^T
     typedef typename T::vec8 vec8;
 
+#ifdef FINO_ATTN_STAMP
+    unsigned long long wg_ts[6] = {0, 0, 0, 0, 0, 0};
+    ASTAMP(wg_ts[0])
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -416,6 +420,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         qf[ks] = __builtin_bit_cast(vec8, u);
     }
 
+#ifdef FINO_ATTN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(wg_ts[1])
+#endif
     // ---- staging roles: each group (waves 0-3 / 4-7) moves ITS half (32 rows) of a tile ----
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     int st_row[kLoadsPerThread], st_ch[kLoadsPerThread], st_off[kLoadsPerThread], st_off_k[kLoadsPerThread];
@@ -485,6 +493,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     }
     if (grp == 1) { PP_LOAD(1) }          // group 1 writes tile 1 in its first softmax phase
     __syncthreads();
+#ifdef FINO_ATTN_STAMP
+    ASTAMP(wg_ts[2])
+#endif
 
     f32x16_t sc0, sc1;   // S of the tile in flight
 #define QK_TILE(KB_)                                                                                        \
@@ -524,6 +535,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         const float m0 = vmax2(vmax3(MAX8(sc0, 0), MAX8(sc0, 8), MAX8(sc1, 0)), MAX8(sc1, 8));
         MAX_FINISH1(m0, mx_next)
     }
+#ifdef FINO_ATTN_STAMP
+    ASTAMP(wg_ts[3])
+#endif
     if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
 
     // LDS fragment addresses of the matrix phase: three registers.  The swizzle is an XOR on the chunk bits, so k-step
@@ -685,6 +699,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
     }
 #endif
     if (grp == 0) __builtin_amdgcn_s_barrier();
+#ifdef FINO_ATTN_STAMP
+    ASTAMP(wg_ts[4])
+#endif
 #undef QK_TILE
 #undef PP_LOAD
 #undef PP_WRITE
@@ -725,6 +742,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
             }
         }
     }
+#ifdef FINO_ATTN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(wg_ts[5])
+    if (blockIdx.x == 40 && lane == 0)
+        for (int i = 0; i < 6; ++i) fino_attn_dbg[64 + wave * 8 + i] = wg_ts[i];
+#endif
   }   // piece
 }
 
