@@ -32,6 +32,10 @@ SIGNATURES = {
                           c_void_p],
     "fino_rmsnorm_rope_scaled": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float,
                                  c_int, c_void_p],
+    "fino_qkv_rmsnorm_rope": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_void_p, c_float, c_void_p, c_void_p, c_int,
+                              c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "fino_rmsnorm_rope_scatter": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_void_p, c_void_p, c_int, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "fino_diag_mfma_peak": [c_int, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_void_p],
     "fino_headnorm_rope": [c_void_p, c_int, c_i64, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p, c_float,
                            c_void_p, c_void_p, c_i64, c_int, c_void_p],
@@ -64,6 +68,8 @@ SIGNATURES = {
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_gemm_split_n": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                           c_i64, c_i64, c_void_p],
+    "fino_gemm_blocked_a": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                            c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_gemm_plan": [c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)],
     "fino_skinny_linear": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
     "fino_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],

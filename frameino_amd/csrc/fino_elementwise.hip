@@ -159,18 +159,17 @@ __global__ __launch_bounds__(256) void gated_residual_kernel(const uint16_t* __r
 }
 
 // RMSNorm over the full row + weight (T) + RoPE, in place.  grid.y selects nothing; one wave per row.
+// One row of fino_rmsnorm_rope*: RMSNorm over the row's `dim` channels (weight in T, diffusers' rounding points), RoPE on
+// adjacent channel pairs, out_scale, then stored in place or scattered by head (out != nullptr).
 template <typename T, int NP>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint16_t* __restrict__ x, int64_t rows,
-                                                                           int dim, int64_t ldx,
-                                                                           const uint16_t* __restrict__ w, float eps,
-                                                                           const float* __restrict__ cos_t,
-                                                                           const float* __restrict__ sin_t,
-                                                                           int head_dim, float out_scale) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (row >= rows) return;
+__device__ __forceinline__ void rmsnorm_rope_row(uint16_t* __restrict__ xrow, int64_t row, int dim,
+                                                 const uint16_t* __restrict__ w, float eps,
+                                                 const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                 int head_dim, float out_scale, uint16_t* __restrict__ out,
+                                                 const int64_t* __restrict__ head_off,
+                                                 const int64_t* __restrict__ head_ld, int lane) {
     float v[NP][8];
-    load_row<T, NP>(x + row * ldx, dim, lane, v);
+    load_row<T, NP>(xrow, dim, lane, v);
     float rs = 1.f;
     if (w) {
         float q = 0.f;
@@ -212,8 +211,39 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint1
         // fino_rmsnorm_rope_scaled: the fp32 result times out_scale, rounded ONCE (1.0f: the plain op, bit for bit)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] *= out_scale;
-        EW_STORE(x + row * ldx + c, pack8<T>(o));
+        if (out) {     // scatter: head hd of the row lands at out + head_off[hd] + row * head_ld[hd]
+            const int hd = c / head_dim;
+            EW_STORE(out + head_off[hd] + row * head_ld[hd] + (c - hd * head_dim), pack8<T>(o));
+        } else {
+            EW_STORE(xrow + c, pack8<T>(o));
+        }
     }
+}
+
+// Up to three column segments of `dim` channels of the same rows in ONE launch (blockIdx.y = segment): q | k | v of a fused
+// projection.  A segment without weight and without RoPE is a copy (meaningful only with a scatter destination).
+struct RmsRopeParts {
+    const uint16_t* w[3];
+    float eps[3];
+    float out_scale[3];
+    int rope[3];
+};
+template <typename T, int NP>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint16_t* __restrict__ x, int64_t rows,
+                                                                           int dim, int64_t ldx, const RmsRopeParts pp,
+                                                                           const float* __restrict__ cos_t,
+                                                                           const float* __restrict__ sin_t,
+                                                                           int head_dim, uint16_t* __restrict__ out,
+                                                                           const int64_t* __restrict__ head_off,
+                                                                           const int64_t* __restrict__ head_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int s = blockIdx.y;
+    const bool rope = pp.rope[s] != 0;
+    rmsnorm_rope_row<T, NP>(x + row * ldx + (int64_t)s * dim, row, dim, pp.w[s], pp.eps[s], rope ? cos_t : nullptr,
+                            rope ? sin_t : nullptr, head_dim, pp.out_scale[s], out,
+                            head_off ? head_off + (int64_t)s * (dim / head_dim) : nullptr, head_ld, lane);
 }
 
 // CogVideoX: per-head LayerNorm(head_dim) (affine, T params; statistics fp32, output rounded to T) then RoPE
@@ -597,34 +627,75 @@ static int gated_residual_impl(const void* x, const void* y, void* out, int64_t 
     return FINO_OK;
 }
 
-extern "C" int fino_rmsnorm_rope_scaled(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
-                                        const float* cos_t, const float* sin_t, int head_dim, float out_scale, int dtype,
-                                        void* stream) {
+static int rmsnorm_rope_impl(void* x, int64_t rows, int dim, int64_t ldx, int parts, const RmsRopeParts& pp,
+                             const float* cos_t, const float* sin_t, int head_dim, void* out, const int64_t* head_off,
+                             const int64_t* head_ld, int dtype, void* stream) {
     CHECK_ROWS_DIM("fino_rmsnorm_rope");
     FINO_CHECK(x, FINO_ERR_ARG, "fino_rmsnorm_rope: null pointer");
-    FINO_CHECK(out_scale > 0.f, FINO_ERR_ARG, "fino_rmsnorm_rope_scaled: out_scale must be > 0");
+    FINO_CHECK(parts >= 1 && parts <= 3, FINO_ERR_ARG, "fino_rmsnorm_rope: parts %d", parts);
+    bool any_rope = false;
+    for (int i = 0; i < parts; ++i) {
+        FINO_CHECK(pp.out_scale[i] > 0.f, FINO_ERR_ARG, "fino_rmsnorm_rope_scaled: out_scale must be > 0");
+        FINO_CHECK(fino_aligned16(pp.w[i]), FINO_ERR_ARG, "fino_rmsnorm_rope: 16-byte alignment required");
+        any_rope = any_rope || pp.rope[i];
+    }
     FINO_CHECK((cos_t == nullptr) == (sin_t == nullptr), FINO_ERR_ARG, "fino_rmsnorm_rope: cos/sin must both be set");
-    FINO_CHECK(!cos_t || (head_dim > 0 && head_dim % 8 == 0 && dim % head_dim == 0), FINO_ERR_ARG,
+    FINO_CHECK(!any_rope || cos_t, FINO_ERR_ARG, "fino_rmsnorm_rope: a segment asks for RoPE without tables");
+    FINO_CHECK((!cos_t && !out) || (head_dim > 0 && head_dim % 8 == 0 && dim % head_dim == 0), FINO_ERR_ARG,
                "fino_rmsnorm_rope: head_dim=%d must divide dim=%d and be a multiple of 8", head_dim, dim);
-    FINO_CHECK(ldx % 8 == 0 && fino_aligned16(x) && fino_aligned16(weight) && fino_aligned16(cos_t) &&
-                   fino_aligned16(sin_t),
+    FINO_CHECK(ldx % 8 == 0 && fino_aligned16(x) && fino_aligned16(cos_t) && fino_aligned16(sin_t) && fino_aligned16(out),
                FINO_ERR_ARG, "fino_rmsnorm_rope: 16-byte alignment required");
-    const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+    FINO_CHECK(parts == 1 || dim % 8 == 0, FINO_ERR_ARG, "fino_rmsnorm_rope: segments need dim % 8 == 0");
+    const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)parts), block(kWavesPerBlock * 64);
     hipStream_t st = (hipStream_t)stream;
     const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if (dtype == FINO_BF16)
-            rmsnorm_rope_kernel<BF16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx,
-                                                                  (const uint16_t*)weight, eps, cos_t, sin_t, head_dim,
-                                                                  out_scale);
+            rmsnorm_rope_kernel<BF16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx, pp, cos_t, sin_t, head_dim,
+                                                                  (uint16_t*)out, head_off, head_ld);
         else
-            rmsnorm_rope_kernel<F16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx,
-                                                                 (const uint16_t*)weight, eps, cos_t, sin_t, head_dim,
-                                                                  out_scale);
+            rmsnorm_rope_kernel<F16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx, pp, cos_t, sin_t, head_dim,
+                                                                 (uint16_t*)out, head_off, head_ld);
     });
     FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "fino_rmsnorm_rope: dim %d > %d unsupported", dim, kMaxPasses * 512);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
+}
+
+static RmsRopeParts one_part(const void* weight, float eps, float out_scale, bool rope) {
+    RmsRopeParts pp = {};
+    pp.w[0] = (const uint16_t*)weight; pp.eps[0] = eps; pp.out_scale[0] = out_scale; pp.rope[0] = rope ? 1 : 0;
+    return pp;
+}
+
+extern "C" int fino_rmsnorm_rope_scaled(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                                        const float* cos_t, const float* sin_t, int head_dim, float out_scale, int dtype,
+                                        void* stream) {
+    return rmsnorm_rope_impl(x, rows, dim, ldx, 1, one_part(weight, eps, out_scale, cos_t != nullptr), cos_t, sin_t,
+                             head_dim, nullptr, nullptr, nullptr, dtype, stream);
+}
+
+extern "C" int fino_rmsnorm_rope_scatter(const void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                                         const float* cos_t, const float* sin_t, int head_dim, float out_scale, void* out,
+                                         const int64_t* head_off, const int64_t* head_ld, int dtype, void* stream) {
+    FINO_CHECK(out && head_off && head_ld, FINO_ERR_ARG, "fino_rmsnorm_rope_scatter: null destination / table");
+    return rmsnorm_rope_impl(const_cast<void*>(x), rows, dim, ldx, 1, one_part(weight, eps, out_scale, cos_t != nullptr),
+                             cos_t, sin_t, head_dim, out, head_off, head_ld, dtype, stream);
+}
+
+extern "C" int fino_qkv_rmsnorm_rope(void* qkv, int64_t rows, int dim, int64_t ldx, const void* q_weight, float q_eps,
+                                     const void* k_weight, float k_eps, const float* cos_t, const float* sin_t,
+                                     int head_dim, float q_out_scale, void* out, const int64_t* head_off,
+                                     const int64_t* head_ld, int dtype, void* stream) {
+    FINO_CHECK((out == nullptr) == (head_off == nullptr) && (out == nullptr) == (head_ld == nullptr), FINO_ERR_ARG,
+               "fino_qkv_rmsnorm_rope: out, head_off and head_ld go together");
+    RmsRopeParts pp = {};
+    pp.w[0] = (const uint16_t*)q_weight; pp.eps[0] = q_eps; pp.out_scale[0] = q_out_scale; pp.rope[0] = cos_t ? 1 : 0;
+    pp.w[1] = (const uint16_t*)k_weight; pp.eps[1] = k_eps; pp.out_scale[1] = 1.0f; pp.rope[1] = cos_t ? 1 : 0;
+    pp.w[2] = nullptr; pp.eps[2] = 0.f; pp.out_scale[2] = 1.0f; pp.rope[2] = 0;
+    // in place: q and k only (v is left alone); scattered: v travels too, as a copy
+    return rmsnorm_rope_impl(qkv, rows, dim, ldx, out ? 3 : 2, pp, cos_t, sin_t, head_dim, out, head_off, head_ld, dtype,
+                             stream);
 }
 
 extern "C" int fino_rmsnorm_rope(void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,

@@ -310,7 +310,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 // tiles of 160 x 256 in one round of 0.625 of the time (fino_gemm's planner, plan_tiles below).  A tiles are staged in
 // MI pieces of 32 rows: group 0 issues the first ceil(MI / 2) of them (they cover every row IT reads: its loads one phase
 // later must find them landed, and only its own vmcnt wait can vouch for that), group 1 the rest.
-template <typename T, bool CONV, int MI>
+// byte offset of K-tile kt inside a row of a K-blocked A (GemmParams::a_tpb): block j = kt / a_tpb starts at j * a_blk_elems
+__device__ __forceinline__ int ablk_koff(const GemmParams& p, int kt) {
+    const int j = (kt * p.a_inv) >> 16;
+    return j * (int)(p.a_blk_elems * 2) + (kt - j * p.a_tpb) * (BK * 2);
+}
+
+template <typename T, bool CONV, int MI, bool ABLK = false>
 __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, const int64_t m0, const int64_t n0,
                                             const int kb, const int nk, f32x4_t (&acc)[MI][4], const int tid,
                                             const int lane, const int wave, const int wm, const int wn) {
@@ -337,6 +343,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     int ck = 0, tap_t = 0, tap_h = 0, tap_w = 0, t_first = 0, t_in_first = 0;
     const uint16_t* a_base_ptr = p.a;
     int64_t a_bytes = ((p.m - 1) * p.lda + p.k) * 2;
+    if constexpr (ABLK) a_bytes = ((p.k / (BK * p.a_tpb) - 1) * p.a_blk_elems + (p.m - 1) * p.lda + BK * p.a_tpb) * 2;
     if constexpr (CONV) {
         const int hw = p.ho * p.wo;
         t_first = (int)(m0 / hw);
@@ -408,7 +415,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     if ((QI_) < NA1 || wm == 0)                                                                                   \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
             a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + ((aq0 + (QI_)) * 32 + wn * 8) * 128), 16,    \
-            a_off[QI_], CONV ? ck * (BK * 2) : (kb + (KT_)) * (BK * 2), 0, 0);
+            a_off[QI_], CONV ? ck * (BK * 2) : (ABLK ? ablk_koff(p, kb + (KT_)) : (kb + (KT_)) * (BK * 2)), 0, 0);
 #define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
     if (!CONV || (Q_) < w_pieces)                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
@@ -513,7 +520,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
 #undef PP_DMA_W
 }
 
-template <typename T, int EPI, bool CONV = false, int MI = 8>
+template <typename T, int EPI, bool CONV = false, int MI = 8, bool ABLK = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     // lock step and the epilogue bursts of later rounds are spread in time
     if (blockIdx.x < 256) nk = nk * (int)((blockIdx.x >> 3) % 8 + 1) / 8;
 #endif
-    pp_mainloop<T, CONV, MI>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn);
+    pp_mainloop<T, CONV, MI, ABLK>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn);
     gemm_epilogue<T, EPI, false, MI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
@@ -544,11 +551,11 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
-template <typename T, int EPI, bool CONV = false, int MI = 8>
+template <typename T, int EPI, bool CONV = false, int MI = 8, bool ABLK = false>
 int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     static FinoPerDeviceOnce once;
-    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV, MI>), kSmemBytes, "fino_gemm")) return rc;
-    gemm_pp_kernel<T, EPI, CONV, MI><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV, MI, ABLK>), kSmemBytes, "fino_gemm")) return rc;
+    gemm_pp_kernel<T, EPI, CONV, MI, ABLK><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -633,6 +640,22 @@ inline bool use_pingpong() {
 
 template <typename T, int EPI>
 int launch_gemm_pp_mi(const GemmParams& p, int mi, hipStream_t st) {
+    if (p.a_tpb > 0) {     // K-blocked A: built for the out-projection's epilogue only (fino_gemm_blocked_a checks)
+        if constexpr (EPI == FINO_EPI_GATED_RESIDUAL) {
+            switch (mi) {
+                case 2: return launch_gemm_pp<T, EPI, false, 2, true>(p, st);
+                case 3: return launch_gemm_pp<T, EPI, false, 3, true>(p, st);
+                case 4: return launch_gemm_pp<T, EPI, false, 4, true>(p, st);
+                case 5: return launch_gemm_pp<T, EPI, false, 5, true>(p, st);
+                case 6: return launch_gemm_pp<T, EPI, false, 6, true>(p, st);
+                case 7: return launch_gemm_pp<T, EPI, false, 7, true>(p, st);
+                default: return launch_gemm_pp<T, EPI, false, 8, true>(p, st);
+            }
+        } else {
+            fino_set_error("fino_gemm_blocked_a: epilogue must be FINO_EPI_GATED_RESIDUAL");
+            return FINO_ERR_UNSUPPORTED;
+        }
+    }
     switch (mi) {
         case 2: return launch_gemm_pp<T, EPI, false, 2>(p, st);
         case 3: return launch_gemm_pp<T, EPI, false, 3>(p, st);
@@ -782,6 +805,47 @@ extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias,
     if (dtype == FINO_BF16)
         return generic ? launch_gemm_e<BF16, true>(p, epilogue, st) : launch_gemm_e<BF16, false>(p, epilogue, st);
     return generic ? launch_gemm_e<F16, true>(p, epilogue, st) : launch_gemm_e<F16, false>(p, epilogue, st);
+}
+
+extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
+                                   int64_t a_block_k, int64_t a_block_stride, int64_t lda, int64_t ldw, int64_t ldc,
+                                   const void* r, int64_t ldr, const float* gate, int64_t mod_stride, const int32_t* sel,
+                                   int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm_blocked_a: dtype %d", dtype);
+    FINO_CHECK(a && w && c && r && gate, FINO_ERR_ARG, "fino_gemm_blocked_a: null pointer");
+    FINO_CHECK(m >= 0 && n > 0 && k > 0 && n % 8 == 0, FINO_ERR_ARG, "fino_gemm_blocked_a: bad shape");
+    FINO_CHECK(a_block_k > 0 && a_block_k % BK == 0 && k % a_block_k == 0 && a_block_k / BK <= 256 && k / BK <= 4096,
+               FINO_ERR_ARG, "fino_gemm_blocked_a: a_block_k=%lld must be a multiple of %d dividing K=%lld",
+               (long long)a_block_k, BK, (long long)k);
+    FINO_CHECK(lda % 8 == 0 && lda >= a_block_k && a_block_stride % 8 == 0 && ldw % 8 == 0 && ldw >= k && ldc % 8 == 0 &&
+                   ldc >= n && ldr % 8 == 0 && ldr >= n && mod_stride % 4 == 0,
+               FINO_ERR_ARG, "fino_gemm_blocked_a: leading dimensions");
+    FINO_CHECK(fino_aligned16(a) && fino_aligned16(w) && fino_aligned16(c) && fino_aligned16(r) && fino_aligned16(gate),
+               FINO_ERR_ARG, "fino_gemm_blocked_a: 16-byte alignment required");
+    const int64_t nblk = k / a_block_k;
+    const int64_t span = ((nblk - 1) * a_block_stride + (m > 0 ? m - 1 : 0) * lda + a_block_k) * 2;
+    FINO_CHECK(span < (1ll << 31) && ((n - 1) * ldw + k) * 2 < (1ll << 31), FINO_ERR_ARG,
+               "fino_gemm_blocked_a: operands must span < 2 GiB");
+    if (m == 0) return FINO_OK;
+    GemmParams p = {};
+    p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.c = (uint16_t*)c;
+    p.r = (const uint16_t*)r; p.gate = gate; p.sel = sel;
+    p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
+    p.a_tpb = (int)(a_block_k / BK); p.a_inv = (65536 + p.a_tpb - 1) / p.a_tpb; p.a_blk_elems = a_block_stride;
+    p.tiles_m = (int)((m + BM - 1) / BM);
+    p.tiles_n = (int)((n + BN - 1) / BN);
+    p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
+    if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
+    hipStream_t st = (hipStream_t)stream;
+    const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus());
+    auto rows = [&](int64_t r0, int64_t nr, int mi) {
+        return dtype == FINO_BF16 ? launch_gemm_rows<BF16>(p, r0, nr, mi, FINO_EPI_GATED_RESIDUAL, st)
+                                  : launch_gemm_rows<F16>(p, r0, nr, mi, FINO_EPI_GATED_RESIDUAL, st);
+    };
+    if (tp.rows1 > 0)
+        if (int rc = rows(0, tp.rows1, 8)) return rc;
+    if (tp.rows1 < p.m) return rows(tp.rows1, p.m - tp.rows1, tp.mi2);
+    return FINO_OK;
 }
 
 extern "C" int fino_conv3d(const void* x, const void* w, const void* bias, void* y, int t_in, int h_in, int w_in,

@@ -26,6 +26,11 @@ struct GemmParams {
     // column n_split = its column 0); n_split is a multiple of BN, 0 = one output
     uint16_t* c2;
     int64_t ldc2, n_split;
+    // K-blocked A (fino_gemm_blocked_a; the ABLK kernels): columns [j * 64 a_tpb, (j + 1) * 64 a_tpb) of a row live at
+    // a + j * a_blk_elems + row * lda -- the layout the heads all-to-all returns the attention output in ([peer][token]
+    // [heads of that peer]); a_inv = ceil(65536 / a_tpb) turns the K-tile index into its block by a multiply and a shift
+    int a_tpb, a_inv;
+    int64_t a_blk_elems;
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents

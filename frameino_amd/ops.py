@@ -150,6 +150,39 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0, out_scale=1.0)
     return x
 
 
+def qkv_rmsnorm_rope_(qkv, dim, q_weight, q_eps, k_weight, k_eps, cos, sin, head_dim, q_out_scale=1.0, out=None,
+                      head_off=None, head_ld=None):
+    """q (columns [0, dim)) and k ([dim, 2 dim)) of the fused projection qkv [rows, 3 dim] in ONE launch: the arithmetic of
+    rmsnorm_rope_(q, ..., out_scale=q_out_scale) and rmsnorm_rope_(k, ...).  With `out` (flat buffer) + head_off [3 heads]
+    + head_ld [heads] (int64 device tables) nothing changes in place and q, k and v are scattered by head (see
+    rmsnorm_rope_scatter)."""
+    x2, rows, width, ldx = _rows2d(qkv)
+    assert width == 3 * dim
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and cos.shape == (rows, head_dim // 2) and sin.shape == cos.shape
+    if out is not None:
+        assert head_off.dtype == torch.int64 and head_off.numel() == 3 * (dim // head_dim) and head_off.is_contiguous()
+        assert head_ld.dtype == torch.int64 and head_ld.numel() == dim // head_dim and out.is_contiguous()
+    _lib.check(_lib.lib().fino_qkv_rmsnorm_rope(_p(x2), rows, dim, ldx, _p(q_weight), q_eps, _p(k_weight), k_eps, _p(cos),
+                                                _p(sin), head_dim, float(q_out_scale), _p(out), _p(head_off), _p(head_ld),
+                                                _dt(qkv), _stream()), "fino_qkv_rmsnorm_rope")
+    return qkv if out is None else out
+
+
+def rmsnorm_rope_scatter(x, weight, eps, cos, sin, head_dim, out, head_off, head_ld, out_scale=1.0):
+    """rmsnorm_rope_ out of place: head hd of row r of x [rows, D] (row-strided view) is written to the flat buffer `out`
+    at element head_off[hd] + r * head_ld[hd] (int64 device tables).  weight = cos = None: a scattering copy."""
+    x2, rows, dim, ldx = _rows2d(x)
+    assert head_off.dtype == torch.int64 and head_ld.dtype == torch.int64 and head_off.is_cuda and head_ld.is_cuda
+    assert head_off.numel() == dim // head_dim == head_ld.numel() and out.is_contiguous() and out.dtype == x.dtype
+    if cos is not None:
+        assert cos.dtype == torch.float32 and cos.is_contiguous() and cos.shape == (rows, head_dim // 2)
+        assert sin.dtype == torch.float32 and sin.is_contiguous() and sin.shape == cos.shape
+    _lib.check(_lib.lib().fino_rmsnorm_rope_scatter(_p(x2), rows, dim, ldx, _p(weight), eps, _p(cos), _p(sin), head_dim,
+                                                    float(out_scale), _p(out), _p(head_off), _p(head_ld), _dt(x),
+                                                    _stream()), "fino_rmsnorm_rope_scatter")
+    return out
+
+
 def headnorm_rope_(x, heads, head_dim, weight, bias, eps, cos=None, sin=None, rope_row0=0, out_scale=1.0):
     """In place on x [B, rows, heads*head_dim] (row-strided): per-head LayerNorm + RoPE on rows >= rope_row0.
     out_scale: multiplies the result before it is stored (q for attention(scale=SCALE_FOLDED))."""
@@ -309,6 +342,27 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     if ev is not None:
         ev.record()
         KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
+    return out
+
+
+def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
+    """out = residual + gate[sel] * (A.W^T + bias) with A given as K blocks: a_blocks [nblk, rows_pad, blk_k] (last two dims
+    row-strided), A[i, j * blk_k + c] = a_blocks[j, i, c] for i < rows.  fino_gemm_blocked_a: the out-projection reading the
+    heads exchange's return buffer as it arrived."""
+    assert a_blocks.dim() == 3 and a_blocks.stride(2) == 1 and w.dtype == a_blocks.dtype and w.stride(1) == 1
+    nblk, _, bk = a_blocks.shape
+    n, k = w.shape
+    assert k == nblk * bk and residual.shape == (rows, n) and out.shape == (rows, n)
+    r2, _, _, ldr = _rows2d(residual)
+    o2, _, _, ldc = _rows2d(out)
+    ms = gate.stride(0) if gate.dim() == 2 else 0
+    ev = _timed("gemm")
+    _lib.check(_lib.lib().fino_gemm_blocked_a(_p(a_blocks), _p(w), _p(bias), _p(o2), rows, n, k, bk, a_blocks.stride(0),
+                                              a_blocks.stride(1), w.stride(0), ldc, _p(r2), ldr, _p(gate), ms, _p(sel),
+                                              _dt(a_blocks), _stream()), "fino_gemm_blocked_a")
+    if ev is not None:
+        ev.record()
+        KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * rows * n * k
     return out
 
 

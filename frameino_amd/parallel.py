@@ -122,6 +122,34 @@ class TokenShard:
         cuts = [hp * i // g for i in range(g + 1)]
         return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
+    def heads_send_layout(self, heads, dh, lpad, dtype, dev):
+        """The send side of the heads exchange as ONE flat buffer: per head group g a [ways, lpad, 3, dg] block (slice j =
+        q | k | v of MY tokens for the heads of rank j in that group), plus the per-head destination tables of
+        ops.rmsnorm_rope_scatter (element offset of head h's 128 columns for q / k / v, and the row stride there) -- the
+        RMSNorm + RoPE kernel writes q and k straight into it and v goes by the same kernel as a scattering copy, instead of
+        a permute copy of all three after the in-place kernel.  Rows [n, lpad) are never written and stay zero."""
+        key = ("heads_send_layout", heads, dh, lpad, dtype, str(dev), int(self.head_groups))
+        lay = self._buf.get(key)
+        if lay is None:
+            from types import SimpleNamespace
+            ways, hp = self.ways, heads // self.ways
+            flat = torch.zeros(ways * lpad * 3 * hp * dh, dtype=dtype, device=dev)
+            views, off, ld, base = [], [[0] * heads for _ in range(3)], [0] * heads, 0
+            for h0, h1 in self.head_ranges(hp):
+                dg = (h1 - h0) * dh
+                views.append(flat[base:base + ways * lpad * 3 * dg].view(ways, lpad, 3, dg))
+                for j in range(ways):
+                    for hl in range(h0, h1):
+                        for which in range(3):
+                            off[which][j * hp + hl] = base + j * lpad * 3 * dg + which * dg + (hl - h0) * dh
+                        ld[j * hp + hl] = 3 * dg
+                base += ways * lpad * 3 * dg
+            lay = self._buf[key] = SimpleNamespace(
+                flat=flat, views=views, ld=torch.tensor(ld, dtype=torch.int64, device=dev),
+                off=[torch.tensor(o_, dtype=torch.int64, device=dev) for o_ in off],
+                off_qkv=torch.tensor(off[0] + off[1] + off[2], dtype=torch.int64, device=dev))
+        return lay
+
     def all_to_all(self, key, send, async_op=False):
         """send [ways, rows, width] (slice j goes to rank j) -> (received [ways, rows, width]: slice j came from rank j,
         work handle or None).  Without async_op the call is blocking in stream order."""

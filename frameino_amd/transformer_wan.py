@@ -320,6 +320,17 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         tproj = torch.cat([o[1] for o in outs]).unflatten(1, (6, -1))
         return temb, tproj
 
+    def _qk_norm_rope(self, blk, qkv, d, cos, sin, dh, qfold):
+        """norm_q / norm_k ("rms_norm_across_heads", :64-67) + RoPE (:73-90) on the q and k columns of the fused projection,
+        in place: one launch where the ops offer it (the arithmetic of the two rmsnorm_rope_ calls, bit for bit)"""
+        o, a = self.ops, blk.attn1
+        if hasattr(o, "qkv_rmsnorm_rope_"):
+            o.qkv_rmsnorm_rope_(qkv, d, a.norm_q.weight, a.norm_q.eps, a.norm_k.weight, a.norm_k.eps, cos, sin, dh,
+                                q_out_scale=qfold.get("out_scale", 1.0))
+        else:
+            o.rmsnorm_rope_(qkv[:, :d], a.norm_q.weight, a.norm_q.eps, cos, sin, dh, **qfold)
+            o.rmsnorm_rope_(qkv[:, d:2 * d], a.norm_k.weight, a.norm_k.eps, cos, sin, dh)
+
     def _text_kv(self, encoder_hidden_states, pk):
         """text_embedder (:185) + the 30 layers' attn2 K (after norm_k) and V: step-invariant, cached per
         cache_context name for as long as the caller passes the SAME prompt tensor object, unmodified."""
@@ -473,8 +484,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 n1, q1, sel1 = nrm[:n], ws.qkv[:n], (None if sel is None else sel[:n])
                 o.adaln_modulate(x[:n], m[:, 0], m[:, 1], sel1, cfg.eps, out=n1)
                 self._lin(li, "qkv", n1, e.wqkv, e.bqkv, out=q1)
-                o.rmsnorm_rope_(q1[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos1, sin1, dh, **qfold)
-                o.rmsnorm_rope_(q1[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos1, sin1, dh)
+                self._qk_norm_rope(blk, q1, d, cos1, sin1, dh, qfold)
                 q3 = q1.view(1, n, 3 * d)
                 o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att[:n].view(1, n, d), **afold)
                 self._lin(li, "out", att[:n], blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
@@ -484,8 +494,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             elif sh is None:
                 qkv = ws.qkv[:nr]
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
-                o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
-                o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                self._qk_norm_rope(blk, qkv, d, cos, sin, dh, qfold)
                 q3 = qkv.view(b, n, 3 * d)
                 o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
             elif sh.heads_exchange_ok(heads):
@@ -496,16 +505,27 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 dp = hp * dh
                 qkv = ws.qkv[:n]
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
-                o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
-                o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                 # the heads travel in groups, every group its own all-to-all on the communicator's stream: while group g
                 # is attended to, group g+1 arrives and group g-1's outputs leave
-                q4 = qkv.view(n, 3, ways, dp)
+                lay = sh.heads_send_layout(heads, dh, lpad, dt, dev) if hasattr(o, "qkv_rmsnorm_rope_") else None
+                if lay is not None:
+                    # ONE launch: RMSNorm + RoPE write q and k straight into the send buffers (slice j: heads of rank j) and
+                    # v follows as a scattering copy -- no permute copy of q | k | v afterwards
+                    o.qkv_rmsnorm_rope_(qkv, d, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, blk.attn1.norm_k.weight,
+                                        blk.attn1.norm_k.eps, cos, sin, dh, q_out_scale=qfold.get("out_scale", 1.0),
+                                        out=lay.flat, head_off=lay.off_qkv, head_ld=lay.ld)
+                else:
+                    o.rmsnorm_rope_(qkv[:, :d], blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
+                    o.rmsnorm_rope_(qkv[:, d:2 * d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
+                    q4 = qkv.view(n, 3, ways, dp)
                 inflight = []
                 for gi, (h0, h1) in enumerate(sh.head_ranges(hp)):
                     dg = (h1 - h0) * dh
-                    send = sh.a2a_buffer(f"qkv_send{gi}", (ways, lpad, 3, dg), dt, dev)   # slice j: heads of rank j
-                    send[:, :n].copy_(q4[:, :, :, h0 * dh:h1 * dh].permute(2, 0, 1, 3))
+                    if lay is not None:
+                        send = lay.views[gi]
+                    else:
+                        send = sh.a2a_buffer(f"qkv_send{gi}", (ways, lpad, 3, dg), dt, dev)   # slice j: heads of rank j
+                        send[:, :n].copy_(q4[:, :, :, h0 * dh:h1 * dh].permute(2, 0, 1, 3))
                     inflight.append((gi, h0, h1, dg) + sh.all_to_all(f"qkv_recv{gi}", send, async_op=True))
                 back = []
                 for gi, h0, h1, dg, recv, work in inflight:                                # slice j: tokens of rank j
@@ -516,11 +536,20 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     o.attention(r3[:, :, :dg], r3[:, :, dg:2 * dg], r3[:, :, 2 * dg:], h1 - h0,
                                 out=oh.view(1, ways * lpad, dg)[:, :L], **afold)
                     back.append((h0, h1) + sh.all_to_all(f"o_recv{gi}", oh, async_op=True))
-                a3 = att.view(n, ways, dp)
-                for h0, h1, orv, work in back:                                             # slice j: heads of rank j
+                if len(back) == 1 and not self._fp8 and hasattr(o, "gemm_blocked_a"):
+                    # one head group: the out-projection reads the returned [rank j's heads][token] blocks as they arrived
+                    # (fino_gemm_blocked_a) instead of a permute copy into [token, D] first
+                    _, _, orv, work = back[0]
                     if work is not None:
                         work.wait()
-                    a3[:, :, h0 * dh:h1 * dh].copy_(orv[:, :n].permute(1, 0, 2))
+                    o.gemm_blocked_a(orv, n, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, x, m[:, 2], sel, out=x)
+                    once = True                                     # the common out-projection below is done
+                else:
+                    a3 = att.view(n, ways, dp)
+                    for h0, h1, orv, work in back:                                         # slice j: heads of rank j
+                        if work is not None:
+                            work.wait()
+                        a3[:, :, h0 * dh:h1 * dh].copy_(orv[:, :n].permute(1, 0, 2))
             else:
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
                 if sh.fused_qkv_ok() and not self._fp8:

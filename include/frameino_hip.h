@@ -92,6 +92,25 @@ int fino_rmsnorm_rope_scaled(void* x, int64_t rows, int dim, int64_t ldx, const 
                              const float* cos_t, const float* sin_t, int head_dim, float out_scale, int dtype,
                              void* stream);
 
+/* The same arithmetic, out of place, with the result SCATTERED by head: head hd (channels [hd*head_dim, (hd+1)*head_dim) of a
+ * row) is written to out + head_off[hd] + row * head_ld[hd] (element offsets, multiples of 8; the tables live in device
+ * memory).  weight == NULL and cos_t == NULL make it a pure scattering copy (the v columns).  What the token-sharded
+ * forward's heads exchange uses to write q, k, v of its tokens straight into the all-to-all send buffer [peer][token][q|k|v]
+ * [heads of that peer] instead of a permute copy after the in-place kernel (frameino_amd/transformer_wan.py, heads exchange). */
+int fino_rmsnorm_rope_scatter(const void* x, int64_t rows, int dim, int64_t ldx, const void* weight, float eps,
+                              const float* cos_t, const float* sin_t, int head_dim, float out_scale, void* out,
+                              const int64_t* head_off, const int64_t* head_ld, int dtype, void* stream);
+
+/* q and k of a fused q | k | v projection in ONE launch: qkv is [rows, 3*dim] with row stride ldx; columns [0, dim) get
+ * fino_rmsnorm_rope_scaled(q_weight, q_eps, q_out_scale), columns [dim, 2 dim) fino_rmsnorm_rope(k_weight, k_eps), both
+ * bit for bit.  out == NULL: in place, v untouched.  out != NULL: nothing is modified in place; q, k AND v (a copy) are
+ * scattered by head as in fino_rmsnorm_rope_scatter with head_off = [q heads | k heads | v heads] (3 * dim / head_dim
+ * entries) and head_ld per head (dim / head_dim entries). */
+int fino_qkv_rmsnorm_rope(void* qkv, int64_t rows, int dim, int64_t ldx, const void* q_weight, float q_eps,
+                          const void* k_weight, float k_eps, const float* cos_t, const float* sin_t, int head_dim,
+                          float q_out_scale, void* out, const int64_t* head_off, const int64_t* head_ld, int dtype,
+                          void* stream);
+
 /* Per-head LayerNorm(head_dim, affine) + RoPE on rows >= rope_row0 of every batch element (CogVideoX):
  * architecture/attention_processor.py:2851-2860.  x is [batch, rows, heads*head_dim] with row stride ldx.
  * w/b are T vectors of head_dim (NULL => skip LN). cos/sin are [rows - rope_row0, head_dim] fp32 (full width,
@@ -183,6 +202,14 @@ int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, i
                       int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
                       int64_t mod_stride, const int32_t* sel, int dtype, void* c2, int64_t ldc2, int64_t n_split,
                       void* stream);
+/* c = r + gate[sel] * (A w^T + bias) (FINO_EPI_GATED_RESIDUAL) with a K-BLOCKED A: columns [j * a_block_k, (j + 1) *
+ * a_block_k) of row i live at a + j * a_block_stride + i * lda (elements; a_block_k a multiple of 64 dividing K).  That is
+ * the layout in which the heads all-to-all returns the attention output to the token owners ([peer][token][heads of that
+ * peer]): the out-projection (transformer_wan.py:336) reads it as it arrived, without the permute copy into [token, D]. */
+int fino_gemm_blocked_a(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
+                        int64_t a_block_k, int64_t a_block_stride, int64_t lda, int64_t ldw, int64_t ldc, const void* r,
+                        int64_t ldr, const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
+
 /* The tiling fino_gemm uses for an M x N problem on the current device: `rows_256` leading rows run as 256 x 256 tiles
  * (a whole number of rounds of the CUs), the remaining rows as ONE more launch of `tile_rows_rest`-row tiles (64 .. 256
  * in steps of 32; 0 = no second launch) chosen so that they fit (at most) one more round: 3080 rows x 3072 columns are

@@ -59,6 +59,30 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, head_dim=0, out_scale=1.0)
     return x
 
 
+def qkv_rmsnorm_rope_(qkv, dim, q_weight, q_eps, k_weight, k_eps, cos, sin, head_dim, q_out_scale=1.0, out=None,
+                      head_off=None, head_ld=None):
+    heads = dim // head_dim
+    if out is None:
+        rmsnorm_rope_(qkv[:, :dim], q_weight, q_eps, cos, sin, head_dim, q_out_scale)
+        rmsnorm_rope_(qkv[:, dim:2 * dim], k_weight, k_eps, cos, sin, head_dim)
+        return qkv
+    rmsnorm_rope_scatter(qkv[:, :dim], q_weight, q_eps, cos, sin, head_dim, out, head_off[:heads], head_ld, q_out_scale)
+    rmsnorm_rope_scatter(qkv[:, dim:2 * dim], k_weight, k_eps, cos, sin, head_dim, out, head_off[heads:2 * heads], head_ld)
+    rmsnorm_rope_scatter(qkv[:, 2 * dim:], None, 0.0, None, None, head_dim, out, head_off[2 * heads:], head_ld)
+    return out
+
+
+def rmsnorm_rope_scatter(x, weight, eps, cos, sin, head_dim, out, head_off, head_ld, out_scale=1.0):
+    y = rmsnorm_rope_(x.clone(), weight, eps, cos, sin, head_dim, out_scale)
+    rows = y.shape[0]
+    flat = out.view(-1)
+    r = torch.arange(rows, device=y.device)[:, None]
+    c = torch.arange(head_dim, device=y.device)[None, :]
+    for hd in range(y.shape[1] // head_dim):
+        flat[int(head_off[hd]) + r * int(head_ld[hd]) + c] = y[:, hd * head_dim:(hd + 1) * head_dim]
+    return out
+
+
 def attention(q, k, v, heads, out=None, scale=None):
     b, lq, hd = q.shape
     dh = hd // heads
@@ -102,6 +126,11 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     elif epilogue == EPI_GATED_RESIDUAL:
         y = (residual.float() + y.float() * _g(gate, sel)).to(a.dtype)
     return y if out is None else out.copy_(y)
+
+
+def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
+    a = a_blocks[:, :rows].permute(1, 0, 2).reshape(rows, -1)
+    return gemm(a, w, bias, EPI_GATED_RESIDUAL, residual, gate, sel, out=out)
 
 
 def skinny_linear(x, w, b=None, silu_input=False):

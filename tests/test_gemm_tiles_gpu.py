@@ -124,3 +124,26 @@ def test_split_n_output_equals_the_column_slices_of_one_output(lib, m):
     assert float(q[m:].abs().max()) == 0.0 and float(kv[m:].abs().max()) == 0.0 and float(kv[:, 2 * d:].abs().max()) == 0.0
     with pytest.raises(RuntimeError, match="n_split"):
         ops.gemm(a, w, bias, out=q[:m], out2=kv[:m, :2 * d], split=d + 8)
+
+
+@pytest.mark.parametrize("ways,n,lpad", [(4, 3080, 3080), (8, 1540, 1540), (2, 6160, 6160), (4, 1000, 1024)])
+def test_blocked_a_out_projection_equals_the_permute_copy_plus_gemm(ways, n, lpad):
+    """fino_gemm_blocked_a: the gated-residual out-projection reading [peer][token][heads of that peer] (what the heads
+    all-to-all returns) == the permute copy into [token, D] followed by fino_gemm, bit for bit"""
+    from frameino_amd import ops
+    d = 3072
+    dp = d // ways
+    g = torch.Generator(device=DEV).manual_seed(ways * 1000 + n)
+    orv = torch.randn(ways, lpad, dp, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(d, d, device=DEV, generator=g) * 0.02).bfloat16()
+    b = torch.randn(d, device=DEV, generator=g).bfloat16()
+    x = torch.randn(n, d, device=DEV, generator=g).bfloat16()
+    gate = torch.randn(2, d, device=DEV, generator=g)
+    sel = (torch.arange(n, device=DEV) % 2).to(torch.int32)
+    att = orv[:, :n].permute(1, 0, 2).reshape(n, d).contiguous()
+    want = ops.gemm(att, w, b, ops.EPI_GATED_RESIDUAL, x, gate, sel)
+    got = ops.gemm_blocked_a(orv, n, w, b, x, gate, sel, out=torch.empty_like(x))
+    assert torch.equal(got, want)
+    x2 = x.clone()
+    ops.gemm_blocked_a(orv, n, w, b, x2, gate, sel, out=x2)          # in place on the residual, as the forward calls it
+    assert torch.equal(x2, want)

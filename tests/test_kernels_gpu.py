@@ -563,3 +563,47 @@ def test_diag_mfma_peak_runs_and_counts_flops():
         tf = fl.value / (s.elapsed_time(e) * 1e-3) / 1e12
         assert 500.0 < tf < 2600.0, tf
     assert lib.fino_diag_mfma_peak(7, 2, 10, scratch.data_ptr(), ctypes.byref(fl), None) != 0      # bad kind -> error code
+
+
+@pytest.mark.parametrize("ways,groups,n,lpad", [(4, 1, 3080, 3080), (4, 2, 1000, 1024), (8, 2, 1540, 1540), (2, 1, 777, 784)])
+def test_rmsnorm_rope_scatter_equals_inplace_kernel_plus_permute_copy(ways, groups, n, lpad):
+    """fino_rmsnorm_rope_scatter: q, k (RMSNorm + RoPE) and v (plain copy) of a token shard written straight into the heads
+    exchange's send buffers == the in-place kernel followed by the permute copy it replaces, bit for bit"""
+    from frameino_amd import ops
+    from frameino_amd.parallel import TokenShard
+    heads, dh = 24, 128
+    d = heads * dh
+    g = torch.Generator(device=DEV).manual_seed(n)
+    qkv = torch.randn(n, 3 * d, device=DEV, generator=g).bfloat16()
+    wq = (1 + 0.1 * torch.randn(d, device=DEV, generator=g)).bfloat16()
+    wk = (1 + 0.1 * torch.randn(d, device=DEV, generator=g)).bfloat16()
+    ang = torch.rand(n, dh // 2, device=DEV, generator=g) * 6.28
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+    sh = TokenShard.__new__(TokenShard)
+    sh.ways, sh._buf, sh.head_groups = ways, {}, groups
+    lay = sh.heads_send_layout(heads, dh, lpad, torch.bfloat16, torch.device(DEV))
+    c = dh ** -0.5 * ops.LOG2E
+    ops.rmsnorm_rope_scatter(qkv[:, :d], wq, 1e-6, cos, sin, dh, lay.flat, lay.off[0], lay.ld, out_scale=c)
+    ops.rmsnorm_rope_scatter(qkv[:, d:2 * d], wk, 1e-6, cos, sin, dh, lay.flat, lay.off[1], lay.ld)
+    ops.rmsnorm_rope_scatter(qkv[:, 2 * d:], None, 0.0, None, None, dh, lay.flat, lay.off[2], lay.ld)
+    ref = qkv.clone()
+    ops.rmsnorm_rope_(ref[:, :d], wq, 1e-6, cos, sin, dh, out_scale=c)
+    ops.rmsnorm_rope_(ref[:, d:2 * d], wk, 1e-6, cos, sin, dh)
+    hp = heads // ways
+    q4 = ref.view(n, 3, ways, hp * dh)
+    assert len(lay.views) == len(sh.head_ranges(hp))
+    for view, (h0, h1) in zip(lay.views, sh.head_ranges(hp)):
+        want = q4[:, :, :, h0 * dh:h1 * dh].permute(2, 0, 1, 3)
+        assert torch.equal(view[:, :n], want)
+        assert not view[:, n:].any()
+    assert torch.equal(qkv[:, 2 * d:], ref[:, 2 * d:])          # the source is left alone
+    # the one-launch forms: scattered (a fresh layout) and in place
+    sh2 = TokenShard.__new__(TokenShard)
+    sh2.ways, sh2._buf, sh2.head_groups = ways, {}, groups
+    lay2 = sh2.heads_send_layout(heads, dh, lpad, torch.bfloat16, torch.device(DEV))
+    before = qkv.clone()
+    ops.qkv_rmsnorm_rope_(qkv, d, wq, 1e-6, wk, 1e-6, cos, sin, dh, q_out_scale=c, out=lay2.flat, head_off=lay2.off_qkv,
+                          head_ld=lay2.ld)
+    assert torch.equal(lay2.flat, lay.flat) and torch.equal(qkv, before)
+    ops.qkv_rmsnorm_rope_(qkv, d, wq, 1e-6, wk, 1e-6, cos, sin, dh, q_out_scale=c)
+    assert torch.equal(qkv, ref)

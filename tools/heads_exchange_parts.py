@@ -39,10 +39,22 @@ for P in (2, 4, 8):
     kv_all = torch.randn(1, P * lpad, 2 * d, device=dev, generator=g).bfloat16()
     q2 = torch.randn(1, n, d, device=dev, generator=g).bfloat16()
     kvl = torch.empty(n, 2 * d, device=dev, dtype=torch.bfloat16)
+    from frameino_amd.parallel import TokenShard
+    sh = TokenShard.__new__(TokenShard); sh.ways, sh._buf, sh.head_groups = P, {}, 1
+    lay = sh.heads_send_layout(heads, dh, lpad, torch.bfloat16, torch.device(dev))
+    wn = torch.ones(d, device=dev).bfloat16()
+    ang = torch.rand(n, dh // 2, device=dev, generator=g)
+    cs, sn = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
     res = {
         "gemm qkv fused": t_us(lambda: ops.gemm(x, wqkv, bqkv, out=qkv)),
         "gemm kv + gemm q": t_us(lambda: (ops.gemm(x, wqkv[d:], bqkv[d:], out=kvl), ops.gemm(x, wqkv[:d], bqkv[:d], out=att))),
         "pack (torch permute copy)": t_us(lambda: send[:, :n].copy_(qkv.view(n, 3, P, dp).permute(2, 0, 1, 3))),
+        "rmsnorm+rope of q and k in place (what either way runs)": t_us(lambda: (
+            ops.rmsnorm_rope_(qkv[:, :d], wn, 1e-6, cs, sn, dh), ops.rmsnorm_rope_(qkv[:, d:2 * d], wn, 1e-6, cs, sn, dh))),
+        "rmsnorm+rope scattered into the send buffer + v scatter copy (round 3: replaces the two lines above)": t_us(lambda: (
+            ops.rmsnorm_rope_scatter(qkv[:, :d], wn, 1e-6, cs, sn, dh, lay.flat, lay.off[0], lay.ld),
+            ops.rmsnorm_rope_scatter(qkv[:, d:2 * d], wn, 1e-6, cs, sn, dh, lay.flat, lay.off[1], lay.ld),
+            ops.rmsnorm_rope_scatter(qkv[:, 2 * d:], None, 0.0, None, None, dh, lay.flat, lay.off[2], lay.ld))),
         "unpack (torch permute copy)": t_us(lambda: att.view(n, P, dp).copy_(oh[:, :n].permute(1, 0, 2))),
         "attention H/P heads x L x L": t_us(lambda: ops.attention(r3[:, :, :dp], r3[:, :, dp:2 * dp], r3[:, :, 2 * dp:], hp,
                                                                   out=oh.view(1, P * lpad, dp)[:, :L])),
