@@ -43,6 +43,10 @@ for P in (2, 4, 8):
     sh = TokenShard.__new__(TokenShard); sh.ways, sh._buf, sh.head_groups = P, {}, 1
     lay = sh.heads_send_layout(heads, dh, lpad, torch.bfloat16, torch.device(dev))
     wn = torch.ones(d, device=dev).bfloat16()
+    wo = (torch.randn(d, d, device=dev, generator=g) * 0.02).bfloat16()
+    xres = torch.zeros(n, d, device=dev).bfloat16()
+    gt = torch.zeros(2, d, device=dev)
+    sl = (torch.arange(n, device=dev) % 2).to(torch.int32)
     ang = torch.rand(n, dh // 2, device=dev, generator=g)
     cs, sn = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
     res = {
@@ -51,10 +55,14 @@ for P in (2, 4, 8):
         "pack (torch permute copy)": t_us(lambda: send[:, :n].copy_(qkv.view(n, 3, P, dp).permute(2, 0, 1, 3))),
         "rmsnorm+rope of q and k in place (what either way runs)": t_us(lambda: (
             ops.rmsnorm_rope_(qkv[:, :d], wn, 1e-6, cs, sn, dh), ops.rmsnorm_rope_(qkv[:, d:2 * d], wn, 1e-6, cs, sn, dh))),
-        "rmsnorm+rope scattered into the send buffer + v scatter copy (round 3: replaces the two lines above)": t_us(lambda: (
-            ops.rmsnorm_rope_scatter(qkv[:, :d], wn, 1e-6, cs, sn, dh, lay.flat, lay.off[0], lay.ld),
-            ops.rmsnorm_rope_scatter(qkv[:, d:2 * d], wn, 1e-6, cs, sn, dh, lay.flat, lay.off[1], lay.ld),
-            ops.rmsnorm_rope_scatter(qkv[:, 2 * d:], None, 0.0, None, None, dh, lay.flat, lay.off[2], lay.ld))),
+        "q | k norm + rope + scatter of q, k, v into the send buffer, ONE launch (round 3: replaces the two lines above)": t_us(
+            lambda: ops.qkv_rmsnorm_rope_(qkv, d, wn, 1e-6, wn, 1e-6, cs, sn, dh, out=lay.flat, head_off=lay.off_qkv,
+                                          head_ld=lay.ld)),
+        "q | k norm + rope in place, ONE launch (round 3, the 1-GPU forward)": t_us(
+            lambda: ops.qkv_rmsnorm_rope_(qkv, d, wn, 1e-6, wn, 1e-6, cs, sn, dh)),
+        "out-projection (gated residual) on [token, D]": t_us(lambda: ops.gemm(att, wo, bqkv[:d], ops.EPI_GATED_RESIDUAL, xres, gt, sl, out=xres)),
+        "out-projection reading the returned blocks (fino_gemm_blocked_a; replaces unpack + the line above)": t_us(
+            lambda: ops.gemm_blocked_a(oh, n, wo, bqkv[:d], xres, gt, sl, out=xres)),
         "unpack (torch permute copy)": t_us(lambda: att.view(n, P, dp).copy_(oh[:, :n].permute(1, 0, 2))),
         "attention H/P heads x L x L": t_us(lambda: ops.attention(r3[:, :, :dp], r3[:, :, dp:2 * dp], r3[:, :, 2 * dp:], hp,
                                                                   out=oh.view(1, P * lpad, dp)[:, :L])),
