@@ -886,6 +886,301 @@ inline SplitPlan plan_split(int batch, int heads, int nqb, int nt) {
     return sp;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// FREE-RUNNING kernel (round 3): 4 waves x 32 query rows per workgroup, TWO workgroups per CU (<= 256 registers), ONE barrier
+// per key tile, K / V tiles by LDS-DMA into the same 2 + 2 XOR-swizzled ring slots as the ping-pong kernel (the swizzle is
+// applied to the DMA's source offsets).  Built for SHORT key sequences -- the text cross-attention, 8 key tiles per
+// workgroup -- where a workgroup of the ping-pong kernel spends 12 of its 27 us in load / store latency with nothing else
+// resident on its CU (profiles/r03_attn_cross_stamp.txt): here the second workgroup's loop runs under the first one's
+// prologue and epilogue.  Whole blocks only (no tail split, no partials).
+constexpr int kFrWaves = 4;
+constexpr int kFrQBlock = kFrWaves * kQRowsPerWave;      // 128
+
+template <typename T, int D>
+__global__ __launch_bounds__(kFrWaves * 64, D == 64 ? 3 : 2) void attn_fr_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kTileBytes = kKV * D * 2;
+    constexpr int kKS = D / 16;
+    constexpr int kDT = D / 32;
+    constexpr int kChunks = D / 8;                          // 16-byte chunks per row
+    constexpr int kRPP = 1024 / (D * 2);                    // tile rows per 1-KiB DMA piece (one wave instruction)
+    constexpr int kPW = kTileBytes / 1024 / kFrWaves;       // DMA pieces per wave and tile (K and V each)
+    typedef typename T::vec8 vec8;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int xcd = blockIdx.x & 7;
+    int hb, qb;
+    if (!attn_map_block(p, xcd, (int)(blockIdx.x >> 3), hb, qb)) return;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    const int lk = p.lk;
+    const int nt = (lk + kKV - 1) / kKV;
+
+    // ---- K / V staging: piece (4 i + wave) of a tile = rows [(4 i + wave) kRPP, + kRPP); the lane's row inside the piece and
+    //      its chunk position are fixed, and so is the swizzle (it depends on row bits a piece step of 4 kRPP rows leaves
+    //      alone): ONE per-lane offset per operand, the piece and tile advance ride in the scalar offset ----
+    const int rip = lane / kChunks, pos = lane % kChunks;
+    const int srow = wave * kRPP + rip;
+    const int kswz = (k_lds_off<D>(srow, 0) >> 4) & (kChunks - 1), vswz = (lds_off<D>(srow, 0) >> 4) & (kChunks - 1);
+    const uint32_t k_voff = (uint32_t)((srow * p.k_rs + ((pos ^ kswz) << 3)) * 2);
+    const uint32_t v_voff = (uint32_t)((srow * p.v_rs + ((pos ^ vswz) << 3)) * 2);
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)kp, 0, (int)((((int64_t)lk - 1) * p.k_rs + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)vp, 0, (int)((((int64_t)lk - 1) * p.v_rs + D) * 2), 0x00020000);
+    const int k_piece_bytes = (int)(4 * kRPP * p.k_rs * 2), v_piece_bytes = (int)(4 * kRPP * p.v_rs * 2);
+    const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
+    // rows past the last key fail the resource's range check: the DMA writes zeros (masked in the ragged last tile)
+#define FR_DMA_K(TILE_, SLOT_)                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < kPW; ++i_)                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (FINO_LDS void*)(smem + (SLOT_) * kTileBytes + (4 * i_ + wave) * 1024), \
+                                                 16, k_voff, (TILE_) * k_tile_bytes + i_ * k_piece_bytes, 0, 0);
+#define FR_DMA_V(TILE_, SLOT_)                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < kPW; ++i_)                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (FINO_LDS void*)(smem + (2 + (SLOT_)) * kTileBytes + (4 * i_ + wave) * 1024), \
+                                                 16, v_voff, (TILE_) * v_tile_bytes + i_ * v_piece_bytes, 0, 0);
+    FR_DMA_K(0, 0)
+    FR_DMA_V(0, 0)
+    FR_DMA_K(1, 1)
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
+    const int qrow = qb * kFrQBlock + wave * kQRowsPerWave + r;
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+    vec8 qf[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);
+        qf[ks] = __builtin_bit_cast(vec8, u);
+    }
+
+    const int tq = (lane & 15) >> 2;
+    const int tp = lane & 3;
+    const int g1 = (lane >> 4) & 1;
+    f32x16_t o[kDT];
+#pragma unroll
+    for (int i = 0; i < kDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+    const float c2 = p.scale_log2;
+
+    if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
+#define LDS_PTR(TYPE_, ADDR_) ((FINO_LDS TYPE_*)(uintptr_t)(uint32_t)(ADDR_))
+    uint32_t ka0 = k_lds_off<D>(r, h);                                       // K ring slot 0 first (S(0)), then toggled
+    uint32_t vl0 = 2 * kTileBytes + lds_off<D>(4 * h + tq, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+    uint32_t vh0 = 2 * kTileBytes + lds_off<D>(4 * h + tq + 8, 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16_t sc0, sc1;
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // Every LDS read of the loop is inline asm: the compiler puts s_waitcnt vmcnt(0) in front of any LDS read IT can see
+    // while LDS-DMA writes are in flight (it cannot tell the ring slots apart), which would make the DMA of the next tiles
+    // land before this tile's first MFMA instead of under the whole tile.  The waits are explicit and tied to the loaded
+    // registers ("+v"), so no consumer can be scheduled above them.
+    // K fragments of k-steps 2 G_, 2 G_ + 1 (rows r and 32 + r): 4 x ds_read_b128
+#define FR_KISSUE(G_, B_)                                                                                    \
+    {                                                                                                        \
+        const uint32_t a_ = ka0 ^ ((2 * (G_)) << 5), b_ = ka0 ^ ((2 * (G_) + 1) << 5);                       \
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%6\n\t"                              \
+                     "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:%6"                                  \
+                     : "=&v"(kf[B_][0]), "=&v"(kf[B_][1]), "=&v"(kf[B_][2]), "=&v"(kf[B_][3])                \
+                     : "v"(a_), "v"(b_), "n"(32 * D * 2));                                                   \
+    }
+#define FR_KWAIT(N_, B_)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(kf[B_][0]), "+v"(kf[B_][1]), "+v"(kf[B_][2]), "+v"(kf[B_][3]));
+    // V^T fragments of key step STEP_ (16 keys) for d-tile pair (2 P_, 2 P_ + 1): 4 x ds_read_b64_tr_b16
+#define FR_VISSUE(STEP_, P_, B_)                                                                             \
+    {                                                                                                        \
+        const uint32_t l0_ = vl0 ^ ((2 * (P_)) << 6), h0_ = vh0 ^ ((2 * (P_)) << 6);                         \
+        const uint32_t l1_ = vl0 ^ ((2 * (P_) + 1) << 6), h1_ = vh0 ^ ((2 * (P_) + 1) << 6);                 \
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%8\n\tds_read_b64_tr_b16 %1, %5 offset:%8\n\t"        \
+                     "ds_read_b64_tr_b16 %2, %6 offset:%8\n\tds_read_b64_tr_b16 %3, %7 offset:%8"            \
+                     : "=&v"(vf[B_][0]), "=&v"(vf[B_][1]), "=&v"(vf[B_][2]), "=&v"(vf[B_][3])                \
+                     : "v"(l0_), "v"(h0_), "v"(l1_), "v"(h1_), "n"((STEP_) * 16 * D * 2));                   \
+    }
+#define FR_VWAIT(N_, B_)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(vf[B_][0]), "+v"(vf[B_][1]), "+v"(vf[B_][2]), "+v"(vf[B_][3]));
+    u32x4_t kf[2][4];
+    s16x4_t vf[2][4];
+    // S^T = K . Q^T of the tile in the K ring slot ka0 addresses: k-steps in pairs, the next pair's reads under this pair's MFMAs
+#define FR_QK()                                                                                              \
+    {                                                                                                        \
+        FR_KISSUE(0, 0)                                                                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < kKS / 2; ++g_) {                                             \
+            if (g_ + 1 < kKS / 2) {                                                                          \
+                if ((g_ & 1) == 0) { FR_KISSUE(g_ + 1, 1) FR_KWAIT(4, 0) } else { FR_KISSUE(g_ + 1, 0) FR_KWAIT(4, 1) } \
+            } else {                                                                                         \
+                if ((g_ & 1) == 0) { FR_KWAIT(0, 0) } else { FR_KWAIT(0, 1) }                                \
+            }                                                                                                \
+            const int bb_ = g_ & 1;                                                                          \
+            sc0 = T::mfma32(__builtin_bit_cast(vec8, kf[bb_][0]), qf[2 * g_], g_ == 0 ? zero16 : sc0);       \
+            sc1 = T::mfma32(__builtin_bit_cast(vec8, kf[bb_][1]), qf[2 * g_], g_ == 0 ? zero16 : sc1);       \
+            sc0 = T::mfma32(__builtin_bit_cast(vec8, kf[bb_][2]), qf[2 * g_ + 1], sc0);                      \
+            sc1 = T::mfma32(__builtin_bit_cast(vec8, kf[bb_][3]), qf[2 * g_ + 1], sc1);                      \
+        }                                                                                                    \
+    }
+#define FR_MASK(T_)                                                                                          \
+    if ((T_) == nt - 1 && (lk & (kKV - 1))) {                                                                \
+        const int kbase_ = (T_) * kKV + 4 * h;                                                               \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                  \
+            const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);                                              \
+            if (key_ >= lk) sc0[j_] = -INFINITY;                                                             \
+            if (key_ + 32 >= lk) sc1[j_] = -INFINITY;                                                        \
+        }                                                                                                    \
+    }
+#define FR_ROWMAX(OUT_)                                                                                      \
+    {                                                                                                        \
+        float mx_ = fmaxf(sc0[0], sc1[0]);                                                                   \
+        _Pragma("unroll") for (int j_ = 1; j_ < 16; ++j_) mx_ = fmaxf(mx_, fmaxf(sc0[j_], sc1[j_]));         \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false); \
+        OUT_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                      \
+    }
+    FR_QK()
+    FR_MASK(0)
+    float mx_next;
+    FR_ROWMAX(mx_next)
+    ka0 ^= kTileBytes;                                       // -> K(1)
+    __syncthreads();                                         // every wave is done with K(0): its slot takes K(2)
+
+    for (int t = 0; t < nt; ++t) {
+        // K(t+2) into the slot K(t) left, V(t+1) into the slot V(t-1) left: a whole tile of compute to land under
+        FR_DMA_K(t + 2, t & 1)
+        FR_DMA_V(t + 1, (t + 1) & 1)
+        {
+            const float m_cand = fmaxf(m_run, mx_next * c2);
+            if (__any((m_cand - m_run) > rescale_thr<T>())) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+                m_run = m_cand;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < kDT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);
+            sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);
+        }
+        {
+            float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                psum0 += sc0[j];
+                psum1 += sc1[j];
+            }
+            l_run += psum0 + psum1;
+        }
+        vec8 pb[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pb[0][j] = (typename T::scalar)sc0[j];
+            pb[1][j] = (typename T::scalar)sc0[8 + j];
+            pb[2][j] = (typename T::scalar)sc1[j];
+            pb[3][j] = (typename T::scalar)sc1[8 + j];
+        }
+        // S(t+1) for every t: past the last tile the K slot holds the zeros of an out-of-range DMA and the result is dropped
+        FR_QK()
+        FR_MASK(t + 1)
+        // O^T += V(t)^T . P(t)^T: 4 key steps x (kDT / 2) d-tile pairs, the next fragment group's reads under this one's MFMAs
+        {
+            constexpr int kNG = 4 * (kDT / 2);                     // fragment groups: g = step * (kDT / 2) + pair
+            FR_VISSUE(0, 0, 0)
+#pragma unroll
+            for (int gi = 0; gi < kNG; ++gi) {
+                const int step = gi / (kDT / 2), pr = gi % (kDT / 2);
+                if (gi + 1 < kNG) {
+                    const int ns = (gi + 1) / (kDT / 2), np = (gi + 1) % (kDT / 2);
+                    // (macro arguments must be literals for the immediate offset: dispatch on the step)
+                    if ((gi & 1) == 0) {
+                        if (ns == 0) { FR_VISSUE(0, np, 1) } else if (ns == 1) { FR_VISSUE(1, np, 1) }
+                        else if (ns == 2) { FR_VISSUE(2, np, 1) } else { FR_VISSUE(3, np, 1) }
+                        FR_VWAIT(4, 0)
+                    } else {
+                        if (ns == 0) { FR_VISSUE(0, np, 0) } else if (ns == 1) { FR_VISSUE(1, np, 0) }
+                        else if (ns == 2) { FR_VISSUE(2, np, 0) } else { FR_VISSUE(3, np, 0) }
+                        FR_VWAIT(4, 1)
+                    }
+                } else {
+                    if ((gi & 1) == 0) { FR_VWAIT(0, 0) } else { FR_VWAIT(0, 1) }
+                }
+                const int bb = gi & 1;
+                const s16x8_t va0 = __builtin_shufflevector(vf[bb][0], vf[bb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const s16x8_t va1 = __builtin_shufflevector(vf[bb][2], vf[bb][3], 0, 1, 2, 3, 4, 5, 6, 7);
+                o[2 * pr] = T::mfma32(__builtin_bit_cast(vec8, va0), pb[step], o[2 * pr]);
+                o[2 * pr + 1] = T::mfma32(__builtin_bit_cast(vec8, va1), pb[step], o[2 * pr + 1]);
+            }
+        }
+        FR_ROWMAX(mx_next)
+        ka0 ^= kTileBytes;
+        vl0 ^= kTileBytes;
+        vh0 ^= kTileBytes;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef FR_KISSUE
+#undef FR_KWAIT
+#undef FR_VISSUE
+#undef FR_VWAIT
+#undef FR_DMA_K
+#undef FR_DMA_V
+#undef FR_QK
+#undef FR_MASK
+#undef FR_ROWMAX
+#undef LDS_PTR
+
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l_run;
+    if (qrow < p.lq) {
+        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
+                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+            }
+        }
+    }
+}
+
+template <typename T, int D>
+int launch_attn_fr(AttnParams p, hipStream_t st) {
+    constexpr int smem = 4 * kKV * D * 2;
+    static FinoPerDeviceOnce once;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&attn_fr_kernel<T, D>), smem, "fino_attn_fwd")) return rc;
+    p.nqb = (p.lq + kFrQBlock - 1) / kFrQBlock;
+    p.ws = nullptr; p.all_partial = 0;
+    attn_virtual_heads(p.batch, p.heads, p.nqb, p.vsplit, p.nqb_v);
+    const int groups = (p.batch * p.heads * p.vsplit + 7) / 8;
+    p.full_x = groups * p.nqb_v; p.rem_x = 0; p.nwg = 0; p.per = 1;
+    attn_fr_kernel<T, D><<<dim3((unsigned)(8 * p.full_x)), kFrWaves * 64, smem, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
 template <typename T, int D, int VAR>
 int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
@@ -893,6 +1188,12 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
         const char* ev = getenv("FINO_ATTN_PP");          // A/B knob: 0 selects the one-barrier loop
         return !(ev && ev[0] == '0') && kWaves == 8;
     }();
+    // the free-running kernel (two workgroups of 4 waves per CU): FINO_TUNE_ATTN_KERNEL = 3, and by default for the short key
+    // sequences of the text cross-attention at head_dim 128 (whole blocks only: never for fino_attn_partial)
+    {
+        const int tk = fino_tune_get(FINO_TUNE_ATTN_KERNEL);
+        if (!p.all_partial && (tk == 3 || (tk == 0 && VAR == 1 && D == 128))) return launch_attn_fr<T, D>(p, st);
+    }
     static FinoPerDeviceOnce once_a, once_b;
     if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
         return rc;

@@ -607,3 +607,33 @@ def test_rmsnorm_rope_scatter_equals_inplace_kernel_plus_permute_copy(ways, grou
     assert torch.equal(lay2.flat, lay.flat) and torch.equal(qkv, before)
     ops.qkv_rmsnorm_rope_(qkv, d, wq, 1e-6, wk, 1e-6, cos, sin, dh, q_out_scale=c)
     assert torch.equal(qkv, ref)
+
+
+@pytest.mark.parametrize("b,heads,lq,lk,dh", [(2, 24, 1000, 512, 128), (1, 3, 300, 77, 128), (2, 2, 129, 1024, 128),
+                                              (1, 4, 513, 640, 64), (1, 24, 3080, 12320, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_free_running_attention_kernel_equals_the_ping_pong_kernel(b, heads, lq, lk, dh, dtype):
+    """attn_fr_kernel (4 waves, two workgroups per CU, LDS-DMA staging; FINO_TUNE_ATTN_KERNEL = 3, the default for the text
+    cross-attention at head_dim 128): the same arithmetic in the same order as the 8-wave ping-pong kernel -- bit-identical
+    outputs on ragged shapes, strided q / k / v, rows past Lq untouched"""
+    from frameino_amd import _lib, ops
+    d = heads * dh
+    g = torch.Generator(device=DEV).manual_seed(lq * 7 + lk)
+    q = torch.randn(b, lq, d + 64, device=DEV, generator=g).to(dtype)[:, :, :d]
+    kv = torch.randn(b, lk, 2 * d + 64, device=DEV, generator=g).to(dtype)
+    k, v = kv[:, :, :d], kv[:, :, d:2 * d]
+    lib = _lib.lib()
+    split = ops.SPLIT_ATTENTION_TAIL
+    try:
+        lib.fino_tune_set(4, 1)
+        ops.SPLIT_ATTENTION_TAIL = False       # whole blocks, as the free-running kernel runs them (the tail split merges
+        want = ops.attention(q, k, v, heads)   # key-range partials: the same numbers up to one rounding of the merge)
+        ops.SPLIT_ATTENTION_TAIL = split
+        lib.fino_tune_set(4, 3)
+        out = torch.zeros(b, lq + 5, d, device=DEV, dtype=dtype)
+        got = ops.attention(q, k, v, heads, out=out[:, :lq])
+    finally:
+        lib.fino_tune_set(4, 0)
+        ops.SPLIT_ATTENTION_TAIL = split
+    assert torch.isfinite(got.float()).all() and not out[:, lq:].any()
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()

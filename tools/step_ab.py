@@ -41,6 +41,9 @@ settings = {"r01 (group_m 4, no dedup, 8-wave attention)": (4, False, 1, False),
             "+ 4-wave attention kernel": (0, True, 0, False), "+ softmax scale folded into q (MFMA fold)": (0, True, 0, True)}
 if "--tiles" in sys.argv:      # round 3: GEMM tile heights (FINO_TUNE_GEMM_TILE_M: 8 = 256-row tiles only, 0 = planned), default kernels otherwise
     settings = {"256-row GEMM tiles only": (0, True, 1, False, 8), "planned GEMM tile heights": (0, True, 1, False, 0)}
+if "--cross" in sys.argv:      # round 3: text cross-attention on the 8-wave ping-pong kernel (tune 1) vs the free-running one (default policy)
+    settings = {"cross-attention: 8-wave ping-pong kernel": (0, True, 1, False, 0),
+                "cross-attention: free-running kernel (default)": (0, True, 0, False, 0)}
 res = {k: [] for k in settings}
 
 
