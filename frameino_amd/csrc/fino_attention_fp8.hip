@@ -728,70 +728,83 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
     }
     float ex_next = 0.f;
 
-    for (int t = 0; t < nt; ++t) {
-        // tile t + 3 into the slot tile t - 1 left (its last reads ended before the previous barrier)
-        FR_DMA(t + 3)
-        // K fragments of S(t+1): they land under the exp2 work
-        FR_KREAD((t + 1) & (kFrRing - 1))
-        if (__any(ex_next > (float)kPShift + kThr8)) {        // deferred rescale (see the ping-pong kernel)
-            const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
-            const float dm = mn - m_run;
-            m_run = mn;
-            const float alpha = __builtin_amdgcn_exp2f(-dm);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                s0[j] -= dm; s1[j] -= dm;
-                o[0][j] *= alpha; o[1][j] *= alpha; lacc[j] *= alpha;
-            }
-        }
-        i32x8_t pf;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i]), __builtin_amdgcn_exp2f(s0[4 * i + 1]),
-                                   __builtin_amdgcn_exp2f(s0[4 * i + 2]), __builtin_amdgcn_exp2f(s0[4 * i + 3]));
-            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i]), __builtin_amdgcn_exp2f(s1[4 * i + 1]),
-                                       __builtin_amdgcn_exp2f(s1[4 * i + 2]), __builtin_amdgcn_exp2f(s1[4 * i + 3]));
-        }
-        {
-            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
-            const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
-            const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
-            FR_QK(c0, c0, s0, s1)
-        }
-        // V fragments only now: they take the registers the K fragments leave (168 registers per wave is the whole budget
-        // of three waves per SIMD) and land under the two S MFMAs and the other waves' work
-        __builtin_amdgcn_sched_barrier(0);
-        i32x4_t vf0[kDT], vf1[kDT];
-        int vsr[kDT];
-        {
-            const char* vb = smem + kFrLdsV + (t & (kFrRing - 1)) * kTileK8;
-            const char* vsb = smem + kFrLdsVS + (t & (kFrRing - 1)) * 128;
-#pragma unroll
-            for (int dt = 0; dt < kDT; ++dt) {
-                vf0[dt] = *reinterpret_cast<const i32x4_t*>(vb + dt * 2048 + la0);
-                vf1[dt] = *reinterpret_cast<const i32x4_t*>(vb + dt * 2048 + la1);
-                vsr[dt] = *reinterpret_cast<const uint8_t*>(vsb + dt * 64 + ls0);
-            }
-        }
+    // One key tile: P(t) from SI (= S(t) - m), S(t+1) into SO, O += V(t) P(t).  The loop below runs it twice per trip with
+    // the two S register sets swapped: with one set the loop-carried S costs 16 v_mov_b64 per tile (the MFMAs cannot
+    // write S(t+1) over the registers exp2 is still reading, and the back edge copies it home).
 #define FR_PV(DT_)                                                                                           \
         {                                                                                                    \
             const i32x8_t vv_ = __builtin_shufflevector(vf0[DT_], vf1[DT_], 0, 1, 2, 3, 4, 5, 6, 7);         \
             o[DT_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv_, pf, o[DT_], 0, 0, 0, vsr[DT_], 0, kPs); \
         }
-        FR_PV(0)
-        FR_MASK(t + 1, s0, s1)
-        float mxa = max16_behind(s0, o[0][0]);
-        FR_PV(1)
-        const float mxb = max16_behind(s1, o[1][0]);
-        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
-        mxa = vmax2(mxa, mxb);
-        FR_SWAPMAX(mxa, ex_next)
-#undef FR_PV
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     // tile t + 2 has landed (t + 3 may be in flight)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+#define FR_TILE(T_, SI0_, SI1_, SO0_, SO1_)                                                                  \
+    {                                                                                                        \
+        const int t = (T_);                                                                                  \
+        /* tile t + 3 into the slot tile t - 1 left (its last reads ended before the previous barrier) */     \
+        FR_DMA(t + 3)                                                                                        \
+        /* K fragments of S(t+1): they land under the exp2 work */                                           \
+        FR_KREAD((t + 1) & (kFrRing - 1))                                                                    \
+        if (__any(ex_next > (float)kPShift + kThr8)) {        /* deferred rescale (see the ping-pong kernel) */ \
+            const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));           \
+            const float dm = mn - m_run;                                                                     \
+            m_run = mn;                                                                                      \
+            const float alpha = __builtin_amdgcn_exp2f(-dm);                                                 \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                 \
+                /* s -= dm IN PLACE ("+v"): no fresh registers on this path, no copies at the join */        \
+                asm volatile("v_sub_f32 %0, %0, %2\n\tv_sub_f32 %1, %1, %2" : "+v"(SI0_[j]), "+v"(SI1_[j]) : "v"(dm)); \
+                o[0][j] *= alpha; o[1][j] *= alpha; lacc[j] *= alpha;                                        \
+            }                                                                                                \
+        }                                                                                                    \
+        i32x8_t pf;                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(SI0_[4 * i]), __builtin_amdgcn_exp2f(SI0_[4 * i + 1]), \
+                                   __builtin_amdgcn_exp2f(SI0_[4 * i + 2]), __builtin_amdgcn_exp2f(SI0_[4 * i + 3])); \
+            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(SI1_[4 * i]), __builtin_amdgcn_exp2f(SI1_[4 * i + 1]), \
+                                       __builtin_amdgcn_exp2f(SI1_[4 * i + 2]), __builtin_amdgcn_exp2f(SI1_[4 * i + 3])); \
+        }                                                                                                    \
+        {                                                                                                    \
+            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);                \
+            const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);     \
+            const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);                                             \
+            FR_QK(c0, c0, SO0_, SO1_)                                                                        \
+        }                                                                                                    \
+        /* V fragments only now: they take the registers the K fragments leave (168 registers per wave is the whole  \
+           budget of three waves per SIMD) and land under the two S MFMAs and the other waves' work */       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        i32x4_t vf0[kDT], vf1[kDT];                                                                          \
+        int vsr[kDT];                                                                                        \
+        {                                                                                                    \
+            const char* vb = smem + kFrLdsV + (t & (kFrRing - 1)) * kTileK8;                                 \
+            const char* vsb = smem + kFrLdsVS + (t & (kFrRing - 1)) * 128;                                   \
+            _Pragma("unroll") for (int dt = 0; dt < kDT; ++dt) {                                             \
+                vf0[dt] = *reinterpret_cast<const i32x4_t*>(vb + dt * 2048 + la0);                           \
+                vf1[dt] = *reinterpret_cast<const i32x4_t*>(vb + dt * 2048 + la1);                           \
+                vsr[dt] = *reinterpret_cast<const uint8_t*>(vsb + dt * 64 + ls0);                            \
+            }                                                                                                \
+        }                                                                                                    \
+        FR_PV(0)                                                                                             \
+        FR_MASK(t + 1, SO0_, SO1_)                                                                           \
+        float mxa = max16_behind(SO0_, o[0][0]);                                                             \
+        FR_PV(1)                                                                                             \
+        const float mxb = max16_behind(SO1_, o[1][0]);                                                       \
+        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);      \
+        mxa = vmax2(mxa, mxb);                                                                               \
+        FR_SWAPMAX(mxa, ex_next)                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     /* tile t + 2 has landed (t + 3 may be in flight) */ \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
+    {
+        f32x16_t sb0, sb1;
+        int tt = 0;
+        for (; tt + 1 < nt; tt += 2) {
+            FR_TILE(tt, s0, s1, sb0, sb1)
+            FR_TILE(tt + 1, sb0, sb1, s0, s1)
+        }
+        if (tt < nt) FR_TILE(tt, s0, s1, sb0, sb1)
+    }
+#undef FR_TILE
+#undef FR_PV
 #undef FR_DMA
 #undef FR_KREAD
 #undef FR_QK
