@@ -312,8 +312,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmParams p) {
 // later must find them landed, and only its own vmcnt wait can vouch for that), group 1 the rest.
 // byte offset of K-tile kt inside a row of a K-blocked A (GemmParams::a_tpb): block j = kt / a_tpb starts at j * a_blk_elems
 __device__ __forceinline__ int ablk_koff(const GemmParams& p, int kt) {
-    const int j = (kt * p.a_inv) >> 16;
-    return j * (int)(p.a_blk_elems * 2) + (kt - j * p.a_tpb) * (BK * 2);
+    const int b = (kt * p.a_inv) >> 16;              // K block
+    const int j = (b * p.a_ginv) >> 16;              // peer; g = b - j * a_groups: head group
+    return (b - j * p.a_groups) * (int)(p.a_grp_elems * 2) + j * (int)(p.a_blk_elems * 2) + (kt - b * p.a_tpb) * (BK * 2);
 }
 
 template <typename T, bool CONV, int MI, bool ABLK = false>
@@ -343,7 +344,9 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     int ck = 0, tap_t = 0, tap_h = 0, tap_w = 0, t_first = 0, t_in_first = 0;
     const uint16_t* a_base_ptr = p.a;
     int64_t a_bytes = ((p.m - 1) * p.lda + p.k) * 2;
-    if constexpr (ABLK) a_bytes = ((p.k / (BK * p.a_tpb) - 1) * p.a_blk_elems + (p.m - 1) * p.lda + BK * p.a_tpb) * 2;
+    if constexpr (ABLK)
+        a_bytes = ((p.a_groups - 1) * p.a_grp_elems + (p.k / (BK * p.a_tpb) / p.a_groups - 1) * p.a_blk_elems +
+                   (p.m - 1) * p.lda + BK * p.a_tpb) * 2;
     if constexpr (CONV) {
         const int hw = p.ho * p.wo;
         t_first = (int)(m0 / hw);
@@ -808,7 +811,8 @@ extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias,
 }
 
 extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
-                                   int64_t a_block_k, int64_t a_block_stride, int64_t lda, int64_t ldw, int64_t ldc,
+                                   int64_t a_block_k, int64_t a_block_stride, int a_groups, int64_t a_group_stride,
+                                   int64_t lda, int64_t ldw, int64_t ldc,
                                    const void* r, int64_t ldr, const float* gate, int64_t mod_stride, const int32_t* sel,
                                    int dtype, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm_blocked_a: dtype %d", dtype);
@@ -823,7 +827,10 @@ extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bia
     FINO_CHECK(fino_aligned16(a) && fino_aligned16(w) && fino_aligned16(c) && fino_aligned16(r) && fino_aligned16(gate),
                FINO_ERR_ARG, "fino_gemm_blocked_a: 16-byte alignment required");
     const int64_t nblk = k / a_block_k;
-    const int64_t span = ((nblk - 1) * a_block_stride + (m > 0 ? m - 1 : 0) * lda + a_block_k) * 2;
+    FINO_CHECK(a_groups >= 1 && a_groups <= 16 && nblk % a_groups == 0 && a_group_stride % 8 == 0, FINO_ERR_ARG,
+               "fino_gemm_blocked_a: a_groups=%d must divide the %lld K blocks", a_groups, (long long)nblk);
+    const int64_t span = ((a_groups - 1) * a_group_stride + (nblk / a_groups - 1) * a_block_stride +
+                          (m > 0 ? m - 1 : 0) * lda + a_block_k) * 2;
     FINO_CHECK(span < (1ll << 31) && ((n - 1) * ldw + k) * 2 < (1ll << 31), FINO_ERR_ARG,
                "fino_gemm_blocked_a: operands must span < 2 GiB");
     if (m == 0) return FINO_OK;
@@ -832,6 +839,7 @@ extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bia
     p.r = (const uint16_t*)r; p.gate = gate; p.sel = sel;
     p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
     p.a_tpb = (int)(a_block_k / BK); p.a_inv = (65536 + p.a_tpb - 1) / p.a_tpb; p.a_blk_elems = a_block_stride;
+    p.a_groups = a_groups; p.a_ginv = (65536 + a_groups - 1) / a_groups; p.a_grp_elems = a_group_stride;
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
     p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);

@@ -31,6 +31,10 @@ struct GemmParams {
     // [heads of that peer]); a_inv = ceil(65536 / a_tpb) turns the K-tile index into its block by a multiply and a shift
     int a_tpb, a_inv;
     int64_t a_blk_elems;
+    // ... and two-level: K block b = j * a_groups + g lives at a + g * a_grp_elems + j * a_blk_elems (the heads travel in
+    // a_groups groups, each group's all-to-all returning its own [peer][token][heads] buffer); a_ginv = ceil(65536 / a_groups)
+    int a_groups, a_ginv;
+    int64_t a_grp_elems;
     // implicit-GEMM convolution (CONV variant): A is a channels-last activation [T_in, H_in, W_in, lda]; row m of the
     // GEMM is output position (t, h, w); K runs tap-major, channel-minor (cin_chunks x 64 channels per tap).
     int to, ho, wo, ti, hi, wi;      // output / input extents

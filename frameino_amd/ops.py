@@ -346,20 +346,23 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
 
 
 def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
-    """out = residual + gate[sel] * (A.W^T + bias) with A given as K blocks: a_blocks [nblk, rows_pad, blk_k] (last two dims
-    row-strided), A[i, j * blk_k + c] = a_blocks[j, i, c] for i < rows.  fino_gemm_blocked_a: the out-projection reading the
-    heads exchange's return buffer as it arrived."""
-    assert a_blocks.dim() == 3 and a_blocks.stride(2) == 1 and w.dtype == a_blocks.dtype and w.stride(1) == 1
-    nblk, _, bk = a_blocks.shape
+    """out = residual + gate[sel] * (A.W^T + bias) with A given as K blocks: a_blocks [nblk, rows_pad, blk_k], or
+    [groups, peers, rows_pad, blk_k] with K block j * groups + g at a_blocks[g, j] (last dims row-strided):
+    A[i, b * blk_k + c] = block b [i, c] for i < rows.  fino_gemm_blocked_a: the out-projection reading the heads exchange's
+    return buffers as they arrived."""
+    if a_blocks.dim() == 3:
+        a_blocks = a_blocks[None]
+    assert a_blocks.dim() == 4 and a_blocks.stride(3) == 1 and w.dtype == a_blocks.dtype and w.stride(1) == 1
+    groups, peers, _, bk = a_blocks.shape
     n, k = w.shape
-    assert k == nblk * bk and residual.shape == (rows, n) and out.shape == (rows, n)
+    assert k == groups * peers * bk and residual.shape == (rows, n) and out.shape == (rows, n)
     r2, _, _, ldr = _rows2d(residual)
     o2, _, _, ldc = _rows2d(out)
     ms = gate.stride(0) if gate.dim() == 2 else 0
     ev = _timed("gemm")
-    _lib.check(_lib.lib().fino_gemm_blocked_a(_p(a_blocks), _p(w), _p(bias), _p(o2), rows, n, k, bk, a_blocks.stride(0),
-                                              a_blocks.stride(1), w.stride(0), ldc, _p(r2), ldr, _p(gate), ms, _p(sel),
-                                              _dt(a_blocks), _stream()), "fino_gemm_blocked_a")
+    _lib.check(_lib.lib().fino_gemm_blocked_a(_p(a_blocks), _p(w), _p(bias), _p(o2), rows, n, k, bk, a_blocks.stride(1),
+                                              groups, a_blocks.stride(0), a_blocks.stride(2), w.stride(0), ldc, _p(r2),
+                                              ldr, _p(gate), ms, _p(sel), _dt(a_blocks), _stream()), "fino_gemm_blocked_a")
     if ev is not None:
         ev.record()
         KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * rows * n * k

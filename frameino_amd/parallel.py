@@ -150,6 +150,23 @@ class TokenShard:
                 off_qkv=torch.tensor(off[0] + off[1] + off[2], dtype=torch.int64, device=dev))
         return lay
 
+    def heads_recv_layout(self, heads, dh, lpad, dtype, dev, key="o_recv"):
+        """The RETURN side of the heads exchange as one flat buffer [groups, ways, lpad, dg] when the head groups are equal
+        (None otherwise): group g's all-to-all receives into slice g -- registered here under the buffer key all_to_all
+        looks up (f"{key}{g}") -- so that the out-projection can read all of it as K blocks (ops.gemm_blocked_a)."""
+        ways, hp = self.ways, heads // self.ways
+        ranges = self.head_ranges(hp)
+        if len({b - a for a, b in ranges}) != 1:
+            return None
+        dg = (ranges[0][1] - ranges[0][0]) * dh
+        k = ("heads_recv_layout", key, heads, dh, lpad, dtype, str(dev), len(ranges))
+        flat = self._buf.get(k)
+        if flat is None:
+            flat = self._buf[k] = torch.zeros(len(ranges), ways, lpad, dg, dtype=dtype, device=dev)
+            for g in range(len(ranges)):
+                self._buf[(f"{key}{g}", (ways, lpad, dg), dtype, str(dev))] = flat[g]
+        return flat
+
     def all_to_all(self, key, send, async_op=False):
         """send [ways, rows, width] (slice j goes to rank j) -> (received [ways, rows, width]: slice j came from rank j,
         work handle or None).  Without async_op the call is blocking in stream order."""

@@ -527,6 +527,10 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                         send = sh.a2a_buffer(f"qkv_send{gi}", (ways, lpad, 3, dg), dt, dev)   # slice j: heads of rank j
                         send[:, :n].copy_(q4[:, :, :, h0 * dh:h1 * dh].permute(2, 0, 1, 3))
                     inflight.append((gi, h0, h1, dg) + sh.all_to_all(f"qkv_recv{gi}", send, async_op=True))
+                # the outputs return into ONE flat [group][rank j's heads][token] buffer when the groups are equal: the
+                # out-projection then reads it as K blocks (fino_gemm_blocked_a) instead of a permute copy into [token, D]
+                orl = (sh.heads_recv_layout(heads, dh, lpad, dt, dev)
+                       if (not self._fp8 and hasattr(o, "gemm_blocked_a") and hasattr(sh, "heads_recv_layout")) else None)
                 back = []
                 for gi, h0, h1, dg, recv, work in inflight:                                # slice j: tokens of rank j
                     if work is not None:
@@ -536,13 +540,11 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     o.attention(r3[:, :, :dg], r3[:, :, dg:2 * dg], r3[:, :, 2 * dg:], h1 - h0,
                                 out=oh.view(1, ways * lpad, dg)[:, :L], **afold)
                     back.append((h0, h1) + sh.all_to_all(f"o_recv{gi}", oh, async_op=True))
-                if len(back) == 1 and not self._fp8 and hasattr(o, "gemm_blocked_a"):
-                    # one head group: the out-projection reads the returned [rank j's heads][token] blocks as they arrived
-                    # (fino_gemm_blocked_a) instead of a permute copy into [token, D] first
-                    _, _, orv, work = back[0]
-                    if work is not None:
-                        work.wait()
-                    o.gemm_blocked_a(orv, n, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, x, m[:, 2], sel, out=x)
+                if orl is not None and all(orv.data_ptr() == orl[gi].data_ptr() for gi, (_, _, orv, _) in enumerate(back)):
+                    for _, _, _, work in back:
+                        if work is not None:
+                            work.wait()
+                    o.gemm_blocked_a(orl, n, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, x, m[:, 2], sel, out=x)
                     once = True                                     # the common out-projection below is done
                 else:
                     a3 = att.view(n, ways, dp)

@@ -204,13 +204,16 @@ int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, i
                       int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
                       int64_t mod_stride, const int32_t* sel, int dtype, void* c2, int64_t ldc2, int64_t n_split,
                       void* stream);
-/* c = r + gate[sel] * (A w^T + bias) (FINO_EPI_GATED_RESIDUAL) with a K-BLOCKED A: columns [j * a_block_k, (j + 1) *
- * a_block_k) of row i live at a + j * a_block_stride + i * lda (elements; a_block_k a multiple of 64 dividing K).  That is
- * the layout in which the heads all-to-all returns the attention output to the token owners ([peer][token][heads of that
- * peer]): the out-projection (transformer_wan.py:336) reads it as it arrived, without the permute copy into [token, D]. */
+/* c = r + gate[sel] * (A w^T + bias) (FINO_EPI_GATED_RESIDUAL) with a K-BLOCKED A: K block b (columns [b * a_block_k,
+ * (b + 1) * a_block_k) of row i; a_block_k a multiple of 64 dividing K), b = j * a_groups + g, lives at
+ * a + g * a_group_stride + j * a_block_stride + i * lda (elements).  That is the layout in which the heads all-to-all
+ * returns the attention output to the token owners -- per head group g a buffer [peer j][token][heads of that peer in the
+ * group] -- so the out-projection (transformer_wan.py:336) reads it as it arrived, without the permute copy into
+ * [token, D].  a_groups = 1: one buffer [peer][token][heads of that peer]. */
 int fino_gemm_blocked_a(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
-                        int64_t a_block_k, int64_t a_block_stride, int64_t lda, int64_t ldw, int64_t ldc, const void* r,
-                        int64_t ldr, const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
+                        int64_t a_block_k, int64_t a_block_stride, int a_groups, int64_t a_group_stride, int64_t lda,
+                        int64_t ldw, int64_t ldc, const void* r, int64_t ldr, const float* gate, int64_t mod_stride,
+                        const int32_t* sel, int dtype, void* stream);
 
 /* The tiling fino_gemm uses for an M x N problem on the current device: `rows_256` leading rows run as 256 x 256 tiles
  * (a whole number of rounds of the CUs), the remaining rows as ONE more launch of `tile_rows_rest`-row tiles (64 .. 256

@@ -129,6 +129,8 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
 
 
 def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
+    if a_blocks.dim() == 4:                               # [groups, peers, rows_pad, bk]: K block j * groups + g = [g, j]
+        a_blocks = a_blocks.permute(1, 0, 2, 3).reshape(-1, a_blocks.shape[2], a_blocks.shape[3])
     a = a_blocks[:, :rows].permute(1, 0, 2).reshape(rows, -1)
     return gemm(a, w, bias, EPI_GATED_RESIDUAL, residual, gate, sel, out=out)
 

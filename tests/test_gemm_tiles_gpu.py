@@ -147,3 +147,11 @@ def test_blocked_a_out_projection_equals_the_permute_copy_plus_gemm(ways, n, lpa
     x2 = x.clone()
     ops.gemm_blocked_a(orv, n, w, b, x2, gate, sel, out=x2)          # in place on the residual, as the forward calls it
     assert torch.equal(x2, want)
+    # two head groups: K block j * 2 + g comes from the return buffer of group g, slice j
+    if (dp // 128) % 2 == 0:
+        dg = dp // 2
+        flat = torch.empty(2, ways, lpad, dg, device=DEV, dtype=torch.bfloat16)
+        flat[0].copy_(orv[:, :, :dg])
+        flat[1].copy_(orv[:, :, dg:])
+        got2 = ops.gemm_blocked_a(flat, n, w, b, x, gate, sel, out=torch.empty_like(x))
+        assert torch.equal(got2, want)
