@@ -496,6 +496,10 @@ def main():
         # the headline workload again with MXFP8 linears (e4m3 + e8m0 per 32; attention stays bf16): not the headline
         model.enable_mxfp8_linears()
         secondary["wan_704x1280_mxfp8_linears"] = other_workload_ms_per_step(pipe, make_inputs, cfg, dev, a.workload)
+        # ... and with fp8 (e4m3) attention operands on top (fino_attn_fwd_fp8 at head_dim 128): the whole step on the fp8 MFMA path
+        model.enable_fp8_attention()
+        secondary["wan_704x1280_mxfp8_linears_fp8_attention"] = other_workload_ms_per_step(pipe, make_inputs, cfg, dev, a.workload)
+        model.enable_fp8_attention(False)
         model.enable_mxfp8_linears(False)
         # (e) BASELINE config 5: CogVideoX-5B FrameINO 49f 480x720, bf16 and MXFP8 linears
         del pipe, st

@@ -829,12 +829,254 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// head_dim 128 (Wan2.2): the ping-pong kernel over TWO 64-channel sub-heads per head.  The K/V quantisation pre-pass runs
+// unchanged with 2 H "heads" of 64 channels (head stride 64), so sub-head s of head h is image 2 h + s: K8 lo | K8 hi and
+// V8T lo | V8T hi.  S^T = -m + K_lo . Q_lo^T + K_hi . Q_hi^T (two block-scaled MFMAs per 32-key half chained through the
+// accumulator), O^T has four 32-channel d-tiles (two per sub-head), everything else as attn_fp8_kernel: 8 waves, softmax /
+// matrix phases one apart, rings of kRing128 tiles filled by LDS-DMA a tile ahead, operand reads at the top of the matrix
+// phase.  Whole blocks only (no tail split, no partials).
+constexpr int kRing128 = 8;
+constexpr int kTile128 = 2 * kTileK8;                        // K8 lo | K8 hi (and V8T lo | V8T hi) of one key tile: 8 KiB
+constexpr int kL128K = 0, kL128V = kRing128 * kTile128, kL128KS = 2 * kRing128 * kTile128, kL128VS = kL128KS + kRing128 * 256;
+constexpr int kSmem128 = kL128VS + kRing128 * 256;           // 132 KiB
+
+template <typename T>
+__global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8AttnParams fp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AttnParams& p = fp.a;
+    typedef typename T::vec8 vec8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int g = lane >> 5;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int xcd = blockIdx.x & 7;
+    int hb, qb;
+    if (!attn_map_block(p, xcd, (int)(blockIdx.x >> 3), hb, qb)) return;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    const int nt = fp.nt;
+    const int lk = p.lk;
+    const int64_t img0 = (int64_t)hb * 2 * nt;               // first tile of sub-head 0; sub-head 1: + nt
+
+    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
+    i32x8_t qf[2];
+    int q_scale[2];
+    load_q_fp8<T>(p, qp, qrow, g, qf[0], q_scale[0]);
+    load_q_fp8<T>(p, qp + 64, qrow, g, qf[1], q_scale[1]);
+
+    // ---- staging (LDS-DMA): waves 0 / 1 of a group move the group's half of BOTH K8 images of a tile, 2 / 3 of both V8T
+    //      images; lanes 0..15 also the group's half of their scale blocks: four vector-memory operations per wave and tile ----
+    const int wl = __builtin_amdgcn_readfirstlane(wave & 3);
+    const bool st_k = wl < 2;
+    const uint8_t* timg = st_k ? fp.k8 : fp.v8t;
+    const uint8_t* simg = st_k ? fp.ks : fp.vs;
+    const __amdgpu_buffer_rsrc_t st_r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(timg + img0 * kTileK8), 0, nt * kTileK8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(timg + (img0 + nt) * kTileK8), 0, nt * kTileK8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_s0 = __builtin_amdgcn_make_buffer_rsrc((void*)(simg + img0 * 128), 0, nt * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_s1 = __builtin_amdgcn_make_buffer_rsrc((void*)(simg + (img0 + nt) * 128), 0, nt * 128, 0x00020000);
+    const int st_pos = grp * 128 + (wl & 1) * 64 + lane;
+    const uint32_t st_voff = (uint32_t)((st_pos >> 2) * 64 + (((st_pos & 3) ^ swz8(st_pos >> 2)) << 4));
+    const uint32_t st_svoff = (uint32_t)((grp * 16 + (lane & 15)) * 4);
+    const int st_lds = (st_k ? kL128K : kL128V) + (grp * 128 + (wl & 1) * 64) * 16;
+    const int st_slds = (st_k ? kL128KS : kL128VS) + grp * 64;
+#define D8_DMA(U_)                                                                                           \
+    {                                                                                                        \
+        const int tt_ = (U_) < nt ? (U_) : nt - 1;                                                           \
+        const int sl_ = (U_) & (kRing128 - 1);                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st_r0, (FINO_LDS void*)(smem + st_lds + sl_ * kTile128), 16, st_voff, \
+                                                 tt_ * kTileK8, 0, 0);                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st_r1, (FINO_LDS void*)(smem + st_lds + sl_ * kTile128 + kTileK8), 16, \
+                                                 st_voff, tt_ * kTileK8, 0, 0);                              \
+        if (lane < 16) {                                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_s0, (FINO_LDS void*)(smem + st_slds + sl_ * 256), 4, st_svoff, \
+                                                     tt_ * 128, 0, 0);                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_s1, (FINO_LDS void*)(smem + st_slds + sl_ * 256 + 128), 4, \
+                                                     st_svoff, tt_ * 128, 0, 0);                             \
+        }                                                                                                    \
+    }
+    { D8_DMA(0) }
+    { D8_DMA(1) }
+    { D8_DMA(2) }
+    { D8_DMA(3) }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tiles 0 and 1
+    __syncthreads();
+
+    f32x16_t o[4], lacc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { o[0][j] = 0.f; o[1][j] = 0.f; o[2][j] = 0.f; o[3][j] = 0.f; lacc[j] = 0.f; }
+    const i32x8_t ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+    constexpr int kOne = 127, kPs = 127 - kPShift;
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
+    asm volatile("" : "+v"(ones_u.x));
+    const int la0 = r * 64 + 16 * (chunk0(g) ^ swz8(r));
+    const int la1 = r * 64 + 16 * (chunk1(g) ^ swz8(r));
+    const int ls0 = r * 2 + g;
+
+    // K fragments of both sub-heads for both 32-key halves: 8 x ds_read_b128 + 4 scale bytes
+    i32x4_t kA[2][2][2];                                     // [sub][half][chunk]
+    int kS[2][2];                                            // [sub][half]
+#define D8_KREAD(SL_)                                                                                        \
+    _Pragma("unroll") for (int sb_ = 0; sb_ < 2; ++sb_) {                                                    \
+        const char* kb_ = smem + kL128K + (SL_) * kTile128 + sb_ * kTileK8;                                  \
+        const char* sb__ = smem + kL128KS + (SL_) * 256 + sb_ * 128;                                         \
+        kA[sb_][0][0] = *reinterpret_cast<const i32x4_t*>(kb_ + la0);                                        \
+        kA[sb_][0][1] = *reinterpret_cast<const i32x4_t*>(kb_ + la1);                                        \
+        kA[sb_][1][0] = *reinterpret_cast<const i32x4_t*>(kb_ + 2048 + la0);                                 \
+        kA[sb_][1][1] = *reinterpret_cast<const i32x4_t*>(kb_ + 2048 + la1);                                 \
+        kS[sb_][0] = *reinterpret_cast<const uint8_t*>(sb__ + ls0);                                          \
+        kS[sb_][1] = *reinterpret_cast<const uint8_t*>(sb__ + 64 + ls0);                                     \
+    }
+#define D8_QK(C_, S0_, S1_)                                                                                  \
+    {                                                                                                        \
+        S0_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                               \
+            __builtin_shufflevector(kA[0][0][0], kA[0][0][1], 0, 1, 2, 3, 4, 5, 6, 7), qf[0], C_, 0, 0, 0, kS[0][0], 0, q_scale[0]); \
+        S1_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                               \
+            __builtin_shufflevector(kA[0][1][0], kA[0][1][1], 0, 1, 2, 3, 4, 5, 6, 7), qf[0], C_, 0, 0, 0, kS[0][1], 0, q_scale[0]); \
+        S0_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                               \
+            __builtin_shufflevector(kA[1][0][0], kA[1][0][1], 0, 1, 2, 3, 4, 5, 6, 7), qf[1], S0_, 0, 0, 0, kS[1][0], 0, q_scale[1]); \
+        S1_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                               \
+            __builtin_shufflevector(kA[1][1][0], kA[1][1][1], 0, 1, 2, 3, 4, 5, 6, 7), qf[1], S1_, 0, 0, 0, kS[1][1], 0, q_scale[1]); \
+    }
+#define D8_MASK(T_, S0_, S1_)                                                                                \
+    if (__builtin_expect((T_) == nt - 1 && (lk & (kKV - 1)), 0)) {                                           \
+        int rem_ = lk - (T_) * kKV - 4 * g;                                                                  \
+        asm volatile("" : "+v"(rem_));                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                  \
+            const int key_ = (j_ & 3) + 8 * (j_ >> 2);                                                       \
+            if (key_ >= rem_) S0_[j_] = -INFINITY;                                                           \
+            if (key_ + 32 >= rem_) S1_[j_] = -INFINITY;                                                      \
+        }                                                                                                    \
+    }
+#define D8_SWAPMAX(MX_, OUT_)                                                                                \
+    {                                                                                                        \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(MX_), __float_as_uint(MX_), false, false); \
+        OUT_ = vmax2(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                      \
+    }
+
+    f32x16_t s0, s1;
+    D8_KREAD(0)
+    D8_QK(zero16, s0, s1)
+    D8_MASK(0, s0, s1)
+    float m_run;
+    {
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
+        float mxx;
+        D8_SWAPMAX(mx, mxx)
+        m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s0[j] -= m_run; s1[j] -= m_run; }
+    }
+    float ex_next = 0.f;
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
+
+    for (int t = 0; t < nt; ++t) {
+        // ================= softmax phase =================
+        if (__any(ex_next > (float)kPShift + kThr8)) {
+            const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
+            const float dm = mn - m_run;
+            m_run = mn;
+            const float alpha = __builtin_amdgcn_exp2f(-dm);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                s0[j] -= dm; s1[j] -= dm;
+                o[0][j] *= alpha; o[1][j] *= alpha; o[2][j] *= alpha; o[3][j] *= alpha; lacc[j] *= alpha;
+            }
+        }
+        i32x8_t pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i]), __builtin_amdgcn_exp2f(s0[4 * i + 1]),
+                                   __builtin_amdgcn_exp2f(s0[4 * i + 2]), __builtin_amdgcn_exp2f(s0[4 * i + 3]));
+            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i]), __builtin_amdgcn_exp2f(s1[4 * i + 1]),
+                                       __builtin_amdgcn_exp2f(s1[4 * i + 2]), __builtin_amdgcn_exp2f(s1[4 * i + 3]));
+        }
+        D8_DMA(t + 4)
+        asm volatile("" : "+v"(pf));
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // tile t + 3 (issued a tile ago) has landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= matrix phase =================
+        __builtin_amdgcn_s_setprio(1);
+        D8_KREAD((t + 1) & (kRing128 - 1))
+        i32x4_t vA[4][2];                                      // [d-tile = 2 sub + dt][chunk]
+        int vS[4];
+        {
+            const char* vb = smem + kL128V + (t & (kRing128 - 1)) * kTile128;
+            const char* vsb = smem + kL128VS + (t & (kRing128 - 1)) * 256;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                vA[d4][0] = *reinterpret_cast<const i32x4_t*>(vb + (d4 >> 1) * kTileK8 + (d4 & 1) * 2048 + la0);
+                vA[d4][1] = *reinterpret_cast<const i32x4_t*>(vb + (d4 >> 1) * kTileK8 + (d4 & 1) * 2048 + la1);
+                vS[d4] = *reinterpret_cast<const uint8_t*>(vsb + (d4 >> 1) * 128 + (d4 & 1) * 64 + ls0);
+            }
+        }
+        {
+            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
+            const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
+            const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
+            D8_QK(c0, s0, s1)
+        }
+#define D8_PV(D4_)                                                                                           \
+        o[D4_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                            \
+            __builtin_shufflevector(vA[D4_][0], vA[D4_][1], 0, 1, 2, 3, 4, 5, 6, 7), pf, o[D4_], 0, 0, 0, vS[D4_], 0, kPs);
+        D8_PV(0)
+        D8_PV(1)
+        D8_MASK(t + 1, s0, s1)
+        float mxa = max16_behind(s0, o[1][0]);          // behind two P.V MFMAs: S0 was written back long ago
+        D8_PV(2)
+        D8_PV(3)
+        const float mxb = max16_behind(s1, o[3][0]);
+        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
+        mxa = vmax2(mxa, mxb);
+        D8_SWAPMAX(mxa, ex_next)
+#undef D8_PV
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef D8_DMA
+#undef D8_KREAD
+#undef D8_QK
+#undef D8_MASK
+#undef D8_SWAPMAX
+
+    const float inv = 1.0f / lacc[0];
+    if (qrow < p.lq) {
+        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = d4 * 32 + 8 * gq + 4 * g;
+                uint32_t w0 = (uint32_t)T::from_f32(o[d4][4 * gq + 0] * inv) |
+                              ((uint32_t)T::from_f32(o[d4][4 * gq + 1] * inv) << 16);
+                uint32_t w1 = (uint32_t)T::from_f32(o[d4][4 * gq + 2] * inv) |
+                              ((uint32_t)T::from_f32(o[d4][4 * gq + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t fino_attn_fp8_kv_bytes(int batch, int heads, int64_t lk, int head_dim) {
-    if (batch <= 0 || heads <= 0 || lk <= 0 || head_dim != kD8) return 0;
+    if (batch <= 0 || heads <= 0 || lk <= 0 || (head_dim != 64 && head_dim != 128)) return 0;
     const int64_t nt = (lk + kKV - 1) / kKV;
-    return (int64_t)batch * heads * nt * (2 * kTileK8 + 256);
+    return (int64_t)batch * heads * (head_dim / 64) * nt * (2 * kTileK8 + 256);       // per 64-channel sub-head
 }
 
 extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
@@ -842,7 +1084,7 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
                                  int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, float scale, int dtype,
                                  void* kv_workspace, int64_t kv_workspace_bytes, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_fwd_fp8: dtype %d", dtype);
-    FINO_CHECK(head_dim == kD8, FINO_ERR_UNSUPPORTED, "fino_attn_fwd_fp8: head_dim %d (built for 64)", head_dim);
+    FINO_CHECK(head_dim == 64 || head_dim == 128, FINO_ERR_UNSUPPORTED, "fino_attn_fwd_fp8: head_dim %d not in {64, 128}", head_dim);
     FINO_CHECK(q && k && v && o && kv_workspace, FINO_ERR_ARG, "fino_attn_fwd_fp8: null pointer");
     FINO_CHECK(batch > 0 && heads > 0 && lq >= 0 && lk > 0, FINO_ERR_ARG, "fino_attn_fwd_fp8: bad shape");
     FINO_CHECK(fino_aligned16(q) && fino_aligned16(k) && fino_aligned16(v) && fino_aligned16(o) &&
@@ -856,13 +1098,14 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     if (lq == 0) return FINO_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nt = (int)((lk + kKV - 1) / kKV);
-    const int64_t bh = (int64_t)batch * heads;
+    const int sub = head_dim / 64;                            // 64-channel sub-heads per head: images of the pre-pass
+    const int64_t bh = (int64_t)batch * heads * sub;
     uint8_t* w8 = (uint8_t*)kv_workspace;
     QuantParams qp;
     qp.k = (const uint16_t*)k; qp.v = (const uint16_t*)v;
     qp.k8 = w8; qp.v8t = w8 + bh * nt * kTileK8; qp.ks = w8 + 2 * bh * nt * kTileK8; qp.vs = qp.ks + bh * nt * 128;
-    qp.batch = batch; qp.heads = heads; qp.lk = (int)lk; qp.nt = nt;
-    qp.k_bs = k_bs; qp.k_rs = k_rs; qp.k_hs = head_dim; qp.v_bs = v_bs; qp.v_rs = v_rs; qp.v_hs = head_dim;
+    qp.batch = batch; qp.heads = heads * sub; qp.lk = (int)lk; qp.nt = nt;
+    qp.k_bs = k_bs; qp.k_rs = k_rs; qp.k_hs = 64; qp.v_bs = v_bs; qp.v_rs = v_rs; qp.v_hs = 64;
     if (dtype == FINO_BF16) attn_quant_kv_fp8_kernel<BF16><<<dim3((unsigned)nt, (unsigned)bh), 256, 0, st>>>(qp);
     else attn_quant_kv_fp8_kernel<F16><<<dim3((unsigned)nt, (unsigned)bh), 256, 0, st>>>(qp);
     FINO_LAUNCH_CHECK();
@@ -874,7 +1117,7 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = head_dim; p.k_bs = p.k_rs = p.k_hs = p.v_bs = p.v_rs = p.v_hs = 0;
     p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = head_dim;
     p.scale_log2 = scale == FINO_ATTN_SCALE_FOLDED ? 1.0f : scale * 1.4426950408889634f;
-    const bool free_running = fino_tune_get(FINO_TUNE_ATTN_FP8_KERNEL) != 1;       // default: the free-running kernel
+    const bool free_running = head_dim == 64 && fino_tune_get(FINO_TUNE_ATTN_FP8_KERNEL) != 1;   // default at head_dim 64
     const int qblock = free_running ? kFrQBlock : kQBlock;
     p.nqb = (int)((lq + qblock - 1) / qblock);
     p.ws = nullptr; p.all_partial = 0;
@@ -886,6 +1129,17 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     if (free_running) {
         if (dtype == FINO_BF16) attn_fp8_fr_kernel<BF16><<<grid, kFrWaves * 64, kFrSmem, st>>>(fp);
         else attn_fp8_fr_kernel<F16><<<grid, kFrWaves * 64, kFrSmem, st>>>(fp);
+        FINO_LAUNCH_CHECK();
+        return FINO_OK;
+    }
+    if (head_dim == 128) {
+        static FinoPerDeviceOnce once_bf16, once_f16;
+        const int rc = dtype == FINO_BF16
+            ? fino_max_smem_once(once_bf16, (const void*)attn_fp8_d128_kernel<BF16>, kSmem128, "fino_attn_fwd_fp8")
+            : fino_max_smem_once(once_f16, (const void*)attn_fp8_d128_kernel<F16>, kSmem128, "fino_attn_fwd_fp8");
+        if (rc != FINO_OK) return rc;
+        if (dtype == FINO_BF16) attn_fp8_d128_kernel<BF16><<<grid, kWaves * 64, kSmem128, st>>>(fp);
+        else attn_fp8_d128_kernel<F16><<<grid, kWaves * 64, kSmem128, st>>>(fp);
         FINO_LAUNCH_CHECK();
         return FINO_OK;
     }

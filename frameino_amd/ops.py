@@ -238,8 +238,8 @@ _attn_fp8_ws = {}     # (device index, stream) -> byte workspace of the quantise
 
 
 def attention_fp8(q, k, v, heads, out=None, scale=None):
-    """attention() with fp8 (e4m3) matrix operands, head_dim 64: K / V quantised per call (block-scaled, V transposed), Q and
-    P in registers, both products on the block-scaled fp8 MFMA, softmax and accumulation in fp32 (fino_attn_fwd_fp8)."""
+    """attention() with fp8 (e4m3) matrix operands, head_dim 64 or 128: K / V quantised per call (block-scaled, V transposed), Q
+    and P in registers, both products on the block-scaled fp8 MFMA, softmax and accumulation in fp32 (fino_attn_fwd_fp8)."""
     assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
     b, lq, hd = q.shape
     lk = k.shape[1]
@@ -251,7 +251,7 @@ def attention_fp8(q, k, v, heads, out=None, scale=None):
     scale = dh ** -0.5 if scale is None else scale
     need = _lib.lib().fino_attn_fp8_kv_bytes(b, heads, lk, dh)
     if need <= 0:
-        raise RuntimeError(f"attention_fp8: head_dim {dh} is not supported (built for 64)")
+        raise RuntimeError(f"attention_fp8: head_dim {dh} is not supported (64 or 128)")
     key = (q.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _attn_fp8_ws.get(key)
     if ws is None or ws.numel() < need:

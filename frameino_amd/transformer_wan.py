@@ -149,6 +149,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         # 4-wave kernel fold the running maximum into its MFMAs.  False (default): q rounded where the reference rounds it,
         # scale applied to the logits -- inside the power-capped step the fold buys nothing.
         self.fold_softmax_scale = False
+        self.fp8_attention = False        # see enable_fp8_attention
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -258,6 +259,14 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                            ("out2", blk.attn2.to_out[0].weight), ("ff1", blk.ffn.net[0].proj.weight),
                            ("ff2", blk.ffn.net[2].weight)):
                 self._fp8[(li, key)] = o.quantize_mxfp8(w.detach().contiguous())
+        return self
+
+    def enable_fp8_attention(self, enabled=True):
+        """The 3-D self-attention (transformer_wan.py:108) with fp8 (e4m3) matrix operands -- q, k, v and P on the
+        block-scaled fp8 MFMA, softmax and accumulation fp32 (fino_attn_fwd_fp8, head_dim 128 as two 64-channel sub-heads).
+        Opt-in, single-GPU forward only; no reference counterpart: rel-RMS ~5e-2 per attention output on N(0, 1) inputs
+        (tests/test_attention_fp8_gpu.py).  The text cross-attention stays bf16."""
+        self.fp8_attention = bool(enabled)
         return self
 
     def _lin(self, li, key, x, w, b, epi=0, **kw):
@@ -466,6 +475,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         fold = self.fold_softmax_scale and hasattr(o, "SCALE_FOLDED")
         qfold = {"out_scale": dh ** -0.5 * o.LOG2E} if fold else {}
         afold = {"scale": o.SCALE_FOLDED} if fold else {}
+        attend = o.attention_fp8 if (self.fp8_attention and sh is None and hasattr(o, "attention_fp8")) else o.attention
         yield
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
@@ -486,7 +496,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._lin(li, "qkv", n1, e.wqkv, e.bqkv, out=q1)
                 self._qk_norm_rope(blk, q1, d, cos1, sin1, dh, qfold)
                 q3 = q1.view(1, n, 3 * d)
-                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att[:n].view(1, n, d), **afold)
+                attend(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att[:n].view(1, n, d), **afold)
                 self._lin(li, "out", att[:n], blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x[:n], gate=m[:, 2], sel=sel1, out=x[:n])
                 for bi in range(1, b):
@@ -496,7 +506,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
                 self._qk_norm_rope(blk, qkv, d, cos, sin, dh, qfold)
                 q3 = qkv.view(b, n, 3 * d)
-                o.attention(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
+                attend(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
             elif sh.heads_exchange_ok(heads):
                 # heads exchange (frameino_amd/parallel.py): q | k | v of MY tokens -> all-to-all -> all tokens of MY
                 # heads -> one attention launch over the whole sequence -> all-to-all back to the token owners

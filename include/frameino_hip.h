@@ -141,8 +141,8 @@ int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batc
                   int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs,
                   int64_t o_hs, float scale, int dtype, void* stream);
 /* Self-attention with fp8 (OCP e4m3) matrix operands, head_dim 64 (BASELINE config 5's "fp8 MFMA path" for the SDPA at
- * architecture/attention_processor.py:2863: no reference counterpart, SURVEY F11 -- compared with fp32 SDPA and with this
- * library's bf16 kernel).  q / k / v / o as fino_attn_fwd (bf16 | fp16, head stride = head_dim).  K and V are quantised
+ * architecture/attention_processor.py:2863) or 128 (the same for transformer_wan.py:108, as two 64-channel sub-heads per
+ * head): no reference counterpart, SURVEY F11 -- compared with fp32 SDPA and with this library's bf16 kernel).  q / k / v / o as fino_attn_fwd (bf16 | fp16, head stride = head_dim).  K and V are quantised
  * once per call into `kv_workspace` (fino_attn_fp8_kv_bytes: caller-owned, 16-byte aligned; e4m3 tiles + one e8m0 scale
  * per 32 elements, V transposed and key-permuted for the second product), Q in registers, P = exp2(s - m) to e4m3 with a
  * fixed 2^-6 block scale; both products on v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 accumulation, softmax in fp32. */

@@ -65,10 +65,15 @@ def _emulated(q, k, v, heads):
 
 @pytest.mark.parametrize("b,heads,lq,lk", [(1, 2, 256, 256), (2, 3, 300, 1000), (1, 8, 1000, 777), (2, 48, 512, 2048),
                                            (1, 1, 33, 65)])
+@pytest.mark.parametrize("dh", [64, 128])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk, dtype):
+def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk, dtype, dh, fp8_kernel):
     from frameino_amd import ops
-    d = heads * 64
+    if dh == 128:
+        if fp8_kernel == 1:
+            pytest.skip("head_dim 128 has one kernel (attn_fp8_d128_kernel)")
+        heads = max(1, heads // 2)
+    d = heads * dh
     g = torch.Generator(device=DEV).manual_seed(lq + lk + heads)
     q = torch.randn(b, lq, d, device=DEV, generator=g).to(dtype)
     kv = torch.randn(b, lk, 2 * d + 64, device=DEV, generator=g).to(dtype)          # row-strided k | v views
@@ -79,7 +84,7 @@ def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk
     ref = _sdpa(q, k, v, heads)
     emu = _emulated(q, k, v, heads)
     r, re = rel_rms(o, ref), rel_rms(emu, ref)
-    record(f"attention_fp8[b{b}-h{heads}-lq{lq}-lk{lk}-{str(dtype)[6:]}]", f"rel_rms vs fp32 SDPA (torch emulation of the "
+    record(f"attention_fp8[b{b}-h{heads}x{dh}-lq{lq}-lk{lk}-{str(dtype)[6:]}]", f"rel_rms vs fp32 SDPA (torch emulation of the "
            f"quantisation: {re:.4f})", r, 8e-2)
     assert r < 8e-2 and r < 1.2 * re + 2e-3, (r, re)
     # V = 1: every row of P8 / sum(P8) sums to one whatever the rounding
@@ -125,3 +130,29 @@ def test_fp8_attention_full_size_config5_sampled_rows():
         assert r < 8e-2, r
     assert torch.isfinite(o.float()).all()
     assert (ops.attention_fp8(q, k, torch.ones_like(v), heads).float() - 1).abs().max().item() < 4e-3
+
+
+def test_fp8_attention_full_size_wan_shape_sampled_rows(fp8_kernel):
+    """Wan2.2-5B self-attention, 49 f 704x1280: [2, 12320, 24 x 128] (the CFG-batched launch); sampled query rows against fp32
+    on the device, and the library's own bf16 kernel beside it"""
+    if fp8_kernel == 1:
+        pytest.skip("head_dim 128 has one kernel")
+    from frameino_amd import ops
+    b, heads, L = 2, 24, 12320
+    d = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(10)
+    q = torch.randn(b, L, d, device=DEV, generator=g).bfloat16()
+    kv = torch.randn(b, L, 2 * d, device=DEV, generator=g).bfloat16()
+    k, v = kv[:, :, :d], kv[:, :, d:]
+    o = ops.attention_fp8(q, k, v, heads)
+    ob = ops.attention(q, k, v, heads)
+    rows = torch.tensor(sorted({0, 1, 255, 256, L - 1, L - 2, (L // 256) * 256, L // 2} |
+                               set(torch.randint(0, L, (20,)).tolist())), device=DEV)
+    for bi in range(b):
+        ref = _sdpa(q[bi:bi + 1, rows], k[bi:bi + 1], v[bi:bi + 1], heads)[0]
+        r, rb = rel_rms(o[bi, rows], ref), rel_rms(ob[bi, rows], ref)
+        record(f"attention_fp8_full_size_wan[batch {bi}]", f"rel_rms sampled rows vs fp32 SDPA (own bf16 kernel: {rb:.4f})", r, 8e-2)
+        assert r < 8e-2, r
+    assert torch.isfinite(o.float()).all()
+    assert (ops.attention_fp8(q, k, torch.ones_like(v), heads).float() - 1).abs().max().item() < 4e-3
+
