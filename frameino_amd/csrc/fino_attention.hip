@@ -1244,6 +1244,25 @@ int launch_attn(const AttnParams& p, int64_t ws_bytes, hipStream_t st) {
 
 }  // namespace
 
+void fino_attn_plan_split(int batch, int heads, int nqb, int nt, int& full_x, int& rem_x, int& nwg, int& per) {
+    const SplitPlan sp = plan_split(batch, heads, nqb, nt);
+    full_x = sp.full_x; rem_x = sp.rem_x; nwg = sp.nwg; per = sp.per;
+}
+
+int fino_attn_launch_combine(const AttnParams& p, int dtype, int head_dim, hipStream_t st) {
+    if (p.rem_x <= 0) return FINO_OK;
+    const dim3 grid((unsigned)(8 * p.rem_x), (unsigned)(head_dim / 32));
+    if (head_dim == 128) {
+        if (dtype == FINO_BF16) attn_combine_kernel<BF16, 128><<<grid, kWaves * 64, 0, st>>>(p);
+        else attn_combine_kernel<F16, 128><<<grid, kWaves * 64, 0, st>>>(p);
+    } else {
+        if (dtype == FINO_BF16) attn_combine_kernel<BF16, 64><<<grid, kWaves * 64, 0, st>>>(p);
+        else attn_combine_kernel<F16, 64><<<grid, kWaves * 64, 0, st>>>(p);
+    }
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
 extern "C" int64_t fino_attn_workspace_bytes(int batch, int heads, int64_t lq, int64_t lk, int head_dim) {
     if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0 || (head_dim != 64 && head_dim != 128)) return 0;
     const SplitPlan sp = plan_split(batch, heads, (int)((lq + kQBlock - 1) / kQBlock), (int)((lk + kKV - 1) / kKV));

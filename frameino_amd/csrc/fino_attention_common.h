@@ -105,6 +105,11 @@ __device__ __forceinline__ int k_lds_off(int row, int ch) {
 
 }  // namespace fino_attn_ns
 
+// the tail split's plan and the merge of its (O, m, l) partials, for kernels outside fino_attention.hip that write the same
+// partial layout (fino_attention_fp8.hip): defined in fino_attention.hip
+void fino_attn_plan_split(int batch, int heads, int nqb, int nt, int& full_x, int& rem_x, int& nwg, int& per);
+int fino_attn_launch_combine(const fino_attn_ns::AttnParams& p, int dtype, int head_dim, hipStream_t st);
+
 // 4-wave kernel: defined in fino_attention_w4.hip (head_dim 128; head_dim 64 with the folded softmax scale only)
 bool fino_attn_w4_supports(int head_dim, float scale_log2);
 int fino_attn_launch_w4(const fino_attn_ns::AttnParams& p, int dtype, int head_dim, hipStream_t st);

@@ -854,15 +854,38 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
     const int g = lane >> 5;
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    // tail split (as attn_pp_kernel): the first full_x blocks of an XCD run whole; the key tiles of its last rem_x blocks form
+    // one stream cut into nwg ranges of `per` tiles, a range touching at most two blocks (two pieces), partials to p.ws
+    const int ntall = fp.nt;
+    int npieces = 1, first_b = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (slot >= p.full_x) {
+        g0 = (int64_t)(slot - p.full_x) * p.per;
+        g1 = g0 + p.per < (int64_t)p.rem_x * ntall ? g0 + p.per : (int64_t)p.rem_x * ntall;
+        first_b = (int)(g0 / ntall);
+        npieces = (int)((g1 - 1) / ntall) - first_b + 1;
+    }
+  for (int piece = 0; piece < npieces; ++piece) {
+    if (piece > 0) __syncthreads();
+    int bx = slot, part = -1, t_begin = 0, t_end = ntall;
+    if (slot >= p.full_x) {
+        const int tb = first_b + piece;
+        const int64_t b0 = (int64_t)tb * ntall;
+        t_begin = g0 > b0 ? (int)(g0 - b0) : 0;
+        t_end = g1 - b0 < ntall ? (int)(g1 - b0) : ntall;
+        bx = p.full_x + tb;
+        if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
+    }
     int hb, qb;
-    if (!attn_map_block(p, xcd, (int)(blockIdx.x >> 3), hb, qb)) return;
+    if (!attn_map_block(p, xcd, bx, hb, qb)) continue;
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
     const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
     uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
-    const int nt = fp.nt;
-    const int lk = p.lk;
-    const int64_t img0 = (int64_t)hb * 2 * nt;               // first tile of sub-head 0; sub-head 1: + nt
+    const int nt = t_end - t_begin;
+    const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;     // keys of this range, re-based to 0
+    const int64_t img0 = (int64_t)hb * 2 * ntall + t_begin;  // first tile of sub-head 0; sub-head 1: + ntall
 
     const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
     i32x8_t qf[2];
@@ -877,9 +900,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
     const uint8_t* timg = st_k ? fp.k8 : fp.v8t;
     const uint8_t* simg = st_k ? fp.ks : fp.vs;
     const __amdgpu_buffer_rsrc_t st_r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(timg + img0 * kTileK8), 0, nt * kTileK8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t st_r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(timg + (img0 + nt) * kTileK8), 0, nt * kTileK8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(timg + (img0 + ntall) * kTileK8), 0, nt * kTileK8, 0x00020000);
     const __amdgpu_buffer_rsrc_t st_s0 = __builtin_amdgcn_make_buffer_rsrc((void*)(simg + img0 * 128), 0, nt * 128, 0x00020000);
-    const __amdgpu_buffer_rsrc_t st_s1 = __builtin_amdgcn_make_buffer_rsrc((void*)(simg + (img0 + nt) * 128), 0, nt * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t st_s1 = __builtin_amdgcn_make_buffer_rsrc((void*)(simg + (img0 + ntall) * 128), 0, nt * 128, 0x00020000);
     const int st_pos = grp * 128 + (wl & 1) * 64 + lane;
     const uint32_t st_voff = (uint32_t)((st_pos >> 2) * 64 + (((st_pos & 3) ^ swz8(st_pos >> 2)) << 4));
     const uint32_t st_svoff = (uint32_t)((grp * 16 + (lane & 15)) * 4);
@@ -1053,6 +1076,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
 #undef D8_MASK
 #undef D8_SWAPMAX
 
+    if (part >= 0) {
+        // partial in the bf16 kernels' layout (attn_combine_kernel finishes): m, O and l share the 2^kPShift offset, which
+        // cancels in the merge
+        float* w = p.ws + (int64_t)part * partial_floats<128>();
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[(d4 * 16 + j) * (kWaves * 64) + tid] = o[d4][j];
+        w[4 * 16 * (kWaves * 64) + tid] = m_run;
+        w[4 * 16 * (kWaves * 64) + kWaves * 64 + tid] = lacc[0];
+        continue;
+    }
     const float inv = 1.0f / lacc[0];
     if (qrow < p.lq) {
         uint16_t* orow = op + (int64_t)qrow * p.o_rs;
@@ -1069,6 +1104,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
             }
         }
     }
+  }   // piece
 }
 
 }  // namespace
@@ -1076,7 +1112,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
 extern "C" int64_t fino_attn_fp8_kv_bytes(int batch, int heads, int64_t lk, int head_dim) {
     if (batch <= 0 || heads <= 0 || lk <= 0 || (head_dim != 64 && head_dim != 128)) return 0;
     const int64_t nt = (lk + kKV - 1) / kKV;
-    return (int64_t)batch * heads * (head_dim / 64) * nt * (2 * kTileK8 + 256);       // per 64-channel sub-head
+    int64_t b = (int64_t)batch * heads * (head_dim / 64) * nt * (2 * kTileK8 + 256);  // per 64-channel sub-head
+    // head_dim 128: + the fp32 (O, m, l) partials of the tail split (at most 32 ranges per XCD, two pieces each), 16-aligned
+    if (head_dim == 128) b = ((b + 15) & ~(int64_t)15) + (int64_t)8 * 32 * 2 * partial_floats<128>() * 4;
+    return b;
 }
 
 extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
@@ -1133,15 +1172,24 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
         return FINO_OK;
     }
     if (head_dim == 128) {
+        // tail split: the last, partial round of (head, q-block) workgroups is cut over the keys (fino_attention.hip's plan)
+        int full_x, rem_x, nwg, per;
+        fino_attn_plan_split(p.batch, p.heads, p.nqb, nt, full_x, rem_x, nwg, per);
+        if (rem_x > 0 && nwg <= 32) {
+            const int64_t kvb = ((int64_t)bh * nt * (2 * kTileK8 + 256) + 15) & ~(int64_t)15;
+            p.ws = (float*)(w8 + kvb);
+            p.full_x = full_x; p.rem_x = rem_x; p.nwg = nwg; p.per = per;
+        }
+        const dim3 grid128((unsigned)(8 * (p.full_x + p.nwg)));
         static FinoPerDeviceOnce once_bf16, once_f16;
         const int rc = dtype == FINO_BF16
             ? fino_max_smem_once(once_bf16, (const void*)attn_fp8_d128_kernel<BF16>, kSmem128, "fino_attn_fwd_fp8")
             : fino_max_smem_once(once_f16, (const void*)attn_fp8_d128_kernel<F16>, kSmem128, "fino_attn_fwd_fp8");
         if (rc != FINO_OK) return rc;
-        if (dtype == FINO_BF16) attn_fp8_d128_kernel<BF16><<<grid, kWaves * 64, kSmem128, st>>>(fp);
-        else attn_fp8_d128_kernel<F16><<<grid, kWaves * 64, kSmem128, st>>>(fp);
+        if (dtype == FINO_BF16) attn_fp8_d128_kernel<BF16><<<grid128, kWaves * 64, kSmem128, st>>>(fp);
+        else attn_fp8_d128_kernel<F16><<<grid128, kWaves * 64, kSmem128, st>>>(fp);
         FINO_LAUNCH_CHECK();
-        return FINO_OK;
+        return fino_attn_launch_combine(p, dtype, 128, st);
     }
     constexpr int smem = kSmem8;
     {   // 66 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
