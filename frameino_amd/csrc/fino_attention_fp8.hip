@@ -668,6 +668,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
 #pragma unroll
     for (int j = 0; j < 16; ++j) { o[0][j] = 0.f; o[1][j] = 0.f; lacc[j] = 0.f; }
     i32x8_t ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+    asm volatile("" : "+v"(ones8));       // opaque: held in 8 registers for the whole loop instead of 7 moves per tile
     constexpr int kOne = 127, kPs = 127 - kPShift;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
@@ -935,7 +936,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
     f32x16_t o[4], lacc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { o[0][j] = 0.f; o[1][j] = 0.f; o[2][j] = 0.f; o[3][j] = 0.f; lacc[j] = 0.f; }
-    const i32x8_t ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+    i32x8_t ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+    asm volatile("" : "+v"(ones8));       // opaque: held in registers instead of re-materialised every tile
     constexpr int kOne = 127, kPs = 127 - kPShift;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
