@@ -165,6 +165,8 @@ def main():
                          "both probed")
     ap.add_argument("--mxfp8", action="store_true",
                     help="NOT the headline: large linears on the MXFP8 path (BASELINE config 5 style), attention in bf16")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="NOT the headline (with --mxfp8): self-attention with fp8 (e4m3) operands too (fino_attn_fwd_fp8)")
     ap.add_argument("--logit-scale", type=float, default=1.0,
                     help="NOT the headline: scale of the attention-probe q (peaky logits make the rescale branch fire)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,6 +220,8 @@ def main():
     model = build_model(cfg, dev)
     if a.mxfp8:
         model.enable_mxfp8_linears()
+    if a.fp8_attention:
+        model.enable_fp8_attention()
     pipe = WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=model,
                                    expand_timesteps=True)
     plans = {}
@@ -369,7 +373,9 @@ def main():
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if not a.mxfp8 else "mxfp8 linears (e4m3 + e8m0/32) + bf16 attention -- not the headline",
+            "dtype": ("bf16" if not (a.mxfp8 or a.fp8_attention) else
+                      ("mxfp8 linears (e4m3 + e8m0/32)" if a.mxfp8 else "bf16 linears") +
+                      (" + fp8 (e4m3) attention operands" if a.fp8_attention else " + bf16 attention") + " -- not the headline"),
             "data": "synthetic",
             "config": dict(base_cfg, hip_graph=bool(use_graph), parallelism=parallelism,
                            sec_per_50_step_clip_denoise_only=50 * ms_step / 1e3,
@@ -486,7 +492,7 @@ def main():
         extra.update({"vae_encode_conditions_s": enc_s, "vae_decode_s": dec_s,
                       "sec_per_clip_50_steps": enc_s + 50 * ms_step / 1e3 + dec_s})
 
-    if not a.no_secondary and a.workload == "wan2.2-5b-49f-704x1280" and not a.layers and not a.mxfp8:
+    if not a.no_secondary and a.workload == "wan2.2-5b-49f-704x1280" and not a.layers and not a.mxfp8 and not a.fp8_attention:
         # (d) BASELINE config 4's per-GPU-independent part: the same model at 1024x1792 (L = 25088), whole on one GPU
         secondary["config4_wan_1024x1792_L25088"] = other_workload_ms_per_step(
             pipe, make_inputs, cfg, dev, "wan2.2-5b-49f-1024x1792")
