@@ -68,6 +68,8 @@ SIGNATURES = {
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_gemm_split_n": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                           c_i64, c_i64, c_void_p],
+    "fino_ln_mxfp8": [c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                      c_void_p, c_float, c_int, c_void_p],
     "fino_gemm_blocked_a": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_i64,
                             c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_gemm_plan": [c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)],

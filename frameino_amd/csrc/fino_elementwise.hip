@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "fino_common.h"
+#include "fino_gemm_common.h"      // mx_quant8 / mx_scale_index: the MXFP8 activation layout fino_gemm_mxfp8 consumes
 
 namespace {
 
@@ -82,11 +83,14 @@ __device__ __forceinline__ void ln_stats(const float (&v)[NP][8], int dim, int l
 // MODE 1: y = T(LN(x)*w+b)                                    (affine LayerNorm; w/b may be null)
 // MODE 2: y = T(T(T(LN(x)*w+b) * T(1+scale)) + shift)         (CogVideoXLayerNormZero / AdaLayerNorm executed in T:
 //                                                              the reference rounds after every tensor op)
-template <typename T, int NP, int MODE>
+// QOUT: instead of the T row, its MXFP8 quantisation (e4m3 bytes to q [rows, dim] + one e8m0 scale per 32 channels in the
+// fino_quantize_mxfp8 layout): the bytes fino_quantize_mxfp8 would produce from the T-rounded y, without writing y.
+template <typename T, int NP, int MODE, bool QOUT = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
     const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int dim, int64_t ldx, int64_t ldy,
     const float* __restrict__ p_w, const float* __restrict__ p_b, const float* __restrict__ p_shift,
-    const float* __restrict__ p_scale, int64_t mod_stride, const int32_t* __restrict__ sel, float eps) {
+    const float* __restrict__ p_scale, int64_t mod_stride, const int32_t* __restrict__ sel, float eps,
+    uint8_t* __restrict__ q = nullptr, uint8_t* __restrict__ qs = nullptr, int64_t rows_pad = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -121,7 +125,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ln_modulate_kernel(
                 o[j] = t;
             }
         }
-        if constexpr ((FINO_EW_NT & 2) != 0) EW_STORE_NT(y + row * ldy + c, pack8<T>(o))
+        if constexpr (QOUT) {
+            float r8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r8[j] = round_to<T>(o[j]);
+            int e;
+            const uint2 qv = fino_gemm_ns::mx_quant8(r8, e);
+            *reinterpret_cast<uint2*>(q + row * dim + c) = qv;
+            if ((c & 31) == 0) qs[fino_gemm_ns::mx_scale_index(row, c, rows_pad)] = (uint8_t)(e + 127);
+        } else if constexpr ((FINO_EW_NT & 2) != 0) EW_STORE_NT(y + row * ldy + c, pack8<T>(o))
         else EW_STORE(y + row * ldy + c, pack8<T>(o));
     }
 }
@@ -532,6 +544,28 @@ inline int grid_1d(int64_t total, int block = 256) {
 }
 
 template <int MODE>
+int launch_ln_q(const void* x, void* q, void* qs, int64_t rows, int dim, int64_t ldx, const float* w, const float* b,
+                const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel, float eps, int dtype,
+                hipStream_t st) {
+    const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+    const int64_t rows_pad = (rows + 255) / 256 * 256;
+    const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
+        constexpr int NP = decltype(np)::value;
+        if (dtype == FINO_BF16)
+            ln_modulate_kernel<BF16, NP, MODE, true><<<grid, block, 0, st>>>((const uint16_t*)x, nullptr, rows, dim, ldx, 0, w,
+                                                                           b, shift, scale, mod_stride, sel, eps,
+                                                                           (uint8_t*)q, (uint8_t*)qs, rows_pad);
+        else
+            ln_modulate_kernel<F16, NP, MODE, true><<<grid, block, 0, st>>>((const uint16_t*)x, nullptr, rows, dim, ldx, 0, w,
+                                                                          b, shift, scale, mod_stride, sel, eps,
+                                                                          (uint8_t*)q, (uint8_t*)qs, rows_pad);
+    });
+    FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "layernorm: dim %d > %d unsupported", dim, kMaxPasses * 512);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+template <int MODE>
 int launch_ln(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy, const float* w, const float* b,
               const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel, float eps, int dtype,
               hipStream_t st) {
@@ -568,6 +602,23 @@ extern "C" int fino_adaln_modulate(const void* x, void* y, int64_t rows, int dim
                FINO_ERR_ARG, "fino_adaln_modulate: 16-byte alignment required");
     return launch_ln<0>(x, y, rows, dim, ldx, ldy, nullptr, nullptr, shift, scale, mod_stride, sel, eps, dtype,
                         (hipStream_t)stream);
+}
+
+// mode 0 = fino_adaln_modulate, 1 = fino_layernorm (w / b may be NULL), 2 = fino_layernorm_zero; see include/frameino_hip.h
+extern "C" int fino_ln_mxfp8(int mode, const void* x, void* q, void* scales, int64_t rows, int dim, int64_t ldx,
+                             const float* w, const float* b, const float* shift, const float* scale, int64_t mod_stride,
+                             const int32_t* sel, float eps, int dtype, void* stream) {
+    CHECK_ROWS_DIM("fino_ln_mxfp8");
+    FINO_CHECK(mode >= 0 && mode <= 2 && x && q && scales, FINO_ERR_ARG, "fino_ln_mxfp8: mode %d / null pointer", mode);
+    FINO_CHECK(mode == 1 || (shift && scale), FINO_ERR_ARG, "fino_ln_mxfp8: modulation rows missing");
+    FINO_CHECK(dim % 128 == 0, FINO_ERR_ARG, "fino_ln_mxfp8: dim=%d must be a multiple of 128", dim);
+    FINO_CHECK(ldx % 8 == 0 && mod_stride % 4 == 0 && fino_aligned16(x) && fino_aligned16(shift) && fino_aligned16(scale) &&
+                   fino_aligned16(w) && fino_aligned16(b) && ((uintptr_t)q & 7) == 0,
+               FINO_ERR_ARG, "fino_ln_mxfp8: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) return launch_ln_q<0>(x, q, scales, rows, dim, ldx, nullptr, nullptr, shift, scale, mod_stride, sel, eps, dtype, st);
+    if (mode == 1) return launch_ln_q<1>(x, q, scales, rows, dim, ldx, w, b, nullptr, nullptr, 0, nullptr, eps, dtype, st);
+    return launch_ln_q<2>(x, q, scales, rows, dim, ldx, w, b, shift, scale, mod_stride, sel, eps, dtype, st);
 }
 
 extern "C" int fino_layernorm(const void* x, void* y, int64_t rows, int dim, int64_t ldx, int64_t ldy,

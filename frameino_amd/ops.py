@@ -386,6 +386,26 @@ def quantize_mxfp8(x, out=None):
     return q, s
 
 
+def ln_mxfp8(mode, x, weight=None, bias=None, shift=None, scale=None, sel=None, eps=1e-6, out=None):
+    """adaln_modulate (mode 0) / layernorm (1) / layernorm_zero (2) with the result as MXFP8 activations: -> (q, scales) as
+    quantize_mxfp8 would make them from the T-rounded output, in one pass (fino_ln_mxfp8)."""
+    x2, rows, dim, ldx = _rows2d(x)
+    nbytes = _lib.lib().fino_mxfp8_scale_bytes(rows, dim)
+    if nbytes <= 0:
+        raise ValueError(f"ln_mxfp8: dim={dim} must be a positive multiple of 128")
+    if out is None:
+        q = torch.empty((rows, dim), dtype=torch.uint8, device=x.device)
+        s = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+    else:
+        q, s = out
+    for t in (weight, bias, shift, scale):
+        assert t is None or t.dtype == torch.float32
+    ms = shift.stride(0) if (shift is not None and shift.dim() == 2) else 0
+    _lib.check(_lib.lib().fino_ln_mxfp8(mode, _p(x2), _p(q), _p(s), rows, dim, ldx, _p(weight), _p(bias), _p(shift),
+                                       _p(scale), ms, _p(sel), eps, _dt(x), _stream()), "fino_ln_mxfp8")
+    return q, s
+
+
 def gemm_mxfp8(aq, a_scales, wq, w_scales, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None,
                out_dtype=torch.bfloat16):
     """C = epilogue(dequant(aq).dequant(wq)^T + bias): aq [M, K], wq [N, K] uint8 (e4m3) + their MX scales."""

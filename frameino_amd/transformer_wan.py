@@ -16,6 +16,7 @@ What is different by design (results identical):
 """
 import contextlib
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -269,8 +270,17 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         self.fp8_attention = bool(enabled)
         return self
 
-    def _lin(self, li, key, x, w, b, epi=0, **kw):
-        """one of a block's large linears: MXFP8 when enabled (and K is a multiple of 128), else the model-dtype GEMM"""
+    def _ln_q(self, li, key, mode, x, **ln):
+        """the LayerNorm in front of linear (li, key) emitted directly as that linear's MXFP8 activations (fino_ln_mxfp8: one
+        pass instead of norm -> bf16 -> quantise), or None when the linear is not on the MXFP8 path"""
+        o = self.ops
+        if not self._fp8 or (li, key) not in self._fp8 or not hasattr(o, "ln_mxfp8") or _NO_LN_MXFP8:
+            return None
+        return o.ln_mxfp8(mode, x, **ln)
+
+    def _lin(self, li, key, x, w, b, epi=0, xq=None, **kw):
+        """one of a block's large linears: MXFP8 when enabled (and K is a multiple of 128), else the model-dtype GEMM.
+        xq: the activations already quantised (_ln_q)"""
         wq = self._fp8.get((li, key)) if self._fp8 else None
         o = self.ops
         if wq is None and self._fp8 and key in ("kv", "q"):
@@ -279,7 +289,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             wq = self._fp8[(li, key)] = o.quantize_mxfp8(w.detach().contiguous())
         if wq is None:
             return o.gemm(x, w, b, epi, **kw)
-        xq, xs = o.quantize_mxfp8(x)
+        xq, xs = xq if xq is not None else o.quantize_mxfp8(x)
         return o.gemm_mxfp8(xq, xs, wq[0], wq[1], b, epi, **kw)
 
     def _workspace(self, L, dtype, device):
@@ -482,8 +492,12 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
             # 1. self-attention (:334-336)
             once = shared and li == 0
+            xq1 = None
             if not once:
-                o.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=nrm)
+                if default_procs and sh is None:
+                    xq1 = self._ln_q(li, "qkv", 0, x, shift=m[:, 0], scale=m[:, 1], sel=sel, eps=cfg.eps)
+                if xq1 is None:
+                    o.adaln_modulate(x, m[:, 0], m[:, 1], sel, cfg.eps, out=nrm)
             if not default_procs:
                 if sh is not None:
                     raise NotImplementedError("token-sharded execution needs the built-in MI355WanAttnProcessor")
@@ -503,7 +517,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     x[bi * n:(bi + 1) * n].copy_(x[:n])
             elif sh is None:
                 qkv = ws.qkv[:nr]
-                self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
+                self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, xq=xq1, out=qkv)
                 self._qk_norm_rope(blk, qkv, d, cos, sin, dh, qfold)
                 q3 = qkv.view(b, n, 3 * d)
                 attend(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
@@ -602,12 +616,16 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                           residual=x, gate=m[:, 2], sel=sel, out=x)
             # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange
             n2 = blk.norm2
-            if n2 is not None:
+            xq2 = self._ln_q(li, "q2", 1, x, weight=n2.weight, bias=n2.bias, eps=cfg.eps) if (n2 is not None and
+                                                                                                default_procs) else None
+            if xq2 is not None:
+                pass
+            elif n2 is not None:
                 o.layernorm(x, n2.weight, n2.bias, cfg.eps, out=nrm)
             else:
                 nrm.copy_(x)
             if default_procs:
-                self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, out=q2)
+                self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)
                 o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
@@ -618,11 +636,16 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                               **(attention_kwargs or {}))
                 o.gated_residual(x, a.reshape(nr, d), out=x)
             # 3. feed-forward (:344-348)
-            o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
             w1q, w2q = self._fp8.get((li, "ff1")), self._fp8.get((li, "ff2"))
+            xq3 = (self._ln_q(li, "ff1", 0, x, shift=m[:, 3], scale=m[:, 4], sel=sel, eps=cfg.eps)
+                   if (w1q is not None and w2q is not None) else None)
+            if xq3 is None:
+                o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
             if w1q is not None and w2q is not None:
-                # MXFP8: the GELU epilogue emits the hidden activations already quantised (no bf16 round trip)
-                hq = o.gemm_mxfp8_q(*o.quantize_mxfp8(nrm), w1q[0], w1q[1], blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH)
+                # MXFP8: the adaLN emits the FFN input already quantised, and the GELU epilogue the hidden activations (no
+                # bf16 round trips)
+                hq = o.gemm_mxfp8_q(*(xq3 if xq3 is not None else o.quantize_mxfp8(nrm)), w1q[0], w1q[1],
+                                    blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH)
                 o.gemm_mxfp8(hq[0], hq[1], w2q[0], w2q[1], blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
                              gate=m[:, 5], sel=sel, out=x)
             else:
@@ -647,6 +670,9 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
+
+
+_NO_LN_MXFP8 = bool(os.environ.get("FINO_NO_LN_MXFP8"))       # A/B knob: LayerNorm -> bf16 -> quantise as two passes
 
 
 class _CompactRope(tuple):

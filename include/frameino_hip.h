@@ -82,6 +82,14 @@ int fino_layernorm_zero(const void* x, void* y, int64_t rows, int dim, int64_t l
                         const float* b, const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel,
                         float eps, int dtype, void* stream);
 
+/* The three LayerNorm forms above with the result emitted as MXFP8 activations -- the bytes fino_quantize_mxfp8 produces from
+ * the T-rounded y (e4m3 to q [rows, dim], one e8m0 scale per 32 channels in that function's layout), without writing y:
+ * mode 0 = fino_adaln_modulate, 1 = fino_layernorm (w / b may be NULL), 2 = fino_layernorm_zero.  dim % 128 == 0.  The input
+ * of the MXFP8 linears that follow an adaLN (transformer.enable_mxfp8_linears()): one pass instead of two. */
+int fino_ln_mxfp8(int mode, const void* x, void* q, void* scales, int64_t rows, int dim, int64_t ldx, const float* w,
+                  const float* b, const float* shift, const float* scale, int64_t mod_stride, const int32_t* sel,
+                  float eps, int dtype, void* stream);
+
 /* In-place q/k preparation: RMSNorm over the whole row (all heads), weight multiply in T, then RoPE on adjacent
  * channel pairs with per-token tables cos/sin [rows, head_dim/2] fp32 (NULL => no RoPE).
  * transformer_wan.py:64-67 (norm_q / norm_k, "rms_norm_across_heads") and :73-90 (apply_rotary_emb).

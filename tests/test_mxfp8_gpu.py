@@ -181,3 +181,29 @@ def test_token_sharded_branch_uses_the_mxfp8_projections():
         if own_group:
             dist.destroy_process_group()
     assert rel_rms(sharded, base.float()) < 2e-3, rel_rms(sharded, base.float())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("rows", [24640, 1000, 257])
+def test_layernorm_emitting_mxfp8_equals_layernorm_then_quantise(mode, rows):
+    """fino_ln_mxfp8: adaLN / affine LayerNorm / LayerNormZero with the result as MXFP8 activations == the same LayerNorm to
+    bf16 followed by fino_quantize_mxfp8, byte for byte (elements and scales)"""
+    from frameino_amd import ops
+    d = 3072
+    g = torch.Generator(device=DEV).manual_seed(rows + mode)
+    x = torch.randn(rows, d, device=DEV, generator=g).bfloat16()
+    tab = torch.randn(2, 2, d, device=DEV, generator=g) * 0.3
+    sel = (torch.arange(rows, device=DEV) % 2).to(torch.int32)
+    w = 1 + 0.1 * torch.randn(d, device=DEV, generator=g)
+    b = 0.1 * torch.randn(d, device=DEV, generator=g)
+    if mode == 0:
+        y = ops.adaln_modulate(x, tab[:, 0], tab[:, 1], sel, 1e-6)
+        q, s = ops.ln_mxfp8(0, x, shift=tab[:, 0], scale=tab[:, 1], sel=sel, eps=1e-6)
+    elif mode == 1:
+        y = ops.layernorm(x, w, b, 1e-6)
+        q, s = ops.ln_mxfp8(1, x, weight=w, bias=b, eps=1e-6)
+    else:
+        y = ops.layernorm_zero(x, w, b, tab[:, 0], tab[:, 1], sel, 1e-5)
+        q, s = ops.ln_mxfp8(2, x, weight=w, bias=b, shift=tab[:, 0], scale=tab[:, 1], sel=sel, eps=1e-5)
+    q0, s0 = ops.quantize_mxfp8(y)
+    assert torch.equal(q, q0) and torch.equal(s, s0)
