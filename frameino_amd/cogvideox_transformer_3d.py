@@ -12,6 +12,7 @@ reference concatenates them for attention and for the feed-forward in every bloc
 LayerNormZero / gates are single kernels over all rows; the gate multiply + residual is the GEMM epilogue.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -229,12 +230,19 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
         self.fp8_attention = bool(enabled)
         return self
 
-    def _lin(self, li, key, x, w, b, epi=0, **kw):
+    def _lin(self, li, key, x, w, b, epi=0, xq=None, **kw):
         wq = self._fp8.get((li, key)) if self._fp8 else None
         if wq is None:
             return ops.gemm(x, w, b, epi, **kw)
-        xq, xs = ops.quantize_mxfp8(x)
+        xq, xs = xq if xq is not None else ops.quantize_mxfp8(x)
         return ops.gemm_mxfp8(xq, xs, wq[0], wq[1], b, epi, **kw)
+
+    def _lnz_q(self, li, key, x2, w, b, shift, scale, sel, eps):
+        """CogVideoXLayerNormZero in front of linear (li, key) emitted directly as that linear's MXFP8 activations
+        (fino_ln_mxfp8 mode 2: one pass instead of norm -> bf16 -> quantise); None when the linear is not on the MXFP8 path"""
+        if not self._fp8 or (li, key) not in self._fp8 or not hasattr(ops, "ln_mxfp8") or os.environ.get("FINO_NO_LN_MXFP8"):
+            return None
+        return ops.ln_mxfp8(2, x2, weight=w, bias=b, shift=shift, scale=scale, sel=sel, eps=eps)
 
     def _default_processors(self):
         return all(type(b.attn1.processor) in (MI355CogVideoXAttnProcessor, MI355FusedCogVideoXAttnProcessor)
@@ -352,9 +360,10 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
         # 3. blocks (:503-529)
         for li, (blk, e) in enumerate(zip(self.transformer_blocks, pk.layers)):
             t1, t2 = tables[2 * li], tables[2 * li + 1]                              # [2B, 3, D]
-            n = ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
+            xq1 = self._lnz_q(li, "qkv", x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps) if default_procs else None
+            n = None if xq1 is not None else ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
             if default_procs:
-                qkv = self._lin(li, "qkv", n, e.wqkv, e.bqkv).view(b, L, 3 * d)
+                qkv = self._lin(li, "qkv", n, e.wqkv, e.bqkv, xq=xq1).view(b, L, 3 * d)
                 nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
                 ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt, **qfold)
                 ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
@@ -368,11 +377,14 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
                                    image_rotary_emb=image_rotary_emb, **(attention_kwargs or {}))
                 y = torch.cat([ae, ah], dim=1).reshape(b * L, d)
                 ops.gated_residual(x2, y, t1[:, 2], sel, out=x2, staged=True)
-            n = ops.layernorm_zero(x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
             fp8 = self._fp8
             w1q, w2q = fp8.get((li, "ff1")), fp8.get((li, "ff2"))
+            xq2 = (self._lnz_q(li, "ff1", x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
+                   if (w1q is not None and w2q is not None) else None)
+            n = None if xq2 is not None else ops.layernorm_zero(x2, e.n2w, e.n2b, t2[:, 0], t2[:, 1], sel, c.norm_eps)
             if w1q is not None and w2q is not None:
-                hq = ops.gemm_mxfp8_q(*ops.quantize_mxfp8(n), w1q[0], w1q[1], blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
+                hq = ops.gemm_mxfp8_q(*(xq2 if xq2 is not None else ops.quantize_mxfp8(n)), w1q[0], w1q[1],
+                                      blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
                 ops.gemm_mxfp8(hq[0], hq[1], w2q[0], w2q[1], blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED,
                                residual=x2, gate=t2[:, 2], sel=sel, out=x2)
             else:
