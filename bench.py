@@ -5,9 +5,9 @@
 One "step" = what the reference loop does per iteration (pipelines/pipeline_wan_i2v_motion_FrameINO.py:809-908):
 model-input assembly, cond + uncond DiT forward (L = 14 x 22 x 40 = 12320 tokens, one ID frame), CFG, Euler update.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: starts its own N ranks (launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                   # ... or is started as one of them
 
 Prints ONE JSON line (rank 0).  N > 1 shards the SAME clip (strong scaling): CFG branches and/or token shards with a
 K/V all-gather over RCCL per attention layer (frameino_amd/parallel.py).
@@ -149,6 +149,37 @@ class Watchdog:
             os._exit(0 if (fb is not None or ok) else 3)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks OURSELVES, as a child process --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+    <same args>` -- relay rank 0's JSON line and return the child's exit status.  The parent has not touched the GPU
+    (`import torch` does not initialise HIP) and never exec's: a process that holds a GPU context must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ... as a child", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in child.stdout:                  # stderr is inherited; stdout is filtered down to THE line
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("[bench] the ranks exited 0 without a result line", file=sys.stderr, flush=True)
+        return 4
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,23 +205,28 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary numbers (hipGraph replay, UniPC, config 4, config 5, attention probes)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="rehearsal: take the N>1 code path (process group, sharded forward, collectives) with whatever "
+                         "--gpus says, 1 included: one rank drives real RCCL communicators of size 1.  With --plan "
+                         "interleave / --exchange heads the other plans' call sequences run the same way")
     ap.add_argument("--stall-s", type=float, default=240.0, help="N>1: seconds a phase may take before the watchdog acts")
     a = ap.parse_args()
 
+    if (a.gpus > 1 or a.force_shard) and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}: the line's n_gpus would be a guess")
     backend = os.environ.get("FINO_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 flow on fewer GPUs than ranks
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    dog = Watchdog(rank) if world > 1 else None
-    if world > 1:
+    multi = world > 1 or a.force_shard
+    dog = Watchdog(rank) if multi else None
+    if multi:
         dog.arm("init_process_group", a.stall_s)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -225,20 +261,20 @@ def main():
     pipe = WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=model,
                                    expand_timesteps=True)
     plans = {}
-    if world > 1:
+    if multi:
         from frameino_amd.parallel import make_plan, shard_pipeline
         dog.arm("communicators", a.stall_s)
         # every rank creates every communicator, in the same order
         base = {}
         if a.plan in ("auto", "split"):
-            base["split"] = make_plan(rank, world, True, "split")
+            base["split"] = make_plan(rank, world, True, "split", allow_single=a.force_shard)
         if a.plan == "interleave" or (a.plan == "auto" and world >= 4):
-            base["interleave"] = make_plan(rank, world, mode="interleave")
+            base["interleave"] = make_plan(rank, world, mode="interleave", allow_single=a.force_shard)
         # each plan with the K|V all-gather and with the heads all-to-all (same communicators); the all-gather form of the
         # first plan is measured first -- its line stands whatever happens in the probes that follow
         nheads = cfg["num_attention_heads"]
         for name, pl in base.items():
-            heads_ok = pl.token_ways > 1 and nheads % pl.token_ways == 0
+            heads_ok = (pl.token_ways > 1 or a.force_shard) and nheads % pl.token_ways == 0
             if a.exchange in ("auto", "kv") or not heads_ok:
                 plans[name] = pl
             if a.exchange in ("auto", "heads") and heads_ok:
@@ -272,12 +308,12 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not multi:
             return x
         t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -366,7 +402,7 @@ def main():
         ms_step = elapsed / a.steps * 1e3
         # FLOPs actually issued: on one GPU the two CFG branches are one batch-2 forward whose branch-invariant prefix
         # runs once (the N > 1 plans run two whole batch-1 forwards)
-        shared = world == 1 and getattr(model, "dedup_shared_prefix", False) and not a.cfg_streams
+        shared = not multi and getattr(model, "dedup_shared_prefix", False) and not a.cfg_streams
         flops_step = 2 * wan_flops_per_forward(L, cfg) - (wan_flops_shared_prefix(L, cfg) if shared else 0)
         out = {
             "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
@@ -391,7 +427,7 @@ def main():
         return json.dumps(out)
 
     # ================================================================ N > 1: strong scaling of the same clip
-    if world > 1:
+    if multi:
         names = list(plans)
         first = plans[names[0]]
         shard_pipeline(pipe, rank, world, plan=first)
@@ -401,8 +437,14 @@ def main():
         probe = {first.desc: elapsed / a.steps * 1e3}
         gather_us = {first.desc: wire_us(first)}
 
+        # how many ranks the communicator really reached: a sum of ones over the default group (RCCL when backend = nccl)
+        seen_t = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(seen_t)
+        ranks_seen = int(seen_t.item())
+
         def line_for(el, plan):
-            return result_line(el, plan.desc, {"rccl_ranks": world, "backend": backend, "plan_probe_ms_per_step": probe,
+            return result_line(el, plan.desc, {"rccl_ranks": world, "ranks_seen": ranks_seen, "backend": backend,
+                                               "plan_probe_ms_per_step": probe,
                                                "exchange_us_per_layer_call_alone_on_the_wire": gather_us,
                                                "local_first_attention": plan.shard.local_first() and plan.exchange == "kv",
                                                "attention_exchange": plan.exchange if plan.token_ways > 1 else None})
