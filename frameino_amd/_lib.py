@@ -67,11 +67,11 @@ SIGNATURES = {
     "fino_u8_hwc_to_chw_unit": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "fino_gemm": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "fino_gemm_split_n": [c_void_p] * 4 + [c_i64] * 6 + [c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
-                          c_i64, c_i64, c_void_p],
+                          c_i64, c_i64, c_int, c_void_p],
     "fino_ln_mxfp8": [c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                       c_void_p, c_float, c_int, c_void_p],
     "fino_gemm_blocked_a": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_i64,
-                            c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p],
+                            c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p],
     "fino_gemm_plan": [c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)],
     "fino_skinny_linear": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
     "fino_patchify": [c_void_p, c_void_p] + [c_int] * 7 + [c_i64, c_int, c_void_p],
@@ -94,6 +94,11 @@ _RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_
              "fino_attn_partial_bytes": c_i64, "fino_attn_fp8_kv_bytes": c_i64}
 
 
+# the FINO_VERSION this table (argument lists, tune-knob meanings) was written for: a stale library found through
+# FINO_LIB_PATH would otherwise fail late (AttributeError on a new symbol) or silently misread an argument
+ABI_VERSION = 101
+
+
 def declared_symbols(header_path=HEADER_PATH):
     """Every function the public header declares (used by the CPU test that checks the .so exports them)."""
     text = open(header_path).read()
@@ -113,6 +118,10 @@ def load(path=LIB_PATH):
             f"frameino_amd: {path} is a timing-EXPERIMENT build (compiled with -DFINO_EXPERIMENT: its kernels may skip "
             f"work and return wrong results; fino_version() = {lib.fino_version()}).  It is refused as the product library; "
             f"set FINO_ALLOW_EXPERIMENT=1 for the tools/ scripts that time it.")
+    if abs(lib.fino_version()) != ABI_VERSION:
+        raise RuntimeError(
+            f"frameino_amd: {path} reports fino_version() = {lib.fino_version()}, this package binds ABI version "
+            f"{ABI_VERSION} (include/frameino_hip.h: FINO_VERSION).  Rebuild it (`make -C frameino_amd/csrc`).")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

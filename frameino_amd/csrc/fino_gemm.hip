@@ -611,11 +611,34 @@ inline double plan_launch_cost(int64_t rows, int mi, int tiles_n, int cus) {
     }
     return c + 0.07;                                                             // a launch: ~5 us of a 74-us round
 }
-inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus) {
-    const int forced = fino_tune_get(FINO_TUNE_GEMM_TILE_M);          // A/B: 2..7 -> one launch of that height; 8 -> 256 only
+// `tile_m`: the caller's per-call choice (fino_gemm_split_n / fino_gemm_blocked_a: 2..7 -> one launch of 32 x that many rows
+// per tile, 8 -> 256-row tiles only); 0 = planned, or what the A/B knob FINO_TUNE_GEMM_TILE_M says (tools/ only).
+// The search is (M / 256) x 7 cost evaluations and depends on (m, tiles_n, cus) only: memoised in a small direct-mapped
+// table (a step makes ~240 GEMM calls of a handful of shapes; a racing writer can at worst make a reader recompute).
+struct PlanSlot { std::atomic<uint64_t> key; std::atomic<uint64_t> val; };
+inline TilePlan plan_tiles_search(int64_t m, int tiles_n, int cus);
+inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus, int tile_m = 0) {
+    const int forced = tile_m ? tile_m : fino_tune_get(FINO_TUNE_GEMM_TILE_M);
     if (forced >= 2 && forced <= 7) return TilePlan{0, forced};
+    if (forced == 8 || m <= 0) return TilePlan{m, 8};
+    static PlanSlot memo[64];
+    // key: m (40 bits) | tiles_n (14 bits) | cus (10 bits); 0 never occurs (cus > 0)
+    const uint64_t key = ((uint64_t)m << 24) | ((uint64_t)(tiles_n & 0x3fff) << 10) | (uint64_t)(cus & 0x3ff);
+    PlanSlot& slot = memo[(key * 0x9E3779B97F4A7C15ull) >> 58];
+    if (m < (1ll << 40) && slot.key.load(std::memory_order_acquire) == key) {
+        const uint64_t v = slot.val.load(std::memory_order_relaxed);
+        if (slot.key.load(std::memory_order_acquire) == key) return TilePlan{(int64_t)(v >> 8), (int)(v & 0xff)};
+    }
+    const TilePlan tp = plan_tiles_search(m, tiles_n, cus);
+    if (m < (1ll << 40)) {
+        slot.key.store(0, std::memory_order_release);
+        slot.val.store(((uint64_t)tp.rows1 << 8) | (uint64_t)tp.mi2, std::memory_order_relaxed);
+        slot.key.store(key, std::memory_order_release);
+    }
+    return tp;
+}
+inline TilePlan plan_tiles_search(int64_t m, int tiles_n, int cus) {
     TilePlan best{m, 8};
-    if (forced == 8 || m <= 0) return best;
     double best_c = plan_launch_cost(m, 8, tiles_n, cus);
     const double base_c = best_c;
     const int64_t rows256 = (m + 255) / 256;
@@ -690,10 +713,10 @@ int launch_gemm_rows(GemmParams p, int64_t r0, int64_t rows, int mi, int epi, hi
 }
 
 template <typename T, bool GENERIC>
-int launch_gemm_e(const GemmParams& p, int epi, hipStream_t st) {
+int launch_gemm_e(const GemmParams& p, int epi, int tile_m, hipStream_t st) {
     const bool fits32 = ((p.m - 1) * p.lda + p.k) * 2 < (1ll << 31) && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
     if (!GENERIC && use_pingpong() && fits32) {
-        const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus());
+        const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus(), tile_m);
         if (tp.rows1 > 0)
             if (int rc = launch_gemm_rows<T>(p, 0, tp.rows1, 8, epi, st)) return rc;
         if (tp.rows1 < p.m) return launch_gemm_rows<T>(p, tp.rows1, p.m - tp.rows1, tp.mi2, epi, st);
@@ -762,14 +785,15 @@ extern "C" int fino_gemm(const void* a, const void* w, const void* bias, void* c
                          int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
                          const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* stream) {
     return fino_gemm_split_n(a, w, bias, c, m, n, k, lda, ldw, ldc, epilogue, r, ldr, gate, mod_stride, sel, dtype, nullptr,
-                             0, 0, stream);
+                             0, 0, 0, stream);
 }
 
 extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
                                  int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr,
                                  const float* gate, int64_t mod_stride, const int32_t* sel, int dtype, void* c2,
-                                 int64_t ldc2, int64_t n_split, void* stream) {
+                                 int64_t ldc2, int64_t n_split, int tile_m, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm: dtype %d", dtype);
+    FINO_CHECK(tile_m == 0 || (tile_m >= 2 && tile_m <= 8), FINO_ERR_ARG, "fino_gemm: tile_m=%d (0 = planned, 2 .. 8)", tile_m);
     if (c2 || n_split) {
         FINO_CHECK(c2 && n_split > 0 && n_split < n && n_split % BN == 0 && ldc2 % 8 == 0 && ldc2 >= n - n_split &&
                        fino_aligned16(c2) && k % BK == 0 && epilogue <= FINO_EPI_GELU_TANH,
@@ -806,16 +830,18 @@ extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias,
     const bool generic = (k % BK) != 0;
     if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
     if (dtype == FINO_BF16)
-        return generic ? launch_gemm_e<BF16, true>(p, epilogue, st) : launch_gemm_e<BF16, false>(p, epilogue, st);
-    return generic ? launch_gemm_e<F16, true>(p, epilogue, st) : launch_gemm_e<F16, false>(p, epilogue, st);
+        return generic ? launch_gemm_e<BF16, true>(p, epilogue, tile_m, st) : launch_gemm_e<BF16, false>(p, epilogue, tile_m, st);
+    return generic ? launch_gemm_e<F16, true>(p, epilogue, tile_m, st) : launch_gemm_e<F16, false>(p, epilogue, tile_m, st);
 }
 
 extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
                                    int64_t a_block_k, int64_t a_block_stride, int a_groups, int64_t a_group_stride,
                                    int64_t lda, int64_t ldw, int64_t ldc,
                                    const void* r, int64_t ldr, const float* gate, int64_t mod_stride, const int32_t* sel,
-                                   int dtype, void* stream) {
+                                   int dtype, int tile_m, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_gemm_blocked_a: dtype %d", dtype);
+    FINO_CHECK(tile_m == 0 || (tile_m >= 2 && tile_m <= 8), FINO_ERR_ARG, "fino_gemm_blocked_a: tile_m=%d (0 = planned, 2 .. 8)",
+               tile_m);
     FINO_CHECK(a && w && c && r && gate, FINO_ERR_ARG, "fino_gemm_blocked_a: null pointer");
     FINO_CHECK(m >= 0 && n > 0 && k > 0 && n % 8 == 0, FINO_ERR_ARG, "fino_gemm_blocked_a: bad shape");
     FINO_CHECK(a_block_k > 0 && a_block_k % BK == 0 && k % a_block_k == 0 && a_block_k / BK <= 256 && k / BK <= 4096,
@@ -840,12 +866,19 @@ extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bia
     p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.mod_stride = mod_stride;
     p.a_tpb = (int)(a_block_k / BK); p.a_inv = (65536 + p.a_tpb - 1) / p.a_tpb; p.a_blk_elems = a_block_stride;
     p.a_groups = a_groups; p.a_ginv = (65536 + a_groups - 1) / a_groups; p.a_grp_elems = a_group_stride;
+    // (x * ceil(65536 / d)) >> 16 == x / d holds while x * (d * ceil(65536 / d) - 65536) < 65536: check it for the largest
+    // K-tile index and the largest K-block index instead of trusting the shape limits above
+    FINO_CHECK((k / BK - 1) * ((int64_t)p.a_inv * p.a_tpb - 65536) < 65536 &&
+                   (nblk - 1) * ((int64_t)p.a_ginv * a_groups - 65536) < 65536,
+               FINO_ERR_UNSUPPORTED,
+               "fino_gemm_blocked_a: a_block_k=%lld / a_groups=%d with K=%lld is beyond the exact range of the kernel's "
+               "reciprocal index arithmetic", (long long)a_block_k, a_groups, (long long)k);
     p.tiles_m = (int)((m + BM - 1) / BM);
     p.tiles_n = (int)((n + BN - 1) / BN);
     p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
     if (p.group_m <= 0) p.group_m = gemm_default_group_m(p.tiles_n, k);
     hipStream_t st = (hipStream_t)stream;
-    const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus());
+    const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus(), tile_m);
     auto rows = [&](int64_t r0, int64_t nr, int mi) {
         return dtype == FINO_BF16 ? launch_gemm_rows<BF16>(p, r0, nr, mi, FINO_EPI_GATED_RESIDUAL, st)
                                   : launch_gemm_rows<F16>(p, r0, nr, mi, FINO_EPI_GATED_RESIDUAL, st);

@@ -310,10 +310,12 @@ def gemm_plan(m, n):
     return r.value, t.value
 
 
-def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None, out2=None, split=0):
+def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None, out2=None, split=0, tile_m=0):
     """C = epilogue(A.W^T + bias).  a [M, K] row-strided, w [N, K] (nn.Linear weight).
     `out2`, `split`: columns [split, N) of the product go to out2 [M, N - split], columns [0, split) to out [M, split]
-    (fino_gemm_split_n: the fused q | k | v projection of a token shard, k | v landing in the all-gather's send buffer)."""
+    (fino_gemm_split_n: the fused q | k | v projection of a token shard, k | v landing in the all-gather's send buffer).
+    `tile_m`: this call's tile height (0 = planned, 8 = 256-row tiles only, 2 .. 7 = 32 x tile_m rows); results do not
+    depend on it."""
     a2, m, k, lda = _rows2d(a)
     assert w.dim() == 2 and w.stride(1) == 1 and w.shape[1] == k and w.dtype == a.dtype
     n = w.shape[0]
@@ -325,7 +327,8 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
         c2, _, _, ldc2 = _rows2d(out2)
         ev = _timed("gemm")
         _lib.check(_lib.lib().fino_gemm_split_n(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue,
-                                               0, 0, 0, 0, 0, _dt(a), _p(c2), ldc2, split, _stream()), "fino_gemm_split_n")
+                                               0, 0, 0, 0, 0, _dt(a), _p(c2), ldc2, split, tile_m, _stream()),
+                   "fino_gemm_split_n")
         if ev is not None:
             ev.record()
             KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
@@ -337,15 +340,20 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     if bias is not None:
         assert bias.dtype == a.dtype and bias.is_contiguous()
     ev = _timed("gemm")
-    _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
-                                   ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
+    if tile_m:
+        _lib.check(_lib.lib().fino_gemm_split_n(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue,
+                                               _p(r2), ldr, _p(gate), ms, _p(sel), _dt(a), None, 0, 0, tile_m, _stream()),
+                   "fino_gemm_split_n")
+    else:
+        _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
+                                       ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
     if ev is not None:
         ev.record()
         KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
     return out
 
 
-def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
+def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out, tile_m=0):
     """out = residual + gate[sel] * (A.W^T + bias) with A given as K blocks: a_blocks [nblk, rows_pad, blk_k], or
     [groups, peers, rows_pad, blk_k] with K block j * groups + g at a_blocks[g, j] (last dims row-strided):
     A[i, b * blk_k + c] = block b [i, c] for i < rows.  fino_gemm_blocked_a: the out-projection reading the heads exchange's
@@ -362,7 +370,8 @@ def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
     ev = _timed("gemm")
     _lib.check(_lib.lib().fino_gemm_blocked_a(_p(a_blocks), _p(w), _p(bias), _p(o2), rows, n, k, bk, a_blocks.stride(1),
                                               groups, a_blocks.stride(0), a_blocks.stride(2), w.stride(0), ldc, _p(r2),
-                                              ldr, _p(gate), ms, _p(sel), _dt(a_blocks), _stream()), "fino_gemm_blocked_a")
+                                              ldr, _p(gate), ms, _p(sel), _dt(a_blocks), tile_m, _stream()),
+               "fino_gemm_blocked_a")
     if ev is not None:
         ev.record()
         KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * rows * n * k

@@ -61,6 +61,12 @@ class TokenShard:
     # only work it can put under its gather.
     fused_qkv = False
 
+    # tile height this shard's GEMM calls ask for (ops.gemm(..., tile_m=): a per-call argument of the C ABI, never process
+    # state): 0 = the library's planner (built for a GEMM alone on the chip); the interleaved plan sets 8 = 256-row tiles
+    # only -- its second kernel stream fills the CUs a partial round of tiles leaves idle, and lower tiles only add operand
+    # traffic there (tools/plan_sim.py)
+    gemm_tile_m = 0
+
     def fused_qkv_ok(self):
         return bool(self.fused_qkv)
 
@@ -210,6 +216,7 @@ class ParallelPlan:
             for sh in self.shards:
                 sh.head_groups = 1
                 sh.fused_qkv = True
+                sh.gemm_tile_m = 8
         self._buf = None
 
     def with_exchange(self, exchange):
@@ -266,17 +273,6 @@ def make_plan(rank, world, cfg_parallel=True, mode="split", allow_single=False, 
     return ParallelPlan(rank, world, cfg_ways, token_ways, token_group, cfg_group, exchange=exchange)
 
 
-def _set_gemm_tiling(interleaved):
-    """An interleaved rank runs two kernel streams: the other branch fills the CUs a partial round of GEMM tiles leaves
-    idle, so the library's tile-height planner (built for a GEMM alone on the chip) is told to keep 256-row tiles --
-    lower tiles only add operand traffic there (tools/plan_sim.py).  Process-wide: one process per GPU."""
-    try:
-        from . import _lib
-        _lib.lib().fino_tune_set(3, 8 if interleaved else 0)          # FINO_TUNE_GEMM_TILE_M
-    except (RuntimeError, OSError):                                   # CPU-only test runs (gloo): no library, no kernels
-        pass
-
-
 def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None, allow_single=False, exchange="kv"):
     plan = plan or make_plan(rank, world, cfg_parallel, mode, allow_single, exchange)
     heads = getattr(getattr(pipe.transformer, "config", None), "num_attention_heads", None)
@@ -284,7 +280,6 @@ def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None
         raise ValueError(f"the heads exchange needs num_attention_heads ({heads}) divisible by the token shards "
                          f"({plan.token_ways})")
     pipe.parallel = plan
-    _set_gemm_tiling(plan.interleave)
     pipe.parallel_desc = plan.desc
     pipe.token_shards = plan.token_ways
     pipe.transformer.parallel = plan.shard if plan.shard.active else None

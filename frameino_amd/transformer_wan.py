@@ -289,6 +289,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             wq = self._fp8[(li, key)] = o.quantize_mxfp8(w.detach().contiguous())
         if wq is None:
             return o.gemm(x, w, b, epi, **kw)
+        kw.pop("tile_m", None)                                  # (the MXFP8 GEMM has one tile height)
         xq, xs = xq if xq is not None else o.quantize_mxfp8(x)
         return o.gemm_mxfp8(xq, xs, wq[0], wq[1], b, epi, **kw)
 
@@ -423,6 +424,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             cos1, sin1 = cos1[lo:lo + n].contiguous(), sin1[lo:lo + n].contiguous()
         else:
             lo, n, lpad = 0, L, L
+        # the shard's tile height for its GEMM calls (a per-call argument of the C ABI; {} = the library's planner)
+        tk = {"tile_m": sh.gemm_tile_m} if (sh is not None and getattr(sh, "gemm_tile_m", 0)) else {}
         # Batch elements are extra ROWS of the token-major buffers ([B*n, D]): every GEMM / norm is one launch over
         # both CFG branches (twice the tiles per launch, weights read once); attention and RoPE index rows per batch.
         nr = b * n
@@ -480,7 +483,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         else:
             a_rows = torch.cat([o.patchify(hidden_states[i], cfg.patch_size) for i in range(b)])
         x = ws.x[:nr]
-        o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=x[:n] if shared else x)
+        o.gemm(a_rows, pk.w_patch, self.patch_embedding.bias, out=x[:n] if shared else x, **tk)
         nrm, att, q2, ff = ws.n[:nr], ws.att[:nr], ws.q2[:nr], ws.ff[:nr]
         fold = self.fold_softmax_scale and hasattr(o, "SCALE_FOLDED")
         qfold = {"out_scale": dh ** -0.5 * o.LOG2E} if fold else {}
@@ -528,7 +531,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 hp = heads // ways
                 dp = hp * dh
                 qkv = ws.qkv[:n]
-                self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv)
+                self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, out=qkv, **tk)
                 # the heads travel in groups, every group its own all-to-all on the communicator's stream: while group g
                 # is attended to, group g+1 arrives and group g-1's outputs leave
                 lay = sh.heads_send_layout(heads, dh, lpad, dt, dev) if hasattr(o, "qkv_rmsnorm_rope_") else None
@@ -568,7 +571,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     for _, _, _, work in back:
                         if work is not None:
                             work.wait()
-                    o.gemm_blocked_a(orl, n, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, x, m[:, 2], sel, out=x)
+                    o.gemm_blocked_a(orl, n, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, x, m[:, 2], sel, out=x,
+                                     **tk)
                     once = True                                     # the common out-projection below is done
                 else:
                     a3 = att.view(n, ways, dp)
@@ -581,15 +585,15 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 if sh.fused_qkv_ok() and not self._fp8:
                     # ONE q | k | v GEMM whose k | v columns land in the all-gather's send buffer (fino_gemm_split_n): the
                     # interleaved plan, where the OTHER branch's compute is what the gather flies under
-                    o.gemm(nrm, e.wqkv, e.bqkv, out=q2, out2=kv_loc[:n], split=d)
+                    o.gemm(nrm, e.wqkv, e.bqkv, out=q2, out2=kv_loc[:n], split=d, **tk)
                     o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                     kv_all, work = sh.all_gather_kv(kv_loc)
                 else:
                     # K|V of the local tokens first, so that their all-gather (RCCL over xGMI) overlaps the Q projection
-                    self._lin(li, "kv", nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n])
+                    self._lin(li, "kv", nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n], **tk)
                     o.rmsnorm_rope_(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh)
                     kv_all, work = sh.all_gather_kv(kv_loc)
-                    self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2)
+                    self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2, **tk)
                 o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
                 if sh.local_first():
                     # local keys first -- nothing of it waits for the wire -- then what the gather delivered before /
@@ -613,7 +617,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d), **afold)
             if default_procs and not once:
                 self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
-                          residual=x, gate=m[:, 2], sel=sel, out=x)
+                          residual=x, gate=m[:, 2], sel=sel, out=x, **tk)
             # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange
             n2 = blk.norm2
             xq2 = self._ln_q(li, "q2", 1, x, weight=n2.weight, bias=n2.bias, eps=cfg.eps) if (n2 is not None and
@@ -625,12 +629,12 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             else:
                 nrm.copy_(x)
             if default_procs:
-                self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2)
+                self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2, **tk)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)
                 o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
                 self._lin(li, "out2", att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
-                          residual=x, out=x)
+                          residual=x, out=x, **tk)
             else:
                 a = blk.attn2(nrm.view(b, n, d), encoder_hidden_states=text.txt.view(b, lt, d),
                               **(attention_kwargs or {}))
@@ -649,9 +653,10 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 o.gemm_mxfp8(hq[0], hq[1], w2q[0], w2q[1], blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
                              gate=m[:, 5], sel=sel, out=x)
             else:
-                self._lin(li, "ff1", nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff)
+                self._lin(li, "ff1", nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff,
+                          **tk)
                 self._lin(li, "ff2", ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
-                          gate=m[:, 5], sel=sel, out=x)
+                          gate=m[:, 5], sel=sel, out=x, **tk)
             yield
 
         # ---- output head (:519-543) ----
@@ -660,7 +665,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             po = o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=ws.po[:nr])
         else:
             po_loc = sh.out_local(lpad, ws.po.shape[1], dt, dev)
-            o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=po_loc[:n])
+            o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=po_loc[:n], **tk)
             po = sh.all_gather_out(po_loc)[:L]
         if b == 1:
             out = o.unpatchify(po, cfg.out_channels, nf, hh, ww, cfg.patch_size)[None]

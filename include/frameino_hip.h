@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define FINO_VERSION 100
+/* 101: fino_gemm_split_n / fino_gemm_blocked_a take a per-call tile_m; FINO_TUNE_GEMM_TILE_M is an A/B knob only. */
+#define FINO_VERSION 101
 
 enum { FINO_BF16 = 0, FINO_F16 = 1 };
 enum {
@@ -207,11 +208,15 @@ int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m
  * product = column 0 of c2), columns [0, n_split) to c as usual: the fused q | k | v projection of a token-sharded rank
  * (transformer_wan.py:60-62 as ONE GEMM) leaves q in its own buffer and k | v contiguous in the buffer the K|V all-gather
  * sends -- no copy, and one GEMM of 3 D columns instead of a 2 D and a D one.  n_split a multiple of 256, K of 64; the
- * bias / GELU epilogues only. */
+ * bias / GELU epilogues only.  c2 == NULL and n_split == 0: plain fino_gemm (any epilogue).
+ * tile_m (here and in fino_gemm_blocked_a): the caller's tile height for THIS call -- 0 = planned (fino_gemm_plan), 8 =
+ * 256-row tiles only, 2 .. 7 = one launch of 32 x tile_m-row tiles.  Results never depend on it.  A rank that runs a second
+ * kernel stream beside its GEMMs (the interleaved multi-GPU plan) passes 8: the other stream fills the CUs a partial round
+ * leaves idle, lower tiles would only add operand traffic. */
 int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k, int64_t lda,
                       int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
                       int64_t mod_stride, const int32_t* sel, int dtype, void* c2, int64_t ldc2, int64_t n_split,
-                      void* stream);
+                      int tile_m, void* stream);
 /* c = r + gate[sel] * (A w^T + bias) (FINO_EPI_GATED_RESIDUAL) with a K-BLOCKED A: K block b (columns [b * a_block_k,
  * (b + 1) * a_block_k) of row i; a_block_k a multiple of 64 dividing K), b = j * a_groups + g, lives at
  * a + g * a_group_stride + j * a_block_stride + i * lda (elements).  That is the layout in which the heads all-to-all
@@ -221,7 +226,7 @@ int fino_gemm_split_n(const void* a, const void* w, const void* bias, void* c, i
 int fino_gemm_blocked_a(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
                         int64_t a_block_k, int64_t a_block_stride, int a_groups, int64_t a_group_stride, int64_t lda,
                         int64_t ldw, int64_t ldc, const void* r, int64_t ldr, const float* gate, int64_t mod_stride,
-                        const int32_t* sel, int dtype, void* stream);
+                        const int32_t* sel, int dtype, int tile_m, void* stream);
 
 /* The tiling fino_gemm uses for an M x N problem on the current device: `rows_256` leading rows run as 256 x 256 tiles
  * (a whole number of rounds of the CUs), the remaining rows as ONE more launch of `tile_rows_rest`-row tiles (64 .. 256

@@ -112,7 +112,7 @@ def attention_merge(parts, batch, lq, heads, head_dim, dtype, out=None):
     return o if out is None else out.copy_(o)
 
 
-def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None, out2=None, split=0):
+def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None, out=None, out2=None, split=0, tile_m=0):
     y = F.linear(a, w, bias)
     if out2 is not None:                                  # fino_gemm_split_n: columns [split, N) to a second buffer
         assert epilogue == EPI_NONE and residual is None
@@ -128,7 +128,7 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     return y if out is None else out.copy_(y)
 
 
-def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out):
+def gemm_blocked_a(a_blocks, rows, w, bias, residual, gate, sel, out, tile_m=0):
     if a_blocks.dim() == 4:                               # [groups, peers, rows_pad, bk]: K block j * groups + g = [g, j]
         a_blocks = a_blocks.permute(1, 0, 2, 3).reshape(-1, a_blocks.shape[2], a_blocks.shape[3])
     a = a_blocks[:, :rows].permute(1, 0, 2).reshape(rows, -1)

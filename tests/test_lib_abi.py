@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.fino_version() == 100
+    assert lib.fino_version() == 101 == _lib.ABI_VERSION
     # bad dtype -> FINO_ERR_ARG before anything touches a device
     rc = lib.fino_gemm(1, 1, 0, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 0, 0, 7, 0)
     assert rc == -1 and b"dtype" in lib.fino_last_error()
@@ -76,7 +76,7 @@ def test_an_experiment_build_is_refused_as_the_product_library(tmp_path, monkeyp
     and `_lib.load()` refuses it unless FINO_ALLOW_EXPERIMENT=1; the switches themselves do not compile without the macro."""
     import subprocess
     src = tmp_path / "fake.c"
-    src.write_text("int fino_version(void) { return -100; }\n")
+    src.write_text(f"int fino_version(void) {{ return -{_lib.ABI_VERSION}; }}\n")
     so = tmp_path / "libfake_experiment.so"
     subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
     monkeypatch.delenv("FINO_ALLOW_EXPERIMENT", raising=False)
@@ -85,6 +85,12 @@ def test_an_experiment_build_is_refused_as_the_product_library(tmp_path, monkeyp
     monkeypatch.setenv("FINO_ALLOW_EXPERIMENT", "1")
     with pytest.raises(AttributeError):              # accepted, then fails on the first symbol the stand-in lacks
         _lib.load(str(so))
+    # a library of another ABI version (a stale build found through FINO_LIB_PATH) is refused with a clear message
+    src.write_text("int fino_version(void) { return 100; }\n")
+    stale = tmp_path / "libfake_stale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(stale), str(src)], check=True)
+    with pytest.raises(RuntimeError, match="binds ABI version"):
+        _lib.load(str(stale))
     # the guard in the sources: every wrong-result switch is tied to FINO_EXPERIMENT, and the version follows the macro
     csrc = os.path.join(os.path.dirname(_lib.HEADER_PATH), "..", "frameino_amd", "csrc")
     common = open(os.path.join(csrc, "fino_common.h")).read()
