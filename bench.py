@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary numbers (hipGraph replay, UniPC, config 4, config 5, attention probes)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
+    ap.add_argument("--no-graph-probe", action="store_true",
+                    help="N>1: skip the hipGraph-replay probe of the best plan")
     ap.add_argument("--force-shard", action="store_true",
                     help="rehearsal: take the N>1 code path (process group, sharded forward, collectives) with whatever "
                          "--gpus says, 1 included: one rank drives real RCCL communicators of size 1.  With --plan "
@@ -442,16 +444,18 @@ def main():
         dist.all_reduce(seen_t)
         ranks_seen = int(seen_t.item())
 
-        def line_for(el, plan):
+        def line_for(el, plan, graphed=False):
             return result_line(el, plan.desc, {"rccl_ranks": world, "ranks_seen": ranks_seen, "backend": backend,
                                                "plan_probe_ms_per_step": probe,
                                                "exchange_us_per_layer_call_alone_on_the_wire": gather_us,
                                                "local_first_attention": plan.shard.local_first() and plan.exchange == "kv",
-                                               "attention_exchange": plan.exchange if plan.token_ways > 1 else None})
+                                               "attention_exchange": plan.exchange if plan.token_ways > 1 else None},
+                               use_graph=graphed)
 
-        best = (elapsed, first)
+        best = (elapsed, first, False)
         line = line_for(*best)
-        if len(names) > 1:
+        graph_probe = backend == "nccl" and not a.no_graph_probe      # (a gloo exchange is staged through the host)
+        if len(names) > 1 or graph_probe:
             # The first plan's line exists; from here on a stall costs nothing: the watchdog prints that line and leaves.
             # An exception in a probe (a collective the node's RCCL refuses, an out-of-memory) is treated like a stall: the
             # line already measured goes out and the process leaves -- the other ranks' watchdogs do the same.
@@ -470,13 +474,33 @@ def main():
                     if cand is None or probe[other.desc] < probe[cand.desc]:
                         cand = other
                     line = line_for(*best)                               # carries the probe times so far
-                if probe[cand.desc] < 0.98 * probe[first.desc]:
+                if cand is not None and probe[cand.desc] < 0.98 * probe[first.desc]:
                     dog.arm(f"timed run ({cand.desc})", a.stall_s + 2.0 * total, fallback=line)
                     shard_pipeline(pipe, rank, world, plan=cand)
                     el2, _ = timed_run(a.warmup, a.steps)
                     if el2 < elapsed and bool(torch.isfinite(st.lat).all()):
-                        best = (el2, cand)
+                        best = (el2, cand, False)
                 line = line_for(*best)                                   # carries every plan's probe time
+                if graph_probe:
+                    # the best plan's step captured into a hipGraph (RCCL collectives and side streams inside the capture)
+                    # and replayed: what pipe.denoise() does by default.  Probed like another plan -- a stall or an error
+                    # here costs nothing, the eager line is already there
+                    bplan = best[1]
+                    key = bplan.desc + "+hipgraph"
+                    dog.arm(f"probe ({key})", a.stall_s, fallback=line)
+                    shard_pipeline(pipe, rank, world, plan=bplan)
+                    el_g, _ = timed_run(1, 2, use_graph=True)
+                    probe[key] = el_g / 2 * 1e3
+                    if rank == 0:
+                        print(f"[bench] {bplan.desc}: eager {best[0] / a.steps * 1e3:.1f} ms/step; hipGraph replay "
+                              f"{probe[key]:.1f} ms/step (probe)", file=sys.stderr, flush=True)
+                    line = line_for(*best)
+                    if probe[key] < 0.98 * best[0] / a.steps * 1e3:
+                        dog.arm(f"timed run ({key})", a.stall_s + 2.0 * total, fallback=line)
+                        el3, _ = timed_run(max(a.warmup, 1), a.steps, use_graph=True)
+                        if el3 < best[0] and bool(torch.isfinite(st.lat).all()):
+                            best = (el3, bplan, True)
+                    line = line_for(*best)
             except Exception as ex:      # noqa: BLE001
                 print(f"[bench] rank {rank}: {type(ex).__name__} while probing another plan: {ex} -- leaving with the "
                       f"line already measured", file=sys.stderr, flush=True)

@@ -1,0 +1,69 @@
+"""hipGraph replay of a sampler loop's per-step program (BASELINE.json north_star: "the 50-step sampler loop is
+hipGraph-captured").
+
+Both pipelines express one denoise step as `_step(st)` on static device buffers: no host sync, no data-dependent shape,
+timestep / dt / coefficient rows refreshed by device-to-device copies between steps.  `StepGraph` runs such a program
+
+    step 0      eagerly -- it is a REAL step of the loop, and it fills every lazy cache the program reads (text K/V of the
+                30 cross-attention layers, workspaces, RoPE tables, side streams, send / receive buffers of the exchanges);
+    step 1      is captured (`torch.cuda.CUDAGraph` = hipGraph: capture enqueues nothing) and then replayed;
+    step 2 ...  are replays.
+
+So capture costs one host enqueue pass, no wasted step.  The token-sharded steps capture too: RCCL collectives issued with
+`async_op=True` from the capturing stream join the capture through their events (torch's NCCL process group skips its
+watchdog for captured work), and the interleaved plan's two side streams fork from / join the capturing stream with
+`wait_stream`.  What cannot be captured is a gloo exchange staged through host memory (tests) and a user callback between
+steps -- `capturable()` says no there and the loop stays eager.
+
+`mode`: None = automatic (graph when capturable; a failed capture falls back to the eager loop with a warning -- the same
+HIP kernels either way), True = required (a failed capture raises), False = eager.
+"""
+import warnings
+
+import torch
+
+
+def groups_capturable(plan):
+    """every process group the step's exchanges use is RCCL (`nccl`): a gloo exchange is staged through the host"""
+    if plan is None:
+        return True
+    import torch.distributed as dist
+    groups = [plan.token_group, plan.cfg_group, getattr(plan, "token_group_b", None)]
+    try:
+        return all(g is None or dist.get_backend(g) == "nccl" for g in groups)
+    except (RuntimeError, ValueError):
+        return False
+
+
+class StepGraph:
+    def __init__(self, step_fn, mode, capturable, total_steps):
+        self.step_fn, self.mode = step_fn, mode
+        # fewer than three steps: one eager + one capture pass and nothing left to replay
+        self.enabled = mode is not False and bool(capturable) and (total_steps >= 3 or mode is True)
+        if mode is True and not capturable:
+            raise RuntimeError("use_hip_graph=True, but this loop cannot be captured (a callback between steps, a gloo "
+                               "exchange staged through the host, or tensors that are not on a GPU)")
+        self.graph, self.ran = None, 0
+
+    def step(self):
+        if not self.enabled or self.ran == 0:
+            self.step_fn()
+        else:
+            if self.graph is None:
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g):
+                        self.step_fn()
+                except RuntimeError as ex:
+                    if self.mode is True:
+                        raise
+                    warnings.warn(f"hipGraph capture of the denoise step failed ({ex}); the loop continues eagerly on the "
+                                  f"same kernels", RuntimeWarning, stacklevel=2)
+                    self.enabled = False
+                    torch.cuda.synchronize()
+                    self.step_fn()
+                    self.ran += 1
+                    return
+                self.graph = g
+            self.graph.replay()
+        self.ran += 1

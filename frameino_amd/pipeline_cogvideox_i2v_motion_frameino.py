@@ -6,10 +6,11 @@ What is built: the CFG-batched denoise loop (:848-944) -
 kernels, ID-frame drop (:901-902), (dynamic) guidance (:906-911), v-prediction DDIM update (:916) in one kernel --
 plus `_prepare_rotary_positional_embeddings` (:540-584) with the FrameIn extension (:834-839).
 
-What is NOT here: the CogVideoX VAE and the T5 text encoder.  The reference takes them from diffusers / transformers
-(`AutoencoderKLCogVideoX`: third-party, no source in the reference tree, not installable offline), so `__call__`
-(:604-957: condition encodes, loop, decode, post-processing) runs around a user-supplied `vae` object with the
-diffusers interface and pre-computed prompt embeddings; `denoise()` works on latents alone.
+`__call__` (:604-957) takes what the reference's takes: `prompt=` / `negative_prompt=` strings go through `encode_prompt`
+(:269-348) and `_get_t5_prompt_embeds` (:226-267) on the pipeline's `tokenizer` / `text_encoder` -- the HF `transformers`
+T5 objects, third-party on both sides, once per clip -- or pre-computed `prompt_embeds`; the condition encodes and the
+decode run on the `vae` handed in (frameino_amd.autoencoder_kl_cogvideox, or any object with the diffusers
+AutoencoderKLCogVideoX interface); `denoise()` works on latents alone.
 """
 import math
 from types import SimpleNamespace
@@ -91,7 +92,8 @@ class CogVideoXImageToVideoPipeline:
         self.vae_scale_factor_temporal = 4
         self.vae_scaling_factor_image = getattr(getattr(vae, "config", None), "scaling_factor", 0.7)
         self._interrupt = False
-        self.use_hip_graph = False           # replay the step from a captured hipGraph (as the Wan pipeline)
+        self.use_hip_graph = None            # None: replay the step from a captured hipGraph whenever the loop is
+        #                                      capturable (no per-step callback); False: eager; True: capture or raise
 
     def enable_model_cpu_offload(self, *a, **k):
         return self
@@ -124,6 +126,92 @@ class CogVideoXImageToVideoPipeline:
     @property
     def interrupt(self):
         return self._interrupt
+
+    @property
+    def _execution_device(self):
+        return self.transformer.device
+
+    # ---- text (once per clip; HF transformers T5, not on the kernel path) ----
+    def _get_t5_prompt_embeds(self, prompt=None, num_videos_per_prompt=1, max_sequence_length=226, device=None,
+                              dtype=None):
+        """reference :226-267: tokenizer(padding="max_length", truncation) -> text_encoder(ids)[0]; unlike the Wan
+        pipeline no attention mask is passed and the padded positions keep what the encoder made of them"""
+        if self.tokenizer is None or self.text_encoder is None:
+            raise ValueError("encoding a prompt string needs the pipeline's `tokenizer` and `text_encoder` (the HF T5 "
+                             "objects the reference loads, test_code/run_cogvideox_FrameIn_mass_evaluation.py:92-101); "
+                             "pass them, or pass `prompt_embeds` / `negative_prompt_embeds`")
+        device = device or self._execution_device
+        dtype = dtype or self.text_encoder.dtype
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        bsz = len(prompt)
+        ti = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                            add_special_tokens=True, return_tensors="pt")
+        ids = ti.input_ids
+        untruncated = self.tokenizer(prompt, padding="longest", return_tensors="pt").input_ids
+        if untruncated.shape[-1] >= ids.shape[-1] and not torch.equal(ids, untruncated):
+            import warnings
+            removed = self.tokenizer.batch_decode(untruncated[:, max_sequence_length - 1:-1])
+            warnings.warn(f"The following part of your input was truncated because `max_sequence_length` is set to "
+                          f"{max_sequence_length} tokens: {removed}")
+        emb = self.text_encoder(ids.to(device))[0].to(dtype=dtype, device=device)
+        _, seq_len, _ = emb.shape
+        return emb.repeat(1, num_videos_per_prompt, 1).view(bsz * num_videos_per_prompt, seq_len, -1)
+
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, num_videos_per_prompt=1,
+                      prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length=226, device=None, dtype=None):
+        """reference :269-348"""
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        bsz = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = self._get_t5_prompt_embeds(prompt, num_videos_per_prompt, max_sequence_length, device, dtype)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = bsz * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got "
+                                f"{type(negative_prompt)} != {type(prompt)}.")
+            elif bsz != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but "
+                                 f"`prompt`: {prompt} has batch size {bsz}. Please make sure that passed "
+                                 f"`negative_prompt` matches the batch size of `prompt`.")
+            negative_prompt_embeds = self._get_t5_prompt_embeds(negative_prompt, num_videos_per_prompt,
+                                                                max_sequence_length, device, dtype)
+        return prompt_embeds, negative_prompt_embeds
+
+    def check_inputs(self, image, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs,
+                     latents=None, prompt_embeds=None, negative_prompt_embeds=None):
+        """reference :461-523 (same conditions, same error classes)"""
+        import PIL.Image
+        if not isinstance(image, (torch.Tensor, PIL.Image.Image, list)):
+            raise ValueError(f"`image` has to be of type `torch.Tensor` or `PIL.Image.Image` or `List[PIL.Image.Image]` "
+                             f"but is {type(image)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            bad = [k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but "
+                             f"found {bad}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of "
+                             "the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` "
+                             "undefined.")
+        elif prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `negative_prompt_embeds`. Please make sure to only forward "
+                             "one of the two.")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`. Please make sure to "
+                             "only forward one of the two.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None \
+                and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError(f"`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed "
+                             f"directly, but got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` "
+                             f"{negative_prompt_embeds.shape}.")
 
     def _prepare_rotary_positional_embeddings(self, height, width, num_frames, device):
         """reference :540-584 (patch_size_t None) + the FrameIn first-frame extension :834-839."""
@@ -191,7 +279,11 @@ class CogVideoXImageToVideoPipeline:
         st.coef = torch.zeros(coefs.shape[1], dtype=torch.float32, device=dev)
         st.x0_old = torch.zeros(lat.shape, dtype=torch.float32, device=dev) if dpm else None
         st.noise = torch.zeros_like(lat) if dpm else None
-        graph = None
+        from .graph_step import StepGraph
+        from .pipeline_wan_i2v_motion_frameino import tr_default_procs
+        stepper = StepGraph(lambda: self._step(st), self.use_hip_graph,
+                            callback_on_step_end is None and lat.is_cuda
+                            and (self.use_hip_graph is True or tr_default_procs(tr)), len(ts))
         for i, t in enumerate(ts):
             if self._interrupt:
                 continue
@@ -199,19 +291,7 @@ class CogVideoXImageToVideoPipeline:
             st.coef.copy_(coefs[i])
             if dpm:
                 st.noise.copy_(self.scheduler.noise(i, lat.shape, generator, dev, dt))
-            if self.use_hip_graph and callback_on_step_end is None:
-                if graph is None:
-                    keep = [st.lat] + ([st.x0_old] if dpm else [])
-                    snap = [b.clone() for b in keep]
-                    self._step(st)                            # eager pass fills every lazy cache before the capture
-                    for b, sv in zip(keep, snap):
-                        b.copy_(sv)
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        self._step(st)
-                graph.replay()
-            else:
-                self._step(st)
+            stepper.step()
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": lat[None]})
                 if "latents" in out and out["latents"] is not None:
@@ -279,18 +359,28 @@ class CogVideoXImageToVideoPipeline:
                  generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type="pil",
                  return_dict=True, attention_kwargs=None, callback_on_step_end=None,
                  callback_on_step_end_tensor_inputs=["latents"], max_sequence_length=226):
-        """reference :604-957 with pre-computed prompt embeddings (the T5 encoder is third-party; pass
-        `prompt_embeds` / `negative_prompt_embeds` [1, 226, 4096]) and one video per call."""
+        """reference :604-957, one video per call: `prompt=` / `negative_prompt=` strings (what app.py:719 and
+        test_code/run_cogvideox_FrameIn_mass_evaluation.py:206-213 pass) or pre-computed `prompt_embeds` /
+        `negative_prompt_embeds` [1, 226, 4096].  As in the reference (:744, :766-768) guidance needs a negative branch:
+        with `guidance_scale > 1` and no `negative_prompt_embeds` the empty negative prompt is encoded."""
         self._need_vae()
         if timesteps is not None or eta != 0.0:
             raise NotImplementedError("custom timesteps / eta: the built sampler is the v-prediction DDIM step (eta 0)")
-        if prompt_embeds is None:
-            raise NotImplementedError("text encoding (T5, third-party) is outside the path: pass prompt_embeds")
+        if hasattr(callback_on_step_end, "tensor_inputs"):
+            callback_on_step_end_tensor_inputs = callback_on_step_end.tensor_inputs
         c = self.transformer.config
         height = height or c.sample_height * self.vae_scale_factor_spatial
         width = width or c.sample_width * self.vae_scale_factor_spatial
-        dev = prompt_embeds.device
+        self.check_inputs(image, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, latents,
+                          prompt_embeds, negative_prompt_embeds)
+        if isinstance(prompt, list) and len(prompt) != 1:
+            raise NotImplementedError("one video per call")
+        dev = self._execution_device
         dt = self.transformer.dtype
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, negative_prompt, guidance_scale > 1.0, 1, prompt_embeds, negative_prompt_embeds, max_sequence_length,
+            dev)                                                                                # :757-766
+        prompt_embeds = prompt_embeds.to(dev)
         self._interrupt = False
         if isinstance(image, torch.Tensor):
             img = image if image.ndim == 4 else image[None]

@@ -11,8 +11,10 @@ The 50-step loop (:809-908) runs on HIP kernels only:
     WanTransformer3DModel x2  cond / uncond forward with the de-duplicated per-token timestep {0, t} (:832-843)
     fino_cfg_euler_step       CFG combine, ID-frame drop, flow-match Euler update (:882-891)
 
-With `use_hip_graph=True` one step is captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; timestep and
-dt live in device buffers that a tiny copy node refreshes between replays (no host sync inside the loop).
+The loop replays ONE captured step from a hipGraph (frameino_amd/graph_step.py: step 0 eager, step 1 captured, the rest
+replays; timestep and dt live in device buffers that a device-to-device copy refreshes between replays, no host sync
+inside the loop) whenever the call has no per-step callback -- single GPU and token-sharded plans alike.
+`use_hip_graph = False` keeps the eager loop, `True` makes a failed capture an error.
 """
 import html
 import re
@@ -75,6 +77,13 @@ class WanPipelineOutput(SimpleNamespace):
     pass
 
 
+def tr_default_procs(transformer):
+    """the built-in processors run only this library's kernels: capturable.  A user-installed processor may do anything
+    (host syncs included), so its loop stays eager unless `use_hip_graph = True` asks for the capture"""
+    f = getattr(transformer, "_default_processors", None)
+    return bool(f()) if callable(f) else True
+
+
 class WanImageToVideoPipeline:
     model_cpu_offload_seq = "text_encoder->image_encoder->transformer->transformer_2->vae"
     _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
@@ -92,7 +101,7 @@ class WanImageToVideoPipeline:
         self.vae_scale_factor_temporal = vae.config.scale_factor_temporal if vae is not None else 4
         self.vae_scale_factor_spatial = vae.config.scale_factor_spatial if vae is not None else 8
         self.video_processor = VideoProcessor(vae_scale_factor=self.vae_scale_factor_spatial)
-        self.use_hip_graph = False
+        self.use_hip_graph = None        # None: graph replay whenever the loop is capturable (graph_step.StepGraph)
         self.batch_cfg = True            # run cond+uncond as one batch-2 forward when not CFG-parallel
         self.cfg_streams = False         # ... or as two B=1 forwards on two concurrent streams (takes precedence)
         self._streams = None
@@ -416,7 +425,11 @@ class WanImageToVideoPipeline:
         ts_dev = timesteps.to(dev).float()
         self._num_timesteps = len(timesteps)
 
-        graph = None
+        from .graph_step import StepGraph, groups_capturable
+        stepper = StepGraph(lambda: self._step(st), self.use_hip_graph,
+                            callback_on_step_end is None and st.lat.is_cuda
+                            and (self.use_hip_graph is True or tr_default_procs(self.transformer))
+                            and groups_capturable(getattr(self, "parallel", None)), len(timesteps))
         for i in range(len(timesteps)):
             if self._interrupt:
                 continue
@@ -426,20 +439,7 @@ class WanImageToVideoPipeline:
                 st.coef.copy_(coefs[i])
             else:
                 st.dt.copy_(dts[i:i + 1])
-            if self.use_hip_graph and callback_on_step_end is None:
-                if graph is None:
-                    # eager warm-up step fills every lazy cache (text K/V, workspaces, kernel attributes)
-                    keep = [st.lat] + list(st.unipc or ())
-                    snap = [b.clone() for b in keep]
-                    self._step(st)
-                    for b, sv in zip(keep, snap):
-                        b.copy_(sv)
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        self._step(st)
-                graph.replay()
-            else:
-                self._step(st)
+            stepper.step()
             if callback_on_step_end is not None:
                 latents = st.lat[None]
                 loc = {"latents": latents, "prompt_embeds": st.pe, "negative_prompt_embeds": st.ne}

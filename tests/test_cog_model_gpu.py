@@ -179,8 +179,19 @@ def test_cog_full_call_vs_the_reference_pipeline_run(golden):
     ref = a["out_video"].numpy()
     mse = float(((vid - ref) ** 2).mean())
     psnr = 10 * torch.log10(torch.tensor(1.0 / max(mse, 1e-20))).item()
-    record("cog_call[out_video]", "PSNR dB hip bf16 video vs reference fp32 run (higher is better)", psnr, 22.0, lower_is_better=False)
-    assert vid.shape == ref.shape and psnr > 22.0, psnr
+    # the yardstick: the REFERENCE pipeline's own bf16 run against its fp32 run on this fixture (recorded by the generator;
+    # 29.9 dB -- the tiny random-weight DiT + VAE amplify bf16 rounding of 4 sampler steps, so ~30 dB is what reduced
+    # precision costs HERE, on either implementation).  Bound: that figure minus 2 dB.
+    ref_b = a["out_video_bf16"].numpy()
+    psnr_ref = 10 * torch.log10(torch.tensor(1.0 / max(float(((ref_b - ref) ** 2).mean()), 1e-20))).item()
+    record("cog_call[out_video]", f"PSNR dB hip bf16 video vs reference fp32 run (reference's own bf16 run: "
+           f"{psnr_ref:.2f} dB; higher is better)", psnr, psnr_ref - 2.0, lower_is_better=False)
+    assert vid.shape == ref.shape and psnr > psnr_ref - 2.0, (psnr, psnr_ref)
+    # where the error sits: the loop's latents (3.3e-2 from fp32 on both implementations) decoded by the reference-fp32
+    # arithmetic give the same PSNR as the bf16 decode of them -- the decode adds nothing measurable
+    mse_b = float(((vid - ref_b) ** 2).mean())
+    record("cog_call[out_video vs ref bf16]", "PSNR dB hip bf16 video vs the reference's bf16 video", 
+           10 * torch.log10(torch.tensor(1.0 / max(mse_b, 1e-20))).item(), psnr_ref - 2.0, lower_is_better=False)
 
 
 def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):
@@ -382,8 +393,9 @@ def test_cog_loop_hip_graph_replay_equals_eager(golden, sched):
         return pipe.denoise(d("latents0"), d("image_latents"), d("traj_latents"), d("id_latent"), d("prompt_embeds"),
                             d("negative_embeds"), float(a["guidance"]), 5, generator=torch.Generator().manual_seed(3))
 
+    pipe.use_hip_graph = False
     eager = run()
-    pipe.use_hip_graph = True
+    pipe.use_hip_graph = True                  # (the default, None, also replays: True makes a failed capture an error)
     graphed = run()
     assert torch.equal(eager, graphed)
 

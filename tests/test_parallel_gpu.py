@@ -128,6 +128,7 @@ def _nccl_worker(q, port, mode, exchange="kv"):
         assert dist.get_backend() == "nccl"
         pipe, a = _pipe("cuda:0")
         pipe.batch_cfg = False
+        pipe.use_hip_graph = False
         single = _run(pipe, a, "cuda:0").cpu()
         plan = shard_pipeline(pipe, 0, 1, cfg_parallel=False, mode=mode, allow_single=True, exchange=exchange)
         assert plan.shard.force and pipe.transformer.parallel is plan.shard
@@ -135,8 +136,14 @@ def _nccl_worker(q, port, mode, exchange="kv"):
         out = _run(pipe, a, "cuda:0")
         # a second pass: buffers and communicators are reused, nothing stale
         out2 = _run(pipe, a, "cuda:0")
+        # the SHARDED step captured into a hipGraph (the async RCCL collectives and, interleaved, the two side streams
+        # join the capture) and replayed: True = a failed capture raises; then the default (None = automatic)
+        pipe.use_hip_graph = True
+        out_g = _run(pipe, a, "cuda:0")
+        pipe.use_hip_graph = None
+        out_auto = _run(pipe, a, "cuda:0")
         torch.cuda.synchronize()
-        q.put((plan.desc, single, out.cpu(), out2.cpu()))
+        q.put((plan.desc, single, out.cpu(), out2.cpu(), out_g.cpu(), out_auto.cpu()))
     finally:
         dist.destroy_process_group()
 
@@ -155,7 +162,7 @@ def test_sharded_path_through_rccl_single_rank(mode, desc, exchange):
     p = ctx.Process(target=_nccl_worker, args=(q, _free_port(), mode, exchange))
     p.start()
     try:
-        d, single, out, out2 = q.get(timeout=600)
+        d, single, out, out2, out_g, out_auto = q.get(timeout=600)
     finally:
         p.join(timeout=120)
         if p.is_alive():
@@ -163,6 +170,8 @@ def test_sharded_path_through_rccl_single_rank(mode, desc, exchange):
     assert p.exitcode == 0
     assert d == desc
     assert torch.isfinite(out).all() and torch.equal(out, out2)
+    # graph replay of the sharded step (steps 1 .. n-1 replayed; step 0 eager) == the eager sharded loop, bit for bit
+    assert torch.equal(out, out_g) and torch.equal(out, out_auto)
     # separate K|V and Q projections instead of the fused QKV GEMM: same per-element arithmetic
     assert rel_rms(out, single) < 5e-3, rel_rms(out, single)
 

@@ -47,8 +47,9 @@ def test_denoise_loop_vs_reference_pipeline(golden):
 
 def test_hip_graph_replay_equals_eager(golden):
     pipe, a = _pipe(golden)
+    pipe.use_hip_graph = False
     eager = _run(pipe, a)
-    pipe.use_hip_graph = True
+    pipe.use_hip_graph = True                  # (the default, None, also replays: True makes a failed capture an error)
     graphed = _run(pipe, a)
     assert torch.equal(eager, graphed)
 
@@ -153,8 +154,9 @@ def test_unipc_loop_vs_reference_pipeline_run(golden):
 
 def test_unipc_hip_graph_replay_equals_eager(golden):
     pipe, a = _unipc_pipe(golden)
+    pipe.use_hip_graph = False
     eager = _run(pipe, a)
-    pipe.use_hip_graph = True
+    pipe.use_hip_graph = True                  # (the default, None, also replays: True makes a failed capture an error)
     graphed = _run(pipe, a)
     assert torch.equal(eager, graphed)
 

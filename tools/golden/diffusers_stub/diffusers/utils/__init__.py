@@ -40,7 +40,9 @@ def replace_example_docstring(doc):
 
 
 def is_ftfy_available():
-    return False
+    import importlib.util
+    import sys
+    return "ftfy" in sys.modules or importlib.util.find_spec("ftfy") is not None
 
 
 def __getattr__(name):      # names only the reference's training script imports (never called on the denoising path)

@@ -125,8 +125,25 @@ def gen_wan_dit():
 
 
 # ----------------------------------------------------------------------------------- Wan pipeline
+def _ftfy_stand_in():
+    """`ftfy` is absent offline and the reference's prompt_clean (pipelines/pipeline_wan_i2v_motion_FrameINO.py:103-117)
+    calls ftfy.fix_text whenever a prompt STRING is given.  For the plain-ASCII prompts recorded here fix_text is the
+    identity (it repairs mojibake), so an identity module stands in; html.unescape and the whitespace collapse that follow
+    are the reference's own code and are exercised by the prompt below."""
+    import types
+    if "ftfy" not in sys.modules:
+        mod = types.ModuleType("ftfy")
+        mod.fix_text = lambda s: s
+        sys.modules["ftfy"] = mod
+
+
+WAN_PROMPT = "  A red ball   rolls to the right &amp;amp; stops.\n"      # doubled spaces, a double-escaped entity, a newline
+COG_PROMPT = "a red ball"
+
+
 def gen_wan_pipe():
     import PIL.Image
+    _ftfy_stand_in()
     from diffusers.schedulers import FlowMatchEulerDiscreteScheduler, UniPCMultistepScheduler
     from architecture.autoencoder_kl_wan import AutoencoderKLWan
     from architecture.transformer_wan import WanTransformer3DModel
@@ -181,6 +198,22 @@ def gen_wan_pipe():
     np.savez_compressed(os.path.join(OUT, "wan_pipe_unipc_tiny.npz"), out_latents=to_np(out_unipc), steps=np.array(6),
                         timesteps=to_np(pipe.scheduler.timesteps))
     print("wrote wan_pipe_unipc_tiny.npz (outputs only: weights and inputs are wan_pipe_tiny's)")
+    # the `prompt=` route both canonical callers take (app.py:708-719): the reference's own encode_prompt /
+    # _get_t5_prompt_embeds (:206-337: prompt_clean, tokenizer call, UMT5 encoder, zero padding past the true length) on a
+    # toy UMT5EncoderModel (the real transformers class) and a character tokenizer (tests/text_stub.py)
+    sys.path.insert(0, REPO)
+    from tests.text_stub import CharTokenizer, tiny_text_encoder
+    te = tiny_text_encoder("umt5", seed=71)
+    pipe_t = WanImageToVideoPipeline(tokenizer=CharTokenizer(), text_encoder=te, vae=vae,
+                                     scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=dit,
+                                     expand_timesteps=True)
+    pe_t, ne_t = pipe_t.encode_prompt(WAN_PROMPT, "", True, 1, max_sequence_length=512)
+    out_prompt = pipe_t(image=PIL.Image.fromarray(img), prompt=WAN_PROMPT, negative_prompt="", traj_tensor=traj,
+                        ID_tensor=idt, height=H, width=W, num_frames=F, num_inference_steps=steps, guidance_scale=5.0,
+                        latents=lat0.clone(), output_type="latent").frames
+    text = {"te/" + k: v for k, v in te.state_dict().items()}
+    text.update(prompt=np.array(WAN_PROMPT), negative_prompt=np.array(""), prompt_embeds_from_text=pe_t,
+                negative_embeds_from_text=ne_t, out_latents_prompt=out_prompt)
     sched.set_timesteps(steps)
     sd = {"dit." + k: v for k, v in dit.state_dict().items()}
     sd.update({"vae." + k: v for k, v in vae.state_dict().items()})
@@ -189,7 +222,7 @@ def gen_wan_pipe():
     save("wan_pipe_tiny", cfg=cfg, sd=sd, image=img, traj=traj, id_tensor=idt, prompt_embeds=pe, negative_embeds=ne,
          latents0=lat0, condition=rec["condition"], traj_latents=rec["traj_latents"], id_latent=rec["ID_latent"],
          mask=rec["mask"], timesteps=sched.timesteps, sigmas=sched.sigmas, out_latents=out_lat, out_video=out_np,
-         steps=np.array(steps), guidance=np.array(5.0))
+         steps=np.array(steps), guidance=np.array(5.0), **text)
 
 
 # ----------------------------------------------------------------------------------- Wan VAE
@@ -399,8 +432,15 @@ def gen_cog_pipe():
     lat0 = torch.randn(1, 3, lc, H // 8, W // 8, generator=g)
     steps, gs = 4, 6.0
 
-    def run(sched, seen=None, dit=dit, vae=vae, pe=pe, ne=ne, lat0=lat0, **kw):
-        pipe = CogVideoXImageToVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, transformer=dit, scheduler=sched)
+    def run(sched, seen=None, dit=dit, vae=vae, pe=pe, ne=ne, lat0=lat0, text=None, **kw):
+        pipe = CogVideoXImageToVideoPipeline(tokenizer=text and text[0], text_encoder=text and text[1], vae=vae,
+                                             transformer=dit, scheduler=sched)
+        if text is not None:             # the prompt= route (:757 -> encode_prompt :269-348 -> _get_t5_prompt_embeds :226-267)
+            seen["pe_text"], seen["ne_text"] = pipe.encode_prompt(COG_PROMPT, "", True, 1, max_sequence_length=8)
+            return pipe(image=PIL.Image.fromarray(img), traj_tensor=traj, ID_tensor=idt, prompt=COG_PROMPT,
+                        negative_prompt="", max_sequence_length=8, height=H, width=W, num_frames=F,
+                        num_inference_steps=steps, guidance_scale=gs, add_ID_reference_augment_noise=False,
+                        latents=lat0.clone(), **kw).frames
         if seen is not None:
             orig_prep, orig_fwd = pipe.prepare_latents, dit.forward
 
@@ -432,6 +472,13 @@ def gen_cog_pipe():
     out_dpm_dyn = run(CogVideoXDPMScheduler(), output_type="latent", use_dynamic_cfg=True,
                       generator=torch.Generator().manual_seed(11))
     video = run(CogVideoXDDIMScheduler(), output_type="np")
+    # the call both canonical callers make: prompt strings (app.py:719, test_code/run_cogvideox_FrameIn_mass_evaluation.py:
+    # 206-213) through a toy T5EncoderModel (the real transformers class) and a character tokenizer (tests/text_stub.py)
+    from tests.text_stub import CharTokenizer, tiny_text_encoder
+    te = tiny_text_encoder("t5", seed=72)
+    seen_t = {}
+    torch.manual_seed(7)
+    out_prompt = run(CogVideoXDDIMScheduler(), seen_t, text=(CharTokenizer(), te), output_type="latent")
     # the same calls with every module and the prompt embeddings in bf16 (this pipeline hands the VAE images in the prompt
     # embeddings' dtype, :786-788, so its modules share one dtype -- test_code/run_cogvideox_FrameIn_mass_evaluation.py
     # loads them all in fp16): the reference's own reduced-precision arithmetic and, for DPM, its noise drawn in bf16
@@ -442,6 +489,9 @@ def gen_cog_pipe():
     kwb = dict(dit=dit_b, vae=vae_b, pe=pe.bfloat16(), ne=ne.bfloat16(), lat0=lat0.bfloat16(), output_type="latent")
     out_ddim_b = run(CogVideoXDDIMScheduler(), **kwb)
     out_dpm_b = run(CogVideoXDPMScheduler(), generator=torch.Generator().manual_seed(11), **kwb)
+    # the reference's OWN bf16 video: what a reduced-precision run of the same pipeline scores against its fp32 video is
+    # the yardstick for the HIP pipeline's video
+    video_b = run(CogVideoXDDIMScheduler(), **dict(kwb, output_type="np"))
     x0 = seen["model_input0"]                                       # [2, 4, 48, 8, 8] = [noisy + ID | first frame + 0 | traj + 0]
     print("placeholder modules served:", sorted(set(_PlaceholderFinder.served)))
     sd = {"dit." + k: v for k, v in dit.state_dict().items()}
@@ -452,8 +502,11 @@ def gen_cog_pipe():
          latents0=lat0, latents_scaled=seen["latents_scaled"], image_latents=seen["image_latents"],
          traj_latents=x0[1:2, :3, 2 * lc:], id_latent=x0[1:2, 3:, :lc], model_input0=x0, rope_cos=seen["rope_cos"],
          rope_sin=seen["rope_sin"], out_ddim=out_ddim, out_ddim_dynamic_cfg=out_dyn, out_dpm=out_dpm,
-         out_dpm_dynamic_cfg=out_dpm_dyn, out_ddim_bf16=out_ddim_b, out_dpm_bf16=out_dpm_b, out_video=video, steps=np.array(steps), guidance=np.array(gs),
-         dpm_generator_seed=np.array(11))
+         out_dpm_dynamic_cfg=out_dpm_dyn, out_ddim_bf16=out_ddim_b, out_dpm_bf16=out_dpm_b, out_video=video,
+         out_video_bf16=video_b, steps=np.array(steps), guidance=np.array(gs), dpm_generator_seed=np.array(11),
+         prompt=np.array(COG_PROMPT), negative_prompt=np.array(""), prompt_embeds_from_text=seen_t["pe_text"],
+         negative_embeds_from_text=seen_t["ne_text"], out_ddim_prompt=out_prompt,
+         **{"te/" + k: v for k, v in te.state_dict().items()})
 
 
 GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae, "cog_dit": gen_cog_dit,

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from bench import build_model  # noqa: E402
-from frameino_amd.parallel import TokenShard, _set_gemm_tiling  # noqa: E402
+from frameino_amd.parallel import TokenShard  # noqa: E402
 
 
 class FakeShard(TokenShard):
@@ -54,10 +54,13 @@ def main():
     st.dt[0] = -0.01
 
     host_ms = [0.0]
+    graph_txt = [""]
+    want_graph = not os.environ.get("FINO_PLAN_SIM_NO_GRAPH")
 
     def timed(n=2):
         """ms per step; host_ms[0]: the host's share (time to ENQUEUE a step: if it is close to the step time, the rank is
-        launch-bound, not GPU-bound)"""
+        launch-bound, not GPU-bound).  Round 4: the same step captured into a hipGraph and replayed (what pipe.denoise()
+        does by default): graph_txt[0] = its ms per step and host enqueue."""
         with torch.no_grad():
             pipe._step(st)
             torch.cuda.synchronize()
@@ -66,17 +69,34 @@ def main():
                 pipe._step(st)
             t1 = time.perf_counter()
             torch.cuda.synchronize()
-        host_ms[0] = (t1 - t0) / n * 1e3
-        return (time.perf_counter() - t0) / n * 1e3
+            eager = (time.perf_counter() - t0) / n * 1e3
+            host_ms[0] = (t1 - t0) / n * 1e3
+            graph_txt[0] = ""
+            if want_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    pipe._step(st)
+                g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    g.replay()
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                graph_txt[0] = (f"; hipGraph replay {(time.perf_counter() - t0) / n * 1e3:.1f} ms/step "
+                                f"(host enqueue {(t1 - t0) / n * 1e3:.2f} ms)")
+                del g
+        return eager
 
     from frameino_amd import _lib
     if os.environ.get("FINO_PLAN_SIM_TILE_M"):      # A/B: 8 = 256-row GEMM tiles only (round 2), 2..7 = that height everywhere
         _lib.lib().fino_tune_set(3, int(os.environ["FINO_PLAN_SIM_TILE_M"]))
     forced_tile = bool(os.environ.get("FINO_PLAN_SIM_TILE_M"))
 
-    def set_tiling(interleaved):          # what shard_pipeline does for a real plan (unless the A/B knob above is set)
-        if not forced_tile:
-            _set_gemm_tiling(interleaved)
+    def set_tiling(interleaved):          # what ParallelPlan does for a real plan (unless the A/B knob above is set):
+        if not forced_tile and interleaved:          # a per-call tile height carried by the shards, no process state
+            for sh_ in pipe.parallel.shards:
+                sh_.gemm_tile_m = 8
 
     only = sys.argv[1] if len(sys.argv) > 1 else None     # e.g. "interleave:8" or "split-heads:4": that plan alone (profiling)
     if only:
@@ -96,9 +116,9 @@ def main():
                                             exchange_cfg=lambda mine: (mine, mine))
             set_tiling(False)
             model.parallel = FakeShard(0, ways, exchange=ex) if ways > 1 else None
-        print(f"{only}: {timed(3):.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
+        print(f"{only}: {timed(3):.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
         return
-    print(f"N=1 (batch-2 forward): {timed():.1f} ms/step (host enqueue {host_ms[0]:.1f} ms)")
+    print(f"N=1 (batch-2 forward): {timed():.1f} ms/step (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
     for ways in (1, 2, 4):          # split plans: one branch per rank, token_ways = N/2
         n_gpus = 2 * ways
         sh = FakeShard(0, ways)
@@ -106,7 +126,7 @@ def main():
                                         exchange_cfg=lambda mine: (mine, mine))
         set_tiling(False)
         model.parallel = sh if ways > 1 else None
-        print(f"split      N={n_gpus}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
+        print(f"split      N={n_gpus}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
     for ways in (2, 4, 8):          # interleaved plans: both branches per rank, token_ways = N
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways), FakeShard(0, ways)))
@@ -114,7 +134,7 @@ def main():
         for sh in pipe.parallel.shards:
             sh.fused_qkv = True                 # as ParallelPlan sets it for the interleaved plan
         model.parallel = pipe.parallel.shards[0]
-        print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
+        print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
     # the same plans with the heads exchange (all-to-all instead of the K|V all-gather; attention over H/ways heads x all tokens)
     for ways in (2, 4):
         sh = FakeShard(0, ways, exchange="heads")
@@ -122,7 +142,7 @@ def main():
                                         exchange_cfg=lambda mine: (mine, mine))
         set_tiling(False)
         model.parallel = sh
-        print(f"split-heads      N={2 * ways}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
+        print(f"split-heads      N={2 * ways}: cfg2 x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
     for ways in (2, 4, 8):
         pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
                                         shards=(FakeShard(0, ways, exchange="heads"), FakeShard(0, ways, exchange="heads")))
@@ -130,7 +150,7 @@ def main():
         for sh in pipe.parallel.shards:
             sh.head_groups = 1                  # as ParallelPlan sets it for the interleaved plan
         model.parallel = pipe.parallel.shards[0]
-        print(f"interleave-heads N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms)")
+        print(f"interleave-heads N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
 
 
 if __name__ == "__main__":
