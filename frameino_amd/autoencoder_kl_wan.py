@@ -14,6 +14,7 @@ MI355X design:
 Weights are stored under the reference's parameter names (`load_reference_state_dict`), packed once for the kernels.
 """
 import math
+import warnings
 from types import SimpleNamespace
 
 import torch
@@ -133,16 +134,27 @@ class AutoencoderKLWan(FromPretrainedMixin):
         self._io_dtype = None                  # what `.dtype` reports when fp32 was asked for (reference app.py:157)
         self._device = torch.device("cpu")
         self.use_slicing = self.use_tiling = False
+        self.tile_sample_min_height = self.tile_sample_min_width = 256            # reference :1070-1075 (recorded only)
+        self.tile_sample_stride_height = self.tile_sample_stride_width = 192
         # frames per time chunk of the decoder's tail: results do not depend on it.  0 / None: whole sequence (fastest:
         # 0.73 s and 36 GiB for 49 f 704x1280), n: chunks of n frames (8: 0.80 s, 20 GiB), "auto": whole sequence while
         # its estimated activation peak stays under `decode_memory_budget_gib`, chunks of 8 above (1024x1792, 81 f).
         self.decode_chunk_frames = "auto"
         self.decode_memory_budget_gib = 48.0
 
+    _warned_fp32 = False
+    _warned_tiling = False
+
     # ---- module-like surface ----
     @property
     def dtype(self):
         return self._io_dtype or self._dtype
+
+    @property
+    def compute_dtype(self):
+        """the dtype the convolutions run in (bf16 | fp16 MFMA operands, fp32 accumulation) -- differs from `.dtype` when
+        fp32 was asked for"""
+        return self._dtype
 
     @property
     def device(self):
@@ -157,6 +169,12 @@ class AutoencoderKLWan(FromPretrainedMixin):
         accumulation (MFMA has no fp32 path worth the name: 157 TFLOP/s against 2.5 P)."""
         if dtype == torch.float32:
             self._io_dtype, self._dtype = torch.float32, torch.bfloat16
+            if not AutoencoderKLWan._warned_fp32:
+                AutoencoderKLWan._warned_fp32 = True
+                warnings.warn("AutoencoderKLWan(torch_dtype=float32): inputs, outputs and `.dtype` are fp32 as asked "
+                              "(reference app.py:157), but the convolutions compute in bf16 with fp32 accumulation "
+                              "(`.compute_dtype`); measured against an fp32 decode at 704x1280: PSNR 50.5 dB, rel-RMS "
+                              "1.1e-2 (tests/test_fullsize_oracle_gpu.py)", RuntimeWarning, stacklevel=3)
         else:
             self._io_dtype, self._dtype = None, dtype
 
@@ -170,16 +188,40 @@ class AutoencoderKLWan(FromPretrainedMixin):
 
     def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_sample_stride_height=None,
                       tile_sample_stride_width=None):
-        """The reference's tiling (:1270-1397) cuts the frame into overlapping spatial tiles and BLENDS them: a memory
-        saver that changes the result.  With 288 GB of HBM the memory saver this mirror offers instead is result-IDENTICAL:
-        the decoder's tail runs in time chunks of 8 frames with the causal convs' two carried frames
-        (`decode_chunk_frames`, tests/test_fullsize_gpu.py: torch.equal to the whole-sequence decode, 36 -> 20 GiB at
-        49 f 704x1280).  The tile arguments are accepted and ignored."""
+        """The reference's tiling (:1270-1397) cuts the frame into overlapping spatial tiles and BLENDS them.  On the VAE
+        FrameINO's Wan path uses -- Wan2.2: `patch_size=2`, `is_residual=True`, the only configuration this mirror builds
+        -- those reference paths do not produce a result at all: `tiled_encode` feeds un-patchified 3-channel tiles to an
+        encoder whose conv_in expects 12 (:1304-1316, RuntimeError), `tiled_decode` runs the decoder without
+        `first_chunk=True`, so the residual up-blocks' shortcut and main path disagree on the frame count (:1376,
+        RuntimeError), and would skip unpatchify and clamp.  Verified by running the reference (tools/golden/
+        probe_vae_tiling.py, profiles/r04_ref_vae_tiling_probe.txt; tests/test_reference_plugin_cpu.py repeats it in the
+        build container).  There is therefore no reference output to match: this mirror returns the UN-TILED result, says
+        so once, and turns on the memory saver it does have, which is result-IDENTICAL: the decoder's tail in time chunks
+        of 8 frames with the causal convs' two carried frames (`enable_time_chunking`; tests/test_fullsize_gpu.py:
+        torch.equal to the whole-sequence decode, 36 -> 20 GiB at 49 f 704x1280).  The tile arguments are recorded."""
         self.use_tiling = True
-        self.decode_chunk_frames = 8
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_sample_stride_height = tile_sample_stride_height or self.tile_sample_stride_height
+        self.tile_sample_stride_width = tile_sample_stride_width or self.tile_sample_stride_width
+        if not AutoencoderKLWan._warned_tiling:
+            AutoencoderKLWan._warned_tiling = True
+            warnings.warn("AutoencoderKLWan.enable_tiling(): the reference's tiled_encode / tiled_decode raise on the "
+                          "Wan2.2 VAE (patch_size=2, is_residual=True), so there is no tiled reference result; this "
+                          "mirror returns the UN-TILED encode / decode and switches on its result-identical memory saver "
+                          "(time-chunked decoder tail, `enable_time_chunking`)", RuntimeWarning, stacklevel=2)
+        self.enable_time_chunking(8)
 
     def disable_tiling(self):
         self.use_tiling = False
+        self.disable_time_chunking()
+
+    def enable_time_chunking(self, frames=8):
+        """the decoder's tail (everything after the last temporal upsampling) in chunks of `frames` frames: bit-identical
+        output, activation memory of one chunk (36 -> 20 GiB at 49 f 704x1280 for +9 % time)"""
+        self.decode_chunk_frames = int(frames)
+
+    def disable_time_chunking(self):
         self.decode_chunk_frames = "auto"
 
     def to(self, device=None, dtype=None):
@@ -224,7 +266,8 @@ class AutoencoderKLWan(FromPretrainedMixin):
             else:
                 fan = math.prod(shp[1:])
                 sd[k] = torch.randn(shp, generator=g, device=self._device) * (1.0 / math.sqrt(fan))
-        self._sd, self._dtype, self._pk = sd, dtype, None
+        self._sd, self._pk = sd, None
+        self._set_dtype(dtype)
         return self
 
     # ---- packing ----

@@ -105,3 +105,38 @@ def test_cogvideox_processors_on_the_references_attention(ref_modules):
         fh, fe = attn(vid, encoder_hidden_states=txt, image_rotary_emb=(cos, sin))
         torch.testing.assert_close(fh, rh, atol=2e-5, rtol=2e-5)
         torch.testing.assert_close(fe, re, atol=2e-5, rtol=2e-5)
+
+
+def test_reference_tiling_raises_on_the_wan22_vae_and_the_mirror_says_so(ref_modules):
+    """frameino_amd/autoencoder_kl_wan.py::enable_tiling returns the un-tiled result because the REFERENCE's tiled paths
+    (architecture/autoencoder_kl_wan.py:1270-1397) produce none on the Wan2.2 VAE (patch_size=2, is_residual=True): tiled_encode
+    feeds un-patchified tiles to a 12-channel conv_in, tiled_decode drops first_chunk.  Both are shown on the reference's own
+    class here; the mirror's one-time warning is checked next to it."""
+    import importlib
+    import warnings
+    ref = importlib.import_module("architecture.autoencoder_kl_wan")
+    cfg = dict(base_dim=8, decoder_base_dim=16, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=1, attn_scales=[],
+               temperal_downsample=[False, True, True], dropout=0.0, latents_mean=[0.0] * 4, latents_std=[1.0] * 4,
+               is_residual=True, in_channels=12, out_channels=12, patch_size=2, scale_factor_temporal=4, scale_factor_spatial=16)
+    torch.manual_seed(0)
+    vae = ref.AutoencoderKLWan(**cfg).eval()
+    vae.enable_tiling(tile_sample_min_height=32, tile_sample_min_width=32, tile_sample_stride_height=24,
+                      tile_sample_stride_width=24)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="12 channels"):
+            vae.encode(torch.rand(1, 3, 5, 64, 96))
+        with pytest.raises(RuntimeError, match="must match the size"):
+            vae.decode(torch.randn(1, 4, 2, 8, 12))
+        vae.disable_tiling()                                   # ... and both work un-tiled
+        assert vae.decode(torch.randn(1, 4, 2, 4, 6), return_dict=False)[0].shape == (1, 3, 5, 64, 96)
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    AutoencoderKLWan._warned_tiling = False
+    mine = AutoencoderKLWan(**cfg)
+    with pytest.warns(RuntimeWarning, match="UN-TILED"):
+        mine.enable_tiling(tile_sample_min_height=32)
+    assert mine.use_tiling and mine.tile_sample_min_height == 32 and mine.decode_chunk_frames == 8
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                         # once per process
+        mine.enable_tiling()
+    mine.disable_tiling()
+    assert not mine.use_tiling and mine.decode_chunk_frames == "auto"
