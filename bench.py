@@ -205,8 +205,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary numbers (hipGraph replay, UniPC, config 4, config 5, attention probes)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
-    ap.add_argument("--no-graph-probe", action="store_true",
-                    help="N>1: skip the hipGraph-replay probe of the best plan")
+    ap.add_argument("--graph-probe", action="store_true",
+                    help="N>1, opt-in: after the eager measurements also replay the best plan's step from a hipGraph (only "
+                         "the split plan with the K|V all-gather is capturable on this image's runtime -- "
+                         "frameino_amd/graph_step.py; a crash inside a capture cannot be caught, so never by default)")
     ap.add_argument("--force-shard", action="store_true",
                     help="rehearsal: take the N>1 code path (process group, sharded forward, collectives) with whatever "
                          "--gpus says, 1 included: one rank drives real RCCL communicators of size 1.  With --plan "
@@ -454,7 +456,7 @@ def main():
 
         best = (elapsed, first, False)
         line = line_for(*best)
-        graph_probe = backend == "nccl" and not a.no_graph_probe      # (a gloo exchange is staged through the host)
+        graph_probe = backend == "nccl" and a.graph_probe             # (a gloo exchange is staged through the host)
         if len(names) > 1 or graph_probe:
             # The first plan's line exists; from here on a stall costs nothing: the watchdog prints that line and leaves.
             # An exception in a probe (a collective the node's RCCL refuses, an out-of-memory) is treated like a stall: the
@@ -481,7 +483,8 @@ def main():
                     if el2 < elapsed and bool(torch.isfinite(st.lat).all()):
                         best = (el2, cand, False)
                 line = line_for(*best)                                   # carries every plan's probe time
-                if graph_probe:
+                from frameino_amd.graph_step import groups_capturable
+                if graph_probe and groups_capturable(best[1], explicit=True):
                     # the best plan's step captured into a hipGraph (RCCL collectives and side streams inside the capture)
                     # and replayed: what pipe.denoise() does by default.  Probed like another plan -- a stall or an error
                     # here costs nothing, the eager line is already there

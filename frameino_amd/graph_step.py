@@ -9,11 +9,20 @@ timestep / dt / coefficient rows refreshed by device-to-device copies between st
     step 1      is captured (`torch.cuda.CUDAGraph` = hipGraph: capture enqueues nothing) and then replayed;
     step 2 ...  are replays.
 
-So capture costs one host enqueue pass, no wasted step.  The token-sharded steps capture too: RCCL collectives issued with
-`async_op=True` from the capturing stream join the capture through their events (torch's NCCL process group skips its
-watchdog for captured work), and the interleaved plan's two side streams fork from / join the capturing stream with
-`wait_stream`.  What cannot be captured is a gloo exchange staged through host memory (tests) and a user callback between
-steps -- `capturable()` says no there and the loop stays eager.
+So capture costs one host enqueue pass, no wasted step.  Token-sharded steps: what this image (torch 2.10, HIP 7.0 runtime,
+RCCL 2.26) captures was probed pattern by pattern on an MI355X (tools/debug/rccl_capture_probe.py,
+profiles/r04_rccl_capture_probe.txt, one rank):
+
+    all_gather_into_tensor issued on the CAPTURING stream (async_op or not)     captured, replayed, bit-equal
+    the same collective on a side stream forked from the capturing stream      SIGSEGV inside hipStreamEndCapture
+    all_to_all_single with async_op=True on the capturing stream               SIGSEGV inside hipStreamEndCapture
+    all_to_all_single, blocking                                                 replays; the process group then hangs in teardown
+
+A segfault cannot be caught, so the rule is static: the split plan with the K|V all-gather (collectives on the step's own
+stream) captures -- tests/test_parallel_gpu.py replays it bit-equal through a real RCCL communicator; the interleaved plan
+(two side streams, two communicators) and the heads all-to-all stay eager until the runtime is fixed.  With more than one
+rank a capture has never run on real links here: it is taken only when asked for (`use_hip_graph = True`).  A gloo exchange
+staged through host memory (tests) and a user callback between steps cannot be captured either.
 
 `mode`: None = automatic (graph when capturable; a failed capture falls back to the eager loop with a warning -- the same
 HIP kernels either way), True = required (a failed capture raises), False = eager.
@@ -23,14 +32,19 @@ import warnings
 import torch
 
 
-def groups_capturable(plan):
-    """every process group the step's exchanges use is RCCL (`nccl`): a gloo exchange is staged through the host"""
+def groups_capturable(plan, explicit=False):
+    """May the step of this parallel plan be captured?  (module docstring: the call patterns this image's runtime captures.)
+    `explicit`: the caller asked for the graph (`use_hip_graph = True`) -- needed with more than one rank."""
     if plan is None:
         return True
+    if plan.interleave or (plan.exchange == "heads" and plan.shard.active):
+        return False                       # side-stream / all-to-all captures segfault in hipStreamEndCapture
+    if plan.world > 1 and not explicit:
+        return False                       # never run on real xGMI links here: opt-in
     import torch.distributed as dist
     groups = [plan.token_group, plan.cfg_group, getattr(plan, "token_group_b", None)]
     try:
-        return all(g is None or dist.get_backend(g) == "nccl" for g in groups)
+        return all(g is None or dist.get_backend(g) == "nccl" for g in groups)      # gloo: staged through the host
     except (RuntimeError, ValueError):
         return False
 

@@ -13,8 +13,9 @@ The 50-step loop (:809-908) runs on HIP kernels only:
 
 The loop replays ONE captured step from a hipGraph (frameino_amd/graph_step.py: step 0 eager, step 1 captured, the rest
 replays; timestep and dt live in device buffers that a device-to-device copy refreshes between replays, no host sync
-inside the loop) whenever the call has no per-step callback -- single GPU and token-sharded plans alike.
-`use_hip_graph = False` keeps the eager loop, `True` makes a failed capture an error.
+inside the loop) whenever the call has no per-step callback: on one GPU always, on token shards for the call patterns this
+image's runtime captures (graph_step.py lists them).  `use_hip_graph = False` keeps the eager loop, `True` makes a loop
+that cannot be captured an error.
 """
 import html
 import re
@@ -429,7 +430,8 @@ class WanImageToVideoPipeline:
         stepper = StepGraph(lambda: self._step(st), self.use_hip_graph,
                             callback_on_step_end is None and st.lat.is_cuda
                             and (self.use_hip_graph is True or tr_default_procs(self.transformer))
-                            and groups_capturable(getattr(self, "parallel", None)), len(timesteps))
+                            and groups_capturable(getattr(self, "parallel", None), self.use_hip_graph is True),
+                            len(timesteps))
         for i in range(len(timesteps)):
             if self._interrupt:
                 continue

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Which RCCL call patterns survive hipGraph capture on this image (torch 2.10 + RCCL 2.26, one rank)?  One pattern per
+child process; faulthandler prints the Python stack of a crash.
+    python tools/debug/rccl_capture_probe.py            # all patterns
+    python tools/debug/rccl_capture_probe.py child <pattern>"""
+import faulthandler
+import os
+import subprocess
+import sys
+
+PATTERNS = ["allgather_main", "allgather_side", "allgather_two_comms_two_sides", "alltoall_main", "alltoall_side",
+            "allgather_main_sync", "alltoall_main_sync"]
+
+
+def child(pattern):
+    import socket
+    import torch
+    import torch.distributed as dist
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(40, exit=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ga, gb = dist.new_group([0]), dist.new_group([0])
+    x = torch.randn(1024, 256, device=dev)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def body():
+        main = torch.cuda.current_stream()
+        if pattern == "allgather_main":
+            w = dist.all_gather_into_tensor(y1, x, group=ga, async_op=True)
+            z = x * 2
+            w.wait()
+            return y1 + z
+        if pattern == "allgather_main_sync":
+            dist.all_gather_into_tensor(y1, x, group=ga)
+            return y1 + 1
+        if pattern == "alltoall_main":
+            w = dist.all_to_all_single(y1, x, group=ga, async_op=True)
+            z = x * 2
+            w.wait()
+            return y1 + z
+        if pattern == "alltoall_main_sync":
+            dist.all_to_all_single(y1, x, group=ga)
+            return y1 + 1
+        if pattern in ("allgather_side", "alltoall_side"):
+            s1.wait_stream(main)
+            with torch.cuda.stream(s1):
+                f = dist.all_gather_into_tensor if pattern == "allgather_side" else dist.all_to_all_single
+                w = f(y1, x, group=ga, async_op=True)
+                z = x * 2
+                w.wait()
+                r = y1 + z
+            main.wait_stream(s1)
+            return r
+        if pattern == "allgather_two_comms_two_sides":
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                w1 = dist.all_gather_into_tensor(y1, x, group=ga, async_op=True)
+            with torch.cuda.stream(s2):
+                w2 = dist.all_gather_into_tensor(y2, x, group=gb, async_op=True)
+            with torch.cuda.stream(s1):
+                w1.wait()
+                r1 = y1 * 2
+            with torch.cuda.stream(s2):
+                w2.wait()
+                r2 = y2 * 3
+            main.wait_stream(s1)
+            main.wait_stream(s2)
+            return r1 + r2
+        raise ValueError(pattern)
+
+    ref = body()
+    body()
+    torch.cuda.synchronize()
+    print(f"[{pattern}] eager ok", flush=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = body()
+    print(f"[{pattern}] captured", flush=True)
+    g.replay()
+    torch.cuda.synchronize()
+    print(f"[{pattern}] replayed equal={bool(torch.equal(out, ref))}", flush=True)
+    faulthandler.cancel_dump_traceback_later()
+    dist.destroy_process_group()
+    print(f"[{pattern}] DONE", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        child(sys.argv[2])
+        sys.exit(0)
+    for pat in PATTERNS:
+        print(f"===== {pat}", flush=True)
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "child", pat], timeout=80, capture_output=True,
+                               text=True)
+            err = "\n".join(ln for ln in p.stderr.splitlines() if "amdgpu.ids" not in ln and "socket.cpp" not in ln)
+            print(p.stdout[-800:], err[-3500:], f"rc={p.returncode}", flush=True)
+        except subprocess.TimeoutExpired as ex:
+            print("TIMEOUT", (ex.stdout or b"")[-800:], (ex.stderr or b"")[-3000:], flush=True)
