@@ -190,7 +190,8 @@ def test_cog_full_call_vs_the_reference_pipeline_run(golden):
     # (recorded next to it: the HIP video against the reference's bf16 video -- two bf16 runs of the same loop)
     mse_b = float(((vid - ref_b) ** 2).mean())
     record("cog_call[out_video vs ref bf16]", "PSNR dB hip bf16 video vs the reference's bf16 video", 
-           10 * torch.log10(torch.tensor(1.0 / max(mse_b, 1e-20))).item(), psnr_ref - 2.0, lower_is_better=False)
+           10 * torch.log10(torch.tensor(1.0 / max(mse_b, 1e-20))).item(), psnr_ref - 4.0, lower_is_better=False)
+    # (two reduced-precision runs, each ~30 dB from fp32 with independent rounding: ~3 dB further from each other)
 
 
 def test_cog_stage1_pipeline_loop_vs_oracle_loop(golden):

@@ -107,9 +107,9 @@ def test_cog5b_fp8_attention_with_peaky_softmax_full_size_vs_oracle_on_device():
     """The same config-5 forward in the regime where fp8 attention operands CAN hurt: with N(0, 0.02^2)
     weights the softmax over 19126 keys is nearly uniform (entropy ~13.5 of 14.2 bits) and per-key quantisation errors
     average out.  Trained attention is peaky: here the per-head LayerNorm gains of q and k (norm_q / norm_k, the only
-    parameters that set the logit scale behind a per-head LayerNorm) are multiplied by 1.94 each, which puts the logit
-    standard deviation near 3.8 and the softmax entropy near 4 bits (~16 effective keys) -- measured below on the oracle's
-    own logits, not assumed.  Reported: bf16 attention vs fp32 oracle, fp8 attention vs fp32 oracle, fp8 vs own bf16."""
+    parameters that set the logit scale behind a per-head LayerNorm) are multiplied by 2.3 each, which puts the softmax
+    entropy near 4 bits (~16 effective keys; 1.94 -- logit std 3.8 for independent gaussian q, k -- measured 7.0 bits) --
+    measured below on the oracle's own logits, not assumed.  Reported: bf16 attention vs fp32 oracle, fp8 attention vs fp32 oracle, fp8 vs own bf16."""
     import oracle.cog_dit as C
     from frameino_amd.configs import COGVIDEOX_5B_FRAMEINO_CFG
     from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
@@ -119,7 +119,7 @@ def test_cog5b_fp8_attention_with_peaky_softmax_full_size_vs_oracle_on_device():
     with torch.no_grad():
         for name, p_ in m.named_parameters():
             if name.endswith("norm_q.weight") or name.endswith("norm_k.weight"):
-                p_.mul_(1.94)
+                p_.mul_(2.3)
     m.reset_caches()
     sd = _oracle_sd(m)
     g = torch.Generator(device=DEV).manual_seed(24)
@@ -153,8 +153,8 @@ def test_cog5b_fp8_attention_with_peaky_softmax_full_size_vs_oracle_on_device():
     torch.cuda.synchronize()
     h_bits = sum(ent) / len(ent)
     record("cog5b_peaky_attention[softmax entropy, bits]", "oracle logits, 2 layers x 3 heads x 31 rows (uniform = 14.2)",
-           h_bits, 6.0)
-    assert 2.5 < h_bits < 6.0, ent
+           h_bits, 5.5)
+    assert 2.5 < h_bits < 5.5, ent
     r_b, r_8, r_88 = rel_rms(base, ref), rel_rms(out8, ref), rel_rms(out8, base.float())
     record("cog5b_peaky_attention[bf16 attention]", "rel_rms vs oracle fp32 on device", r_b, 2e-2)
     record("cog5b_peaky_attention[fp8 attention operands]", "rel_rms vs oracle fp32 on device", r_8, PEAKY_FP8_BOUND)
@@ -162,9 +162,10 @@ def test_cog5b_fp8_attention_with_peaky_softmax_full_size_vs_oracle_on_device():
     assert torch.isfinite(out8.float()).all() and r_b < 2e-2 and r_8 < PEAKY_FP8_BOUND and r_88 < PEAKY_FP8_BOUND, (r_b, r_8, r_88)
 
 
-# fp8 attention operands at ~4 bits of softmax entropy: the tolerance this regime needs (set from the first measurement,
-# see DESIGN.md section 2); bf16 attention stays under the 2e-2 of the flat-softmax test
-PEAKY_FP8_BOUND = 0.5
+# fp8 attention operands at ~4 bits of softmax entropy (measured 4.26): the model output moves from 7.1e-3 (bf16 attention)
+# to 1.9e-2 from the fp32 oracle -- 2.6x, where the flat-softmax test above sees no difference at all.  The bound is twice
+# the measurement; bf16 attention stays under the 2e-2 of the flat-softmax test.
+PEAKY_FP8_BOUND = 4e-2
 
 
 def _attn_rows_ref(q, k, v, bi, rows, heads):
