@@ -562,6 +562,10 @@ def main():
                       "sec_per_clip_50_steps": enc_s + 50 * ms_step / 1e3 + dec_s})
 
     if not a.no_secondary and a.workload == "wan2.2-5b-49f-704x1280" and not a.layers and not a.mxfp8 and not a.fp8_attention:
+        # (c') the power-capped step's sensitivity to OPERAND BITS: the same step on all-zero weights (a floor: nothing
+        # toggles) and on heavy-tailed weights, next to the N(0, 0.02^2) of the headline -- bounds how far the number can move
+        # on a real checkpoint
+        secondary["operand_sensitivity"] = operand_sensitivity(pipe, model, make_inputs, cfg, dev, a.workload, ms_step)
         # (d) BASELINE config 4's per-GPU-independent part: the same model at 1024x1792 (L = 25088), whole on one GPU
         secondary["config4_wan_1024x1792_L25088"] = other_workload_ms_per_step(
             pipe, make_inputs, cfg, dev, "wan2.2-5b-49f-1024x1792")
@@ -647,7 +651,8 @@ def measured_mfma_peak(dev, achieved_tflops):
         tf = fl.value / (e0.elapsed_time(e1) / 3 * 1e-3) / 1e12
         return {"power_capped_peak": tf, "frac_of_power_capped_peak": achieved_tflops / tf,
                 "power_capped_peak_source": "measured in this run: fino_diag_mfma_peak, 32x32x16 bf16, gaussian operands, "
-                                            "2 waves/SIMD, 3 launches of 4e5 MFMAs per wave"}
+                                            "2 waves/SIMD, 3 launches of 4e5 loop iterations x 16 MFMAs = 6.4e6 MFMAs per "
+                                            "wave (~0.25 s each)"}
     except Exception as ex:      # noqa: BLE001
         return {"power_capped_peak": None, "frac_of_power_capped_peak": None,
                 "power_capped_peak_source": f"not measured ({type(ex).__name__}: {ex})"}
@@ -713,6 +718,44 @@ def unipc_ms_per_step(pipe_euler, model, inputs, dev, steps=3):
             pipe._step(st)
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
+
+
+def operand_sensitivity(pipe, model, make_inputs, cfg, dev, workload, headline_ms):
+    """ms/step of the headline workload with other WEIGHT statistics (same shapes, same kernels, same FLOPs; 1 warm + 2 timed
+    steps each): under the board's power cap the clock follows how many operand bits toggle, so the step time is a function
+    of the data.  `zero_weights`: every large matrix 0 (the W operand of every block GEMM is zeros and what they feed
+    collapses to biases: a floor no checkpoint reaches).  `heavy_tailed_weights`: the N(0, 0.02^2) weights with a log-normal (sigma 1) gain per output
+    channel and 0.1 % of the elements x 16 -- outlier channels and elements as trained transformers have them.  The
+    parameters are restored afterwards (bit-exact: saved copies)."""
+    out = {"n(0,0.02^2)_headline": {"ms_per_step": headline_ms}}
+    big = [p_ for p_ in model.parameters() if p_.ndim == 2 and p_.numel() >= 1 << 20]
+    saved = [p_.detach().clone() for p_ in big]
+    g = torch.Generator(device=dev).manual_seed(99)
+
+    def run(tag):
+        model.reset_caches()
+        r = other_workload_ms_per_step(pipe, make_inputs, cfg, dev, workload)
+        out[tag] = {"ms_per_step": r["ms_per_step"], "vs_headline": r["ms_per_step"] / headline_ms}
+
+    try:
+        with torch.no_grad():
+            for p_ in big:
+                p_.zero_()
+            run("zero_weights")
+            for p_, sv in zip(big, saved):
+                gain = torch.exp(torch.randn(p_.shape[0], 1, device=dev, generator=g))
+                spike = 1.0 + 15.0 * (torch.rand(p_.shape, device=dev, generator=g) < 1e-3)
+                p_.copy_((sv.float() * gain * spike).to(p_.dtype))
+                del gain, spike
+            run("heavy_tailed_weights")
+    finally:
+        with torch.no_grad():
+            for p_, sv in zip(big, saved):
+                p_.copy_(sv)
+        del saved
+        model.reset_caches()
+        torch.cuda.empty_cache()
+    return out
 
 
 def attention_probe(ops, dev, L, heads, dh, logit_scale):
