@@ -155,3 +155,26 @@ def test_blocked_a_out_projection_equals_the_permute_copy_plus_gemm(ways, n, lpa
         flat[1].copy_(orv[:, :, dg:])
         got2 = ops.gemm_blocked_a(flat, n, w, b, x, gate, sel, out=torch.empty_like(x))
         assert torch.equal(got2, want)
+
+
+@pytest.mark.parametrize("blocks,blk_k", [(16, 192), (5, 576), (3, 1088), (7, 448)])
+def test_blocked_a_with_non_power_of_two_blocks(blocks, blk_k):
+    """ADVICE r3: the K-tile -> block index of the K-blocked A is a reciprocal multiply ((kt * ceil(65536 / a_tpb)) >> 16);
+    a_tpb = 3, 9, 17, 7 K-tiles per block (never a power of two) and odd block counts, against the permute copy + fino_gemm"""
+    from frameino_amd import ops
+    n, rows, lpad = 512, 700, 704
+    k = blocks * blk_k
+    g = torch.Generator(device=DEV).manual_seed(blocks * 7 + blk_k)
+    orv = torch.randn(blocks, lpad, blk_k, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(n, k, device=DEV, generator=g) * 0.03).bfloat16()
+    b = torch.randn(n, device=DEV, generator=g).bfloat16()
+    x = torch.randn(rows, n, device=DEV, generator=g).bfloat16()
+    gate = torch.randn(2, n, device=DEV, generator=g)
+    sel = (torch.arange(rows, device=DEV) % 2).to(torch.int32)
+    a = orv[:, :rows].permute(1, 0, 2).reshape(rows, k).contiguous()
+    want = ops.gemm(a, w, b, ops.EPI_GATED_RESIDUAL, x, gate, sel)
+    got = ops.gemm_blocked_a(orv, rows, w, b, x, gate, sel, out=torch.empty_like(x))
+    assert torch.equal(got, want)
+    for tm in (8, 3):                                         # the per-call tile height does not change a bit either
+        assert torch.equal(ops.gemm_blocked_a(orv, rows, w, b, x, gate, sel, out=torch.empty_like(x), tile_m=tm), want)
+        assert torch.equal(ops.gemm(a, w, b, ops.EPI_GATED_RESIDUAL, x, gate, sel, tile_m=tm), want)

@@ -53,6 +53,18 @@ def test_argument_validation_of_the_later_entry_points(lib):
     # UniPC step: null history buffers
     rc = lib.fino_cfg_unipc_step(16, 0, 16, 0, 16, 16, 4, 3, 4, 8, 8, 16, 0, 0)
     assert rc == -1 and b"null" in lib.fino_last_error()
+    # K-blocked A: the kernel turns a K-tile index into its block by a reciprocal multiply, exact only while
+    # kt * (a_tpb * ceil(65536 / a_tpb) - 65536) < 65536 -- a shape beyond that is refused, not computed wrongly:
+    # a_tpb = 255 (a_block_k = 16320), K = 2 blocks -> largest K-tile index 509, 509 * 254 >= 65536
+    blk = 255 * 64
+    rc = lib.fino_gemm_blocked_a(16, 16, 0, 16, 8, 256, 2 * blk, blk, 8 * blk, 1, 0, blk, 2 * blk, 256, 16, 256, 16, 0, 0, 0, 0, 0)
+    assert rc == -3 and b"exact range" in lib.fino_last_error(), lib.fino_last_error()
+    # ... a non-power-of-two block inside the range passes validation (M = 0: nothing is launched): a_tpb = 3, K = 3072
+    rc = lib.fino_gemm_blocked_a(16, 16, 0, 16, 0, 256, 3072, 192, 8 * 192, 1, 0, 192, 3072, 256, 16, 256, 16, 0, 0, 0, 0, 0)
+    assert rc == 0, lib.fino_last_error()
+    # per-call tile height: 0 (planned) or 2 .. 8
+    rc = lib.fino_gemm_split_n(16, 16, 0, 16, 8, 256, 64, 64, 64, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 9, 0)
+    assert rc == -1 and b"tile_m" in lib.fino_last_error()
     # trajectory builder: even tap count
     rc = lib.fino_traj_blur_quantize(16, 16, 16, 16, 44, 3, 8, 8, 0)
     assert rc == -1 and b"odd" in lib.fino_last_error()
