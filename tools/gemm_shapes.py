@@ -18,7 +18,12 @@ for nm, n, k, epi in SHAPES:
     b = torch.randn(n, device=dev, generator=g).bfloat16()
     res = torch.randn(M, n, device=dev, generator=g).bfloat16() if epi >= 2 else None
     gate = torch.randn(2, n, device=dev, generator=g) if epi == 3 else None
-    sel = (torch.arange(M, device=dev) % 2).to(torch.int32) if epi == 3 else None
+    # FrameINO's selector: the first-frame tokens (880 of every 12320) see timestep row 0, the rest row 1 (FINO_SEL_ALT=1: the
+    # worst case instead, a selector that changes on every row)
+    sel = None
+    if epi == 3:
+        ar = torch.arange(M, device=dev)
+        sel = ((ar % 2) if os.environ.get("FINO_SEL_ALT") else ((ar % 12320) >= 880)).to(torch.int32)
     out = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     f = lambda: ops.gemm(A, W, b, epi, res, gate, sel, out=out)
     f(); f()
