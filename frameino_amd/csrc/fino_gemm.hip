@@ -315,21 +315,10 @@ __device__ __forceinline__ int ablk_koff(const GemmParams& p, int kt) {
     return (b - j * p.a_groups) * (int)(p.a_grp_elems * 2) + j * (int)(p.a_blk_elems * 2) + (kt - b * p.a_tpb) * (BK * 2);
 }
 
-// `mode` (wave-uniform): kPpWhole = the whole tile; kPpIssueFirst = ONLY issue the prologue's LDS-DMA (K-tiles 0 and 1 into
-// the two stages) and return -- the persistent kernel calls it for the NEXT tile in front of the current tile's epilogue,
-// which stages its output above the stages: the K-tiles then land under the epilogue instead of in front of an idle matrix
-// pipe (stamps put a tile's prologue at ~10k cycles against ~2.35k per K-tile in the loop); kPpFirstIssued = the tile
-// whose prologue was issued that way: it only waits -- for the DMA, NOT for the previous tile's stores issued behind it:
-// vector-memory operations complete in issue order, so `vmcnt(16)` (the 16 row-chunk stores every wave of an interior
-// tile issues; `prev_full` says the previous tile was one) retires the K-tiles and leaves the stores in flight, and the
-// wait at the end of COMPUTE(0), which has no DMA of its own to wait for, is skipped.
-enum { kPpWhole = 0, kPpIssueFirst = 1, kPpFirstIssued = 2 };
 template <typename T, bool CONV, int MI, bool ABLK = false>
 __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, const int64_t m0, const int64_t n0,
                                             const int kb, const int nk, f32x4_t (&acc)[MI][4], const int tid,
-                                            const int lane, const int wave, const int wm, const int wn,
-                                            const int mode = kPpWhole, const bool prev_full = false,
-                                            const int64_t warm_m0 = -1) {
+                                            const int lane, const int wave, const int wm, const int wn) {
     typedef typename T::vec8 vec8;
     static_assert(MI >= 2 && MI <= 8, "tile height 64 .. 256");
     static_assert(!CONV || MI == 8, "the implicit-GEMM gather is built for 256-row tiles");
@@ -439,16 +428,19 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     const int a_base = (wm * (16 * MI) + frow) * 128;
     const int w_base = kTileBytes + (wn * 64 + frow) * 128;
 
-    // prologue: tiles 0 and 1 whole (each group its A pieces and half of W)
-    if (mode != kPpFirstIssued) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < NA0) { PP_DMA_A(0, 0, q) }
-            if (wm == 0) { PP_DMA_W(0, 0, q) } else { PP_DMA_W(0, 0, 4 + q) }
-        }
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: tiles 0 and 1 whole (each group its A pieces and half of W)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < NA0) { PP_DMA_A(0, 0, q) }
+        if (wm == 0) { PP_DMA_W(0, 0, q) } else { PP_DMA_W(0, 0, 4 + q) }
     }
     if constexpr (CONV) conv_next();
-    if (nk > 1 && mode != kPpFirstIssued) {
+    if (nk > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q < NA0) { PP_DMA_A(1, 1, q) }
@@ -456,13 +448,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         }
         if constexpr (CONV) conv_next();
     }
-    if (!CONV && mode == kPpIssueFirst) return;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (mode == kPpFirstIssued && prev_full) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // phase 0: group 1 has nothing to compute yet
 
@@ -495,18 +481,6 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
             }
             if constexpr (CONV) conv_next();
         }
-        // L2 warm-up (GemmParams::warm): the first 256 bytes (K-tiles 0 and 1) of the 256 A rows of the tile this XCD runs
-        // next, one 4-byte LDS-DMA per lane into 256 bytes of LDS nobody reads (above the stages: free during the loop).  It
-        // is the YOUNGEST vector-memory operation of this phase, so the wait below can leave it in flight.
-        const bool warm_now = !CONV && warm_m0 >= 0 && t == nk - p.warm;
-        if constexpr (!CONV) {
-            if (warm_now) {
-                int64_t gm = warm_m0 + wave * 32 + (lane >> 1);
-                gm = gm < p.m ? gm : p.m - 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (FINO_LDS void*)(smem + 2 * kStageBytes + wave * 256), 4,
-                                                         (uint32_t)((gm * p.lda + (lane & 1) * 64) * 2), 0, 0, 0);
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PSTAMP(t1)
@@ -525,10 +499,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // my pieces of tile t+1, issued one phase ago (t = 0 issued none: behind a chained prologue only the previous tile's
-        // stores would be waited for)
-        if (warm_now) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if (!(t == 0 && mode == kPpFirstIssued)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my pieces of tile t+1, issued one phase ago
         PSTAMP(t3)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -550,22 +521,23 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
 #undef PP_DMA_W
 }
 
-// one output tile: main loop + epilogue (tile = raster id before the XCD remap).  `next_tile` >= 0 (persistent launches of
-// 256-row tiles): that tile's first two K-tiles are issued in front of this tile's epilogue, which then stages its output
-// in four 64-row slices through the 32 KiB of LDS above the two operand stages; `first_issued`: this tile's own prologue was
-// issued that way by the previous call, `prev_full`: ... whose tile lay wholly inside the matrix (all its stores issued).
-// Returns whether THIS tile lies wholly inside.
-template <typename T, int EPI, bool CONV, int MI, bool ABLK>
-__device__ __forceinline__ bool gemm_pp_tile(const GemmParams& p, char* smem, const int tile, const int ntiles, const int tid,
-                                             const int next_tile = -1, const bool first_issued = false,
-                                             const bool prev_full = false) {
-    constexpr bool kChain = !CONV && MI == 8;          // tiles chained through the K-tile-0 prefetch
+// Round 4 measured two ways of taking the per-tile fixed cost (prologue ~10k cycles + epilogue 11k .. 44k against ~113k of
+// loop at K = 3072; profiles/r04_gemm_tile_stamps_*.txt) out of the critical path, and neither is here (git history has
+// both, DESIGN.md section 4.3 the numbers): PERSISTENT workgroups that chain their tiles -- the next tile's first two
+// K-tiles issued in front of the epilogue, which then runs in four slices through the 32 KiB of LDS above the operand
+// stages, the chained prologue waiting with a counted vmcnt so that the previous tile's stores stay in flight -- took 0.8 %
+// off the layer's GEMMs and nothing off the denoise step; an L2 warm-up touch of the next tile's A rows took nothing off
+// either.  What did pay is inside the epilogue (fino_gemm_common.h: order of issue).
+template <typename T, int EPI, bool CONV = false, int MI = 8, bool ABLK = false>
+__global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2;  // group
     const int wn = wave & 3;
     int tm, tn;
-    tile_raster(p, xcd_remap(tile, ntiles), tm, tn);
+    tile_coords(p, tm, tn);
     const int64_t m0 = (int64_t)tm * (32 * MI), n0 = (int64_t)tn * BN;
     f32x4_t acc[MI][4];
     int nk = (int)(p.k / BK);
@@ -578,73 +550,12 @@ __device__ __forceinline__ bool gemm_pp_tile(const GemmParams& p, char* smem, co
     unsigned long long ts0, ts1;
     STAMP(ts0)
 #endif
-    // the tile this XCD runs next: this tile's id + the CUs (dispatch order deals ids round-robin over the XCDs)
-    int64_t warm_m0 = -1;
-    if (!CONV && p.warm > 0 && nk > p.warm) {
-        const int wt = tile + (gridDim.x < 256u ? (int)gridDim.x : 256);
-        if (wt < ntiles) {
-            int tmw, tnw;
-            tile_raster(p, xcd_remap(wt, ntiles), tmw, tnw);
-            if (tmw != tm) warm_m0 = (int64_t)tmw * (32 * MI);
-        }
-    }
-    pp_mainloop<T, CONV, MI, ABLK>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn,
-                                   kChain && first_issued ? kPpFirstIssued : kPpWhole, prev_full, warm_m0);
-    const bool full = m0 + 32 * MI <= p.m && n0 + BN <= p.n;
+    pp_mainloop<T, CONV, MI, ABLK>(p, smem, m0, n0, 0, nk, acc, tid, lane, wave, wm, wn);
 #ifdef FINO_GEMM_STAMP
     STAMP(ts1)
     if (blockIdx.x == 17 && lane == 0) fino_gemm_dbg[wave * 8 + 5] = ts1 - ts0;     // prologue + loop + re-sync
 #endif
-    if constexpr (kChain) {
-        if (next_tile >= 0) {
-            // every wave is past its last operand read (pp_mainloop ends on the barrier that follows them): the stages are free
-            // (this tile's bias first: anything loaded behind the 128 KB of DMA would have to wait for it)
-            float bv[4][4];
-            gemm_load_bias<T>(p, n0, lane, wn, bv);
-            __builtin_amdgcn_sched_barrier(0);
-            int tm2, tn2;
-            tile_raster(p, xcd_remap(next_tile, ntiles), tm2, tn2);
-            f32x4_t none[MI][4];
-            pp_mainloop<T, CONV, MI, ABLK>(p, smem, (int64_t)tm2 * (32 * MI), (int64_t)tn2 * BN, 0, nk, none, tid, lane, wave,
-                                           wm, wn, kPpIssueFirst);
-            __builtin_amdgcn_sched_barrier(0);
-            gemm_epilogue_b<T, EPI, false, MI, 4, 2 * kStageBytes, true>(acc, bv, p, smem, m0, n0, tid, lane, wm, wn);
-            return full;
-        }
-    }
     gemm_epilogue<T, EPI, false, MI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
-    return full;
-}
-
-template <typename T, int EPI, bool CONV = false, int MI = 8, bool ABLK = false>
-__global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntiles = p.tiles_m * p.tiles_n;
-    if constexpr (CONV) {
-        // the implicit-GEMM conv: one tile per workgroup (its gather state is built once; a tile loop around it costs spills)
-        gemm_pp_tile<T, EPI, CONV, MI, ABLK>(p, smem, (int)blockIdx.x, ntiles, (int)threadIdx.x);
-    } else {
-        // The workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: launched with one workgroup per tile that is
-        // one tile; launched PERSISTENT (gridDim.x = the CUs) a CU keeps its workgroup for the whole GEMM and chains its
-        // tiles: the next tile's first K-tile lands under the current tile's epilogue.  Tile ids keep their XCD (gridDim.x
-        // is a multiple of 8), so the raster and every tile's arithmetic are the same either way.
-        bool first_issued = false, prev_full = false;
-        for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
-            // every thread-constant of the tile body is re-derived per tile from an opaque copy of the thread id: hoisted
-            // out of the loop (LICM) they would stay live across the whole body and push the main loop into scratch spills
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            const int nxt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : -1;
-            prev_full = gemm_pp_tile<T, EPI, CONV, MI, ABLK>(p, smem, tile, ntiles, tid, nxt, first_issued, prev_full);
-            first_issued = MI == 8 && nxt >= 0;
-            if (nxt >= 0) {
-                // the epilogue's LDS reads (every wave's) are done before the next tile's DMA overwrites the stages; its
-                // global stores are NOT waited for here
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-    }
 }
 
 template <typename T, int EPI, bool GENERIC, bool CONV = false>
@@ -656,24 +567,11 @@ int launch_gemm_t(const GemmParams& p, hipStream_t st) {
     return FINO_OK;
 }
 
-inline int gemm_device_cus();
-
 template <typename T, int EPI, bool CONV = false, int MI = 8, bool ABLK = false>
 int launch_gemm_pp(const GemmParams& p, hipStream_t st) {
     static FinoPerDeviceOnce once;
-    // the chained (persistent, 256-row) kernel stages its epilogue above the two operand stages: all 160 KiB of the CU
-    constexpr int kSmem = (!CONV && MI == 8) ? 2 * kStageBytes + 64 * BN * 2 : kSmemBytes;
-    static_assert(kSmem <= 160 * 1024 && kSmem >= kSmemBytes, "LDS budget");
-    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV, MI, ABLK>), kSmem, "fino_gemm")) return rc;
-    int grid = p.tiles_m * p.tiles_n;
-    GemmParams q = p;
-    const int knob = fino_tune_get(FINO_TUNE_GEMM_RASTER);      // A/B: bit 0 = persistent workgroups, value >> 4 = warm distance
-    if (!CONV && (knob & 1)) {
-        const int cus = gemm_device_cus() & ~7;
-        grid = grid < cus ? grid : cus;
-    }
-    q.warm = CONV ? 0 : (knob >> 4);
-    gemm_pp_kernel<T, EPI, CONV, MI, ABLK><<<dim3((unsigned)grid), kThreads, kSmem, st>>>(q);
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&gemm_pp_kernel<T, EPI, CONV, MI, ABLK>), kSmemBytes, "fino_gemm")) return rc;
+    gemm_pp_kernel<T, EPI, CONV, MI, ABLK><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), kThreads, kSmemBytes, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

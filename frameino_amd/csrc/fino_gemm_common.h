@@ -30,10 +30,6 @@ struct GemmParams {
     int64_t m, n, k, lda, ldw, ldc, ldr, mod_stride;
     int tiles_m, tiles_n;
     int group_m;                     // tile rows per raster group (tile_coords); 0 = default
-    // L2 warm-up of the NEXT tile this XCD will run (tile id + 256 in dispatch order): `warm` K-tiles before a tile's main
-    // loop ends, each wave touches -- one 4-byte LDS-DMA per lane, 64 cache lines per wave -- the first two K-tiles' worth of
-    // that tile's A rows, which are cold in every cache when its prologue asks for them (0 = off)
-    int warm;
     // column split of the output (fino_gemm_split_n): tile columns at n0 >= n_split go to c2 (leading dimension ldc2,
     // column n_split = its column 0); n_split is a multiple of BN, 0 = one output
     uint16_t* c2;
@@ -137,11 +133,11 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
 // Shared by both main-loop variants.  Every wave must be past its last LDS operand read (barrier) before the call.
 // MI = 16-row fragments per wave: the tile is 32 * MI rows high (256 by default; fino_gemm.hip picks lower tiles for row
 // counts that 256-row tiles would spread badly over the CUs)
-// The bias values of a lane's 4 x 4 output columns (fp32).  Issued FIRST in an epilogue -- and, in the chained kernel, in
-// front of the next tile's prologue DMA: vector-memory results return in issue order, so whatever is loaded AFTER a long
-// transfer (the residual tile: 128 KB per CU, ~14k cycles at the HBM rate; the prefetched K-tiles) cannot be used before all
-// of it has arrived, and the accumulator conversion needs the bias at once.  One branch per TILE (interior column block,
-// 8-byte aligned bias): four 8-byte loads back to back and one wait; the per-element path for the ragged edge.
+// The bias values of a lane's 4 x 4 output columns (fp32).  Issued FIRST in an epilogue: vector-memory results return in
+// issue order, so whatever is loaded AFTER a long transfer (the residual tile: 128 KB per CU, ~14k cycles at the HBM rate)
+// cannot be used before all of it has arrived, and the accumulator conversion needs the bias at once.  One branch per TILE
+// (interior column block, 8-byte aligned bias): four 8-byte loads back to back and one wait; the per-element path for the
+// ragged edge.
 template <typename T>
 __device__ __forceinline__ void gemm_load_bias(const GemmParams& p, int64_t n0, int lane, int wn, float (&bv)[4][4]) {
     const bool fast = p.bias && n0 + BN <= p.n && (reinterpret_cast<uintptr_t>(p.bias) & 7) == 0;      // tile-uniform
@@ -168,145 +164,121 @@ __device__ __forceinline__ void gemm_load_bias(const GemmParams& p, int64_t n0, 
     }
 }
 
-template <typename T, int EPI, bool QOUT = false, int MI = 8, int PASSES = 1, int STAGE_OFF = 0, bool SWZ = false>
-__device__ __forceinline__ void gemm_epilogue_b(f32x4_t (&acc)[MI][4], const float (&bv)[4][4], const GemmParams& p,
-                                                char* smem, int64_t m0, int64_t n0, int tid, int lane, int wm, int wn) {
+template <typename T, int EPI, bool QOUT = false, int MI = 8>
+__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmParams& p, char* smem, int64_t m0,
+                                              int64_t n0, int tid, int lane, int wm, int wn) {
     // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
     // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*16*MI + i*16 + (lane&15)
-    // PASSES > 1 (the persistent ping-pong kernel: 4): the tile goes through LDS in PASSES slices -- pass ps = fragments
-    // [ps MI/PASSES, (ps+1) MI/PASSES) of BOTH wave groups, 32 MI / PASSES rows -- staged at smem + STAGE_OFF, so that the
-    // bytes below STAGE_OFF (both operand stages) can receive the NEXT tile's first two K-tiles while this epilogue runs.
-    // SWZ: rows of exactly 512 bytes, 16-byte chunks XOR-swizzled by the row (no padding: 64 rows fill the 32 KiB that the
-    // two stages leave of a CU's 160 KiB), conflict-free for the fragment-shaped writes and the whole-row reads alike.
-    // Per output element the arithmetic is the same in every configuration.
-    static_assert(MI % PASSES == 0, "fragments must split evenly over the passes");
     constexpr bool kHasRes =
         EPI == FINO_EPI_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED;
     constexpr bool kGated = EPI == FINO_EPI_GATED_RESIDUAL || EPI == FINO_EPI_GATED_RESIDUAL_STAGED;
-    constexpr int MIP = MI / PASSES;                           // fragments per wave and pass
-    constexpr int kItersP = (32 * MIP * BN / 8) / kThreads;    // 16-byte row chunks per thread and pass (2 MIP)
-    constexpr int kIters = PASSES * kItersP;                   // ... per tile (16 at 256 rows)
-    char* const cs = smem + STAGE_OFF;
-    constexpr int kRow = SWZ ? BN * 2 : kCsStride;              // staged row pitch
-    auto cs_chunk = [](int row, int ch) { return SWZ ? (ch ^ (row & 31)) : ch; };      // physical 16-byte chunk of a row
-    // staged row (pass ps, row r of the pass's 32 MIP rows) -> tile row: group r / (16 MIP) keeps its own rows
-    auto tile_row = [](int ps, int r) { return (r / (16 * MIP)) * (16 * MI) + ps * (16 * MIP) + r % (16 * MIP); };
+    constexpr int kIters = (32 * MI * BN / 8) / kThreads;      // 2 * MI row-chunks of 16 bytes per thread (16 at 256 rows)
 #ifdef FINO_GEMM_STAMP
     unsigned long long te0, te1, te2;
     __builtin_amdgcn_sched_barrier(0); STAMP(te0) __builtin_amdgcn_sched_barrier(0);
 #endif
-    // (the bias went out before this point -- gemm_load_bias -- and the residual follows it: round-4 stamps, profiles/
-    // r04_gemm_tile_stamps_*.txt: with the residual loads in front, the conversion of a residual epilogue started 14.6k
-    // cycles after the epilogue did, against 7.5k for the bias-only one)
-    // The residual rows go out in batches: the first now (it flies under the accumulator conversion), the next once
-    // accumulators are dead (behind a pass's LDS writes): all sixteen 16-byte loads beside the 128 accumulator registers
-    // of a 256-row tile spilled into scratch (same-box A/B of the reordered epilogue, profiles/r04_gemm_epilogue_ab.txt:
-    // out-projection 475 -> 438 us, FFN-down 1724 -> 1681 us at M = 24640; the step -0.9 %).  One pass: two halves at 256
-    // rows, everything up front for lower tiles (they have the registers); two passes: a pass's rows per batch.
+    // ORDER OF ISSUE (round 4; stamps in profiles/r04_gemm_tile_stamps_{before,after}.txt).  Vector-memory results return in
+    // issue order and a __syncthreads() waits for all of them, so with the residual tile (128 KB per CU, every CU at once:
+    // ~14k cycles at the HBM rate) requested first, the accumulator conversion of a residual epilogue started 14.6k cycles
+    // after the epilogue did (7.5k for the bias-only one) and its store loop ran on scratch spills.  Now: bias first; then
+    // HALF of the residual rows (they fly under the conversion); the conversion and its LDS writes; a RAW barrier (LDS only);
+    // the other half of the residual rows, once the 128 accumulator registers are dead; the store loop.  Same-box A/B
+    // (profiles/r04_gemm_epilogue_ab.txt, M = 24640): out-projection 475 -> 438 us, FFN-down 1724 -> 1681 us, the six block
+    // GEMMs 5735 -> 5635 us, the denoise step 286.8 -> 284.3 ms; no kernel of the family spills any more.
+    float bv[4][4];
+    gemm_load_bias<T>(p, n0, lane, wn, bv);
+    __builtin_amdgcn_sched_barrier(0);
     uint4 rres[kHasRes ? kIters : 1];
     int rsel[kGated ? kIters : 1];
-    constexpr int kBatch = PASSES > 1 ? kItersP : (MI == 8 ? kIters / 2 : kIters);
-    constexpr int kBatches = kIters / kBatch;
-    constexpr int kAhead = PASSES >= 4 ? 2 : 1;               // batches in flight in front of the pass that consumes them
+    constexpr int kFirst = MI == 8 ? kIters / 2 : kIters;      // lower tiles have the registers for all of it up front
     auto load_residual = [&](int it0, int it1) {
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             if (it < it0 || it >= it1) continue;
-            const int idx = (it % kItersP) * kThreads + tid;
-            int64_t gm = m0 + tile_row(it / kItersP, idx >> 5), gn = n0 + (idx & 31) * 8;
+            const int idx = it * kThreads + tid;
+            int64_t gm = m0 + (idx >> 5), gn = n0 + (idx & 31) * 8;
             gm = gm < p.m ? gm : p.m - 1;
             gn = gn < p.n ? gn : p.n - 8;
             rres[kHasRes ? it : 0] = *reinterpret_cast<const uint4*>(p.r + gm * p.ldr + gn);
             if (kGated) rsel[kGated ? it : 0] = p.sel ? p.sel[gm] : 0;
         }
     };
-    if (kHasRes) load_residual(0, kAhead * kBatch);
+    if (kHasRes) load_residual(0, kFirst);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * (16 * MI) + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = acc[i][j][e] + bv[j][e];
+                if (EPI == FINO_EPI_GELU_TANH) y[e] = gelu_tanh_f32(round_to<T>(y[e]));
+            }
+            const uint32_t w0 = (uint32_t)T::from_f32(y[0]) | ((uint32_t)T::from_f32(y[1]) << 16);
+            const uint32_t w1 = (uint32_t)T::from_f32(y[2]) | ((uint32_t)T::from_f32(y[3]) << 16);
+            const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<uint2*>(smem + row * kCsStride + col * 2) = make_uint2(w0, w1);
+        }
+    }
+    // (a raw barrier behind the LDS writes: __syncthreads() would also wait for every residual load in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kHasRes && kFirst < kIters) load_residual(kFirst, kIters);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef FINO_GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0); STAMP(te1) __builtin_amdgcn_sched_barrier(0);
+#endif
     int gsel = -1;
     float gg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-        if (ps > 0) {      // the previous pass's LDS reads (every wave's) are done before its rows are overwritten
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int ii = 0; ii < MIP; ++ii) {
-            const int i = ps * MIP + ii;
-            const int row = wm * (16 * MIP) + ii * 16 + (lane & 15);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y[e] = acc[i][j][e] + bv[j][e];
-                    if (EPI == FINO_EPI_GELU_TANH) y[e] = gelu_tanh_f32(round_to<T>(y[e]));
+    for (int it = 0; it < kIters; ++it) {
+        const int idx = it * kThreads + tid;
+        const int row = idx >> 5;
+        const int ch = idx & 31;
+        const int64_t gm = m0 + row, gn = n0 + ch * 8;
+        if (gm >= p.m || gn >= p.n) continue;
+        uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
+        if (kHasRes) {
+            float y[8], rv[8], o[8];
+            unpack8<T>(yv, y);
+            unpack8<T>(rres[kHasRes ? it : 0], rv);
+            if (kGated) {
+                // a thread keeps one 8-column chunk for all its rows, and the gate row changes with the timestep row
+                // of the token (2 distinct rows in FrameINO): reload the 8 fp32 gates only when the selector changes
+                // (was: 2 x float4 per row -- 256 KB of L1/L2 reads per tile, more than the residual itself)
+                if (rsel[kGated ? it : 0] != gsel) {
+                    gsel = rsel[kGated ? it : 0];
+                    const float* g = p.gate + (int64_t)gsel * p.mod_stride + gn;
+                    const float4 g0 = *reinterpret_cast<const float4*>(g);
+                    const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
+                    gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w;
+                    gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
                 }
-                const uint32_t w0 = (uint32_t)T::from_f32(y[0]) | ((uint32_t)T::from_f32(y[1]) << 16);
-                const uint32_t w1 = (uint32_t)T::from_f32(y[2]) | ((uint32_t)T::from_f32(y[3]) << 16);
-                const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
-                *reinterpret_cast<uint2*>(cs + row * kRow + cs_chunk(row, col >> 3) * 16 + (col & 7) * 2) = make_uint2(w0, w1);
-            }
-        }
-        // (a raw barrier behind the LDS writes: __syncthreads() would also wait for every residual load in flight)
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kHasRes && ps + kAhead < kBatches) load_residual((ps + kAhead) * kBatch, (ps + kAhead + 1) * kBatch);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef FINO_GEMM_STAMP
-        if (ps == 0) { __builtin_amdgcn_sched_barrier(0); STAMP(te1) __builtin_amdgcn_sched_barrier(0); }
-#endif
 #pragma unroll
-        for (int itl = 0; itl < kItersP; ++itl) {
-            const int it = ps * kItersP + itl;
-            const int idx = itl * kThreads + tid;
-            const int srow = idx >> 5;
-            const int ch = idx & 31;
-            const int64_t gm = m0 + tile_row(ps, srow), gn = n0 + ch * 8;
-            if (gm >= p.m || gn >= p.n) continue;
-            uint4 yv = *reinterpret_cast<const uint4*>(cs + srow * kRow + cs_chunk(srow, ch) * 16);
-            if (kHasRes) {
-                float y[8], rv[8], o[8];
-                unpack8<T>(yv, y);
-                unpack8<T>(rres[kHasRes ? it : 0], rv);
-                if (kGated) {
-                    // a thread keeps one 8-column chunk for all its rows, and the gate row changes with the timestep row
-                    // of the token (2 distinct rows in FrameINO): reload the 8 fp32 gates only when the selector changes
-                    // (was: 2 x float4 per row -- 256 KB of L1/L2 reads per tile, more than the residual itself)
-                    if (rsel[kGated ? it : 0] != gsel) {
-                        gsel = rsel[kGated ? it : 0];
-                        const float* g = p.gate + (int64_t)gsel * p.mod_stride + gn;
-                        const float4 g0 = *reinterpret_cast<const float4*>(g);
-                        const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
-                        gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w;
-                        gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        o[e] = rv[e] + (EPI == FINO_EPI_GATED_RESIDUAL_STAGED ? round_to<T>(y[e] * gg[e]) : y[e] * gg[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
-                }
-                yv = pack8<T>(o);
-            }
-            if constexpr (QOUT) {
-                // the T-rounded result quantised in place of a separate pass: same bytes as fino_quantize_mxfp8 on C
-                float y[8];
-                unpack8<T>(yv, y);
-                int e;
-                const uint2 qv = mx_quant8(y, e);
-                *reinterpret_cast<uint2*>(p.cq + gm * p.n + gn) = qv;
-                if ((ch & 3) == 0) p.cs[mx_scale_index(gm, gn, p.cs_rows_pad)] = (uint8_t)(e + 127);
-            } else if (p.n_split > 0 && n0 >= p.n_split) {
-                *reinterpret_cast<uint4*>(p.c2 + gm * p.ldc2 + (gn - p.n_split)) = yv;
+                for (int e = 0; e < 8; ++e)
+                    o[e] = rv[e] + (EPI == FINO_EPI_GATED_RESIDUAL_STAGED ? round_to<T>(y[e] * gg[e]) : y[e] * gg[e]);
             } else {
-                *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rv[e] + y[e];
             }
+            yv = pack8<T>(o);
+        }
+        if constexpr (QOUT) {
+            // the T-rounded result quantised in place of a separate pass: same bytes as fino_quantize_mxfp8 on C
+            float y[8];
+            unpack8<T>(yv, y);
+            int e;
+            const uint2 qv = mx_quant8(y, e);
+            *reinterpret_cast<uint2*>(p.cq + gm * p.n + gn) = qv;
+            if ((ch & 3) == 0) p.cs[mx_scale_index(gm, gn, p.cs_rows_pad)] = (uint8_t)(e + 127);
+        } else if (p.n_split > 0 && n0 >= p.n_split) {
+            *reinterpret_cast<uint4*>(p.c2 + gm * p.ldc2 + (gn - p.n_split)) = yv;
+        } else {
+            *reinterpret_cast<uint4*>(p.c + gm * p.ldc + gn) = yv;
         }
     }
 #ifdef FINO_GEMM_STAMP
@@ -316,15 +288,6 @@ __device__ __forceinline__ void gemm_epilogue_b(f32x4_t (&acc)[MI][4], const flo
         fino_gemm_dbg[(tid >> 6) * 8 + 7] = te2 - te1;
     }
 #endif
-}
-
-template <typename T, int EPI, bool QOUT = false, int MI = 8, int PASSES = 1, int STAGE_OFF = 0, bool SWZ = false>
-__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmParams& p, char* smem, int64_t m0,
-                                              int64_t n0, int tid, int lane, int wm, int wn) {
-    float bv[4][4];
-    gemm_load_bias<T>(p, n0, lane, wn, bv);
-    __builtin_amdgcn_sched_barrier(0);
-    gemm_epilogue_b<T, EPI, QOUT, MI, PASSES, STAGE_OFF, SWZ>(acc, bv, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
 }  // namespace fino_gemm_ns

@@ -11,10 +11,7 @@ a = torch.randn(L, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="
 res = torch.randn(L, N, device="cuda").bfloat16() if EPI >= 2 else None
 gate = torch.randn(2, N, device="cuda") if EPI >= 3 else None
 sel = (torch.arange(L, device="cuda") >= 880).to(torch.int32) if EPI >= 3 else None
-if os.environ.get("FINO_STAMP_PERSIST"):
-    from frameino_amd import _lib
-    _lib.lib().fino_tune_set(1, 1)          # persistent workgroups (chained tiles): the stamps are those of workgroup 17's LAST tile
-print(f"L={L} N={N} K={K} epilogue={EPI} persistent={bool(os.environ.get('FINO_STAMP_PERSIST'))}")
+print(f"L={L} N={N} K={K} epilogue={EPI}")
 for _ in range(3): ops.gemm(a, w, b, EPI, res, gate, sel)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()

@@ -44,16 +44,13 @@ if "--tiles" in sys.argv:      # round 3: GEMM tile heights (FINO_TUNE_GEMM_TILE
 if "--cross" in sys.argv:      # round 3: text cross-attention on the 8-wave ping-pong kernel (tune 1) vs the free-running one (default policy)
     settings = {"cross-attention: 8-wave ping-pong kernel": (0, True, 1, False, 0),
                 "cross-attention: free-running kernel (default)": (0, True, 0, False, 0)}
-if "--gemm-launch" in sys.argv:      # round 4: one workgroup per tile vs persistent chained tiles (FINO_TUNE_GEMM_RASTER bit 0)
-    settings = {"GEMM: one workgroup per tile": (0, True, 1, False, 0, 0), "GEMM: persistent workgroups, chained tiles": (0, True, 1, False, 0, 1)}
 res = {k: [] for k in settings}
 
 
 attn = {}
 
 
-def run(gm, dedup, attn_k, fold, steps, tile_m=0, raster=0):
-    lib.fino_tune_set(1, raster)
+def run(gm, dedup, attn_k, fold, steps, tile_m=0):
     lib.fino_tune_set(3, tile_m)
     lib.fino_tune_set(0, gm)
     lib.fino_tune_set(4, attn_k)
@@ -65,7 +62,7 @@ def run(gm, dedup, attn_k, fold, steps, tile_m=0, raster=0):
             pipe._step(st)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    attn.setdefault((gm, dedup, attn_k, fold, tile_m, raster)[:len(next(iter(settings.values())))], []).append(kt.summary()["attn_self"]["total_ms"] / steps)
+    attn.setdefault((gm, dedup, attn_k, fold, tile_m)[:len(next(iter(settings.values())))], []).append(kt.summary()["attn_self"]["total_ms"] / steps)
     return ms
 
 
@@ -77,7 +74,6 @@ for rnd in range(5):
 lib.fino_tune_set(0, 0)
 lib.fino_tune_set(4, 0)
 lib.fino_tune_set(3, 0)
-lib.fino_tune_set(1, 0)
 for k, v in res.items():
     a_ms = statistics.median(attn[settings[k]][1:])
     print(f"    self-attention launches {a_ms:7.2f} ms/step, everything else {statistics.median(v) - a_ms:7.2f}")
