@@ -1,4 +1,5 @@
 """Host-side pieces of the product path that need no GPU: tables and caches."""
+import pytest
 import torch
 
 from frameino_amd.transformer_wan import WanTransformer3DModel, wan_rope_tables
@@ -119,3 +120,30 @@ def test_bench_watchdog_prints_the_measured_line_and_exits_zero_on_a_stall():
             "d.arm('timed run', 0.5); time.sleep(30)" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and r.stdout.strip() == ""
+
+
+def test_step_graph_policy_and_schedule():
+    """frameino_amd/graph_step.py: which loops are captured (the static rule behind the RCCL capture probes) and the
+    schedule -- step 0 eager, step 1 captured, the rest replays -- with the capture machinery replaced by a counter."""
+    from types import SimpleNamespace
+    from frameino_amd import graph_step as G
+    assert G.groups_capturable(None)
+    shard = SimpleNamespace(active=True)
+    plan = lambda **kw: SimpleNamespace(**{**dict(interleave=False, exchange="kv", shard=shard, world=1, token_group=None,
+                                                  cfg_group=None, token_group_b=None), **kw})      # noqa: E731
+    assert G.groups_capturable(plan())                                    # split plan, K|V all-gather, one rank
+    assert not G.groups_capturable(plan(interleave=True))                 # side streams: segfault in hipStreamEndCapture
+    assert not G.groups_capturable(plan(exchange="heads"))                # all_to_all_single: the same
+    assert not G.groups_capturable(plan(world=4))                         # real links: only on request
+    assert G.groups_capturable(plan(world=4), explicit=True)
+    assert not G.groups_capturable(plan(world=4, interleave=True), explicit=True)
+    # schedule: eager when not capturable / fewer than three steps / mode False; an impossible explicit request raises
+    calls = []
+    sg = G.StepGraph(lambda: calls.append("s"), None, False, 10)
+    for _ in range(4):
+        sg.step()
+    assert calls == ["s"] * 4 and sg.graph is None
+    assert not G.StepGraph(lambda: None, None, True, 2).enabled and G.StepGraph(lambda: None, None, True, 3).enabled
+    assert not G.StepGraph(lambda: None, False, True, 50).enabled
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        G.StepGraph(lambda: None, True, False, 50)
