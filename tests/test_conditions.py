@@ -172,3 +172,46 @@ def test_bicubic_resize_of_the_trajectory_canvas_hand_computed():
     np.testing.assert_allclose(out.numpy(), np.array(exp), rtol=0, atol=1e-3)
     assert out.max() > 255.0                                    # cubic overshoot next to the step: not clamped here,
     # the uint8 truncation at the end of prepare_traj_tensor (:172) happens after the blur
+
+
+def test_blur_and_area_resampling_against_independent_library_implementations():
+    """OpenCV is absent offline, so `cv2.filter2D(BORDER_REFLECT_101)` and `cv2.resize(INTER_AREA)` are restated from their
+    documented semantics (oracle/conditions.py: parity with OpenCV itself stays unpinned).  Two INDEPENDENT implementations
+    of the same documented operations are installed, though: scipy.ndimage.correlate with mode="mirror" (reflection without
+    repeating the edge sample = REFLECT_101) and PIL's BOX filter (pixel-area average).  The restatement must agree with
+    them -- which rules out a private misreading of the border rule, the kernel orientation or the area weights."""
+    import PIL.Image
+    from scipy import ndimage
+    from oracle import conditions as C
+    rng = np.random.default_rng(3)
+    # (a) the 45-tap Gaussian blur of the trajectory canvas, before the uint8 truncation
+    k = C.bivariate_gaussian()
+    img = rng.uniform(0, 255, (37, 53)).astype(np.float64)
+    half = k.shape[0] // 2
+    rows = np.array([[C._reflect101(y + d - half, img.shape[0]) for d in range(k.shape[0])] for y in range(img.shape[0])])
+    cols = np.array([[C._reflect101(x + d - half, img.shape[1]) for d in range(k.shape[1])] for x in range(img.shape[1])])
+    mine = np.zeros_like(img)
+    for dy in range(k.shape[0]):
+        for dx in range(k.shape[1]):
+            mine += k[dy, dx] * img[rows[:, dy]][:, cols[:, dx]]
+    ref = ndimage.correlate(img, k, mode="mirror")
+    assert np.abs(mine - ref).max() < 1e-9
+    # an asymmetric kernel tells correlation (filter2D) from convolution and x from y
+    ka = rng.uniform(0, 1, (5, 7))
+    ka /= ka.sum()
+    r5 = np.array([[C._reflect101(y + d - 2, 37) for d in range(5)] for y in range(37)])
+    c7 = np.array([[C._reflect101(x + d - 3, 53) for d in range(7)] for x in range(53)])
+    mine = sum(ka[dy, dx] * img[r5[:, dy]][:, c7[:, dx]] for dy in range(5) for dx in range(7))
+    assert np.abs(mine - ndimage.correlate(img, ka, mode="mirror")).max() < 1e-9
+    # (b) pixel-area resampling at integer shrink factors against PIL's BOX filter run on FLOAT planes (its uint8 path rounds
+    # between its horizontal and vertical passes): the restatement's uint8 result must be a correct rounding of the
+    # independent float result everywhere.  (At non-integer factors PIL's BOX weighs a source pixel 0 or 1 by its CENTRE,
+    # not by the overlapped area, so it is no reference there: those cases stay hand-computed, above.)
+    src = rng.integers(0, 256, (96, 120, 3), dtype=np.uint8)
+    for oh, ow in ((48, 60), (32, 40), (24, 30), (48, 40)):
+        mine = C.resize_area(src, oh, ow).astype(np.float64)
+        for ch in range(3):
+            plane = PIL.Image.fromarray(src[:, :, ch].astype(np.float32), mode="F")
+            box = np.asarray(plane.resize((ow, oh), resample=PIL.Image.BOX)).astype(np.float64)
+            d = np.abs(mine[:, :, ch] - box)
+            assert d.max() <= 0.5 + 2e-3, (oh, ow, ch, d.max())
