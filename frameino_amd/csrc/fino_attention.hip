@@ -751,6 +751,425 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
   }   // piece
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// PING-PONG kernel with LDS-DMA staging (round 4; head_dim 128): the softmax / matrix phase structure of attn_pp_kernel, but
+// K / V tiles travel global -> LDS by `buffer_load ... lds` into rings of FOUR slots each (128 KiB of the CU's 160), issued
+// three (K) / two (V) tiles ahead of their first use by group 0 and four / three by group 1.  What that removes from the
+// softmax phase, which the stamps put at the per-wave issue limit (tools/attn_stamp.py: staging 350 of its 1480 cycles): the
+// four ds_write_b128, the vmcnt wait in front of them (a register-staged tile has one tile of compute to arrive, a DMA'd one
+// two), and 16 staging registers.  A slot is re-filled only after BOTH groups have passed the matrix phase that read it:
+//   K(j) is last read by group 1's matrix(j-1) (global phase 2j), V(j) by its matrix(j) (phase 2j+2); group g issues, in its
+//   softmax(t) (phase 2t+g), K(t+g+3) into the slot of K(t+g-1) and V(t+g+2) into the slot of V(t+g-2): both dead by then;
+//   every wave ends a softmax phase with vmcnt(8) -- all but its last two phases' DMAs have landed -- and the barrier
+//   publishes them one full tile before their first reader.
+// Every LDS read of the loop is inline asm with hand-counted lgkmcnt waits (the compiler would put vmcnt(0) in front of any
+// LDS read it can see while a DMA is in flight, see attn_fr_kernel).  Block map, tail split, partial layout and arithmetic
+// are attn_pp_kernel's: results are bit-identical (tests/test_kernels_gpu.py).
+constexpr int kPdSlots = 4;
+
+// A/B knobs of attn_ppd_kernel (make variant VFLAGS=-DPD_...=x; results are the same bits for every setting):
+#ifndef PD_PREK
+#define PD_PREK 1          /* 1: the first two k-steps' K fragments are fetched BEFORE the barrier that opens the matrix phase */
+#endif
+#ifndef PD_PRIO
+#define PD_PRIO 1          /* 0: s_setprio 1 around every matrix phase; 1: static priority for waves 4-7, no flips; 2: none */
+#endif
+#ifndef PD_MAX_SOFTMAX
+#define PD_MAX_SOFTMAX 1   /* 1: the row maxima of S(t) open softmax(t) instead of riding in the P.V shadow of matrix(t-1) */
+#endif
+template <typename T, int VAR>
+__global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = 128;
+    constexpr int kTileBytes = kKV * D * 2;                  // 16 KiB
+    constexpr int kKS = D / 16;
+    constexpr int kDT = D / 32;
+    constexpr int kVBase = kPdSlots * kTileBytes;            // V ring behind the K ring
+    constexpr uint32_t kRingMask = kPdSlots * kTileBytes - 1;
+    typedef typename T::vec8 vec8;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int ntall = (p.lk + kKV - 1) / kKV;
+    int npieces = 1, first_b = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (slot >= p.full_x) {
+        g0 = (int64_t)(slot - p.full_x) * p.per;
+        g1 = g0 + p.per < (int64_t)p.rem_x * ntall ? g0 + p.per : (int64_t)p.rem_x * ntall;
+        first_b = (int)(g0 / ntall);
+        npieces = (int)((g1 - 1) / ntall) - first_b + 1;
+    }
+  for (int piece = 0; piece < npieces; ++piece) {
+    if (piece > 0) __syncthreads();                 // every wave is done with the previous piece's LDS tiles (its DMAs have landed: loop end)
+    int bx = slot, part = -1, t_begin = 0, t_end = ntall;
+    if (slot >= p.full_x) {
+        const int tb = first_b + piece;
+        const int64_t b0 = (int64_t)tb * ntall;
+        t_begin = g0 > b0 ? (int)(g0 - b0) : 0;
+        t_end = g1 - b0 < ntall ? (int)(g1 - b0) : ntall;
+        bx = p.full_x + tb;
+        if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
+    }
+    int hb, qb;
+    if (!attn_map_block(p, xcd, bx, hb, qb)) continue;
+    if (p.all_partial) part = hb * p.nqb + qb;
+    const int bi = hb / p.heads;
+    const int head = hb - bi * p.heads;
+
+    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
+    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs + (int64_t)t_begin * kKV * p.k_rs;
+    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs + (int64_t)t_begin * kKV * p.v_rs;
+    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
+    const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;
+    const int nt = (lk + kKV - 1) / kKV;
+
+    // ---- K / V staging by LDS-DMA: a tile is 16 pieces of 1 KiB (4 rows); wave w moves pieces w and w + 8 of K and of V.
+    //      The lane's row inside the piece, its chunk position and the swizzle (row bits a step of 8 pieces leaves alone) are
+    //      fixed: ONE per-lane offset per operand, the piece and tile advance ride in the scalar offset; rows past the last
+    //      key fail the resource's range check and the DMA writes zeros (masked in the ragged last tile) ----
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = wv >> 2;
+    const int rip = lane >> 4, pos = lane & 15;
+    const int srow = wv * 4 + rip;
+    const int swz = (lds_off<D>(srow, 0) >> 4) & 15;
+    const uint32_t k_voff = (uint32_t)((srow * p.k_rs + ((pos ^ swz) << 3)) * 2);
+    const uint32_t v_voff = (uint32_t)((srow * p.v_rs + ((pos ^ swz) << 3)) * 2);
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)kp, 0, (int)((((int64_t)lk - 1) * p.k_rs + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)vp, 0, (int)((((int64_t)lk - 1) * p.v_rs + D) * 2), 0x00020000);
+    const int k_piece_bytes = (int)(32 * p.k_rs * 2), v_piece_bytes = (int)(32 * p.v_rs * 2);
+    const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
+    // tile index clamped to nt: tile nt lies wholly past the last key (zeros), and the scalar offset stays inside 32 bits
+#define PD_DMA_K(TILE_)                                                                                      \
+    {                                                                                                        \
+        const int tl_ = (TILE_) < nt ? (TILE_) : nt;                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+                k_rsrc, (FINO_LDS void*)(smem + ((TILE_) & (kPdSlots - 1)) * kTileBytes + (8 * i_ + wv) * 1024), 16, \
+                k_voff, tl_ * k_tile_bytes + i_ * k_piece_bytes, 0, 0);                                      \
+    }
+#define PD_DMA_V(TILE_)                                                                                      \
+    {                                                                                                        \
+        const int tl_ = (TILE_) < nt ? (TILE_) : nt;                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+                v_rsrc, (FINO_LDS void*)(smem + kVBase + ((TILE_) & (kPdSlots - 1)) * kTileBytes + (8 * i_ + wv) * 1024), \
+                16, v_voff, tl_ * v_tile_bytes + i_ * v_piece_bytes, 0, 0);                                  \
+    }
+    // prologue: what the loop's schedule assumes was issued before it starts -- K(0..2), V(0..1) by everyone, and group 1
+    // (whose softmax(0) issues K(4) / V(3)) also K(3) / V(2)
+    PD_DMA_K(0) PD_DMA_V(0) PD_DMA_K(1) PD_DMA_V(1) PD_DMA_K(2)
+    if (grp == 1) { PD_DMA_K(3) PD_DMA_V(2) }
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
+    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+    vec8 qf[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+        uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
+        if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);      // rows past Lq are never stored: zero operands draw the least power
+        qf[ks] = __builtin_bit_cast(vec8, u);
+    }
+
+    const int tq = (lane & 15) >> 2;
+    const int tp = lane & 3;
+    const int g1l = (lane >> 4) & 1;
+    f32x16_t o[kDT];
+#pragma unroll
+    for (int i = 0; i < kDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+    const float c2 = p.scale_log2;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // S(0) from K ring slot 0 (plain LDS reads: nothing is in flight here)
+    f32x16_t sc0, sc1;
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sc0[j] = 0.f; sc1[j] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(smem + lds_off<D>(r, 2 * ks + h));
+            const uint4 a1 = *reinterpret_cast<const uint4*>(smem + lds_off<D>(32 + r, 2 * ks + h));
+            sc0 = T::mfma32(__builtin_bit_cast(vec8, a0), qf[ks], sc0);
+            sc1 = T::mfma32(__builtin_bit_cast(vec8, a1), qf[ks], sc1);
+        }
+    }
+#define MASK_RAGGED(T_)                                                                                     \
+    if ((T_) == nt - 1 && (lk & (kKV - 1))) {            /* key = (j&3) + 8*(j>>2) + 4*h (+32) */           \
+        const int kbase_ = (T_) * kKV + 4 * h;                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                 \
+            const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);                                             \
+            if (key_ >= lk) sc0[j_] = -INFINITY;                                                            \
+            if (key_ + 32 >= lk) sc1[j_] = -INFINITY;                                                       \
+        }                                                                                                   \
+    }
+#define MAX8(S_, O_) vmax2(vmax3(vmax3(S_[O_], S_[O_ + 1], S_[O_ + 2]), vmax3(S_[O_ + 3], S_[O_ + 4], S_[O_ + 5]), \
+                                 S_[O_ + 6]), S_[O_ + 7])
+#define MAX_FINISH1(MX_, OUT_)                                                                              \
+    {                                                                                                       \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(MX_), __float_as_uint(MX_), false, false); \
+        OUT_ = vmax2(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                     \
+    }
+    float mx_next = 0.f;
+#if !PD_MAX_SOFTMAX
+    {
+        MASK_RAGGED(0)
+        const float m0 = vmax2(vmax3(MAX8(sc0, 0), MAX8(sc0, 8), MAX8(sc1, 0)), MAX8(sc1, 8));
+        MAX_FINISH1(m0, mx_next)
+    }
+#endif
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
+#if PD_PRIO == 1
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every age arbitration otherwise
+#endif
+
+    // LDS fragment addresses of the matrix phase: k-step / d-tile flip address bits (one v_xor next to the read), the
+    // +32 / +16-row operands are instruction offsets, the ring slot (K: (t+1) & 3, V: t & 3) advances once per tile.
+    if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
+    uint32_t ka0 = 1 * kTileBytes + lds_off<D>(r, h);
+    uint32_t vl0 = kVBase + lds_off<D>(4 * h + tq, 2 * g1l + (tp >> 1)) + 8 * (tp & 1);
+    uint32_t vh0 = kVBase + lds_off<D>(4 * h + tq + 8, 2 * g1l + (tp >> 1)) + 8 * (tp & 1);
+
+    u32x4_t ka[3][2];
+    s16x4_t vlo[2][kDT], vhi[2][kDT];
+#define PD_KISSUE(KS_, B_)                                                                                   \
+    {                                                                                                        \
+        const uint32_t a_ = ka0 ^ ((KS_) << 5);                                                              \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"                                  \
+                     : "=&v"(ka[B_][0]), "=&v"(ka[B_][1]) : "v"(a_), "n"(32 * D * 2));                       \
+    }
+#define PD_KWAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(ka[B_][0]), "+v"(ka[B_][1]));
+#define PD_VISSUE(STEP_, B_)                                                                                 \
+    {                                                                                                        \
+        const uint32_t l1_ = vl0 ^ 64u, l2_ = vl0 ^ 128u, l3_ = vl0 ^ 192u;                                  \
+        const uint32_t h1_ = vh0 ^ 64u, h2_ = vh0 ^ 128u, h3_ = vh0 ^ 192u;                                  \
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%16\n\tds_read_b64_tr_b16 %1, %9 offset:%16\n\t"      \
+                     "ds_read_b64_tr_b16 %2, %10 offset:%16\n\tds_read_b64_tr_b16 %3, %11 offset:%16\n\t"    \
+                     "ds_read_b64_tr_b16 %4, %12 offset:%16\n\tds_read_b64_tr_b16 %5, %13 offset:%16\n\t"    \
+                     "ds_read_b64_tr_b16 %6, %14 offset:%16\n\tds_read_b64_tr_b16 %7, %15 offset:%16"        \
+                     : "=&v"(vlo[B_][0]), "=&v"(vhi[B_][0]), "=&v"(vlo[B_][1]), "=&v"(vhi[B_][1]),           \
+                       "=&v"(vlo[B_][2]), "=&v"(vhi[B_][2]), "=&v"(vlo[B_][3]), "=&v"(vhi[B_][3])            \
+                     : "v"(vl0), "v"(vh0), "v"(l1_), "v"(h1_), "v"(l2_), "v"(h2_), "v"(l3_), "v"(h3_),       \
+                       "n"((STEP_) * 16 * D * 2));                                                           \
+    }
+#define PD_VWAIT(N_, B_)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N_ ")"                                                                \
+                 : "+v"(vlo[B_][0]), "+v"(vhi[B_][0]), "+v"(vlo[B_][1]), "+v"(vhi[B_][1]), "+v"(vlo[B_][2]), \
+                   "+v"(vhi[B_][2]), "+v"(vlo[B_][3]), "+v"(vhi[B_][3]));
+#define PD_QK(KS_, B_, FIRST_)                                                                               \
+    sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][0]), qf[KS_], (FIRST_) ? zero16 : sc0);                  \
+    sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][1]), qf[KS_], (FIRST_) ? zero16 : sc1);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#if PD_MAX_SOFTMAX
+#define PD_SHADOW_MAX(MAXEXPR_)
+#else
+#define PD_SHADOW_MAX(MAXEXPR_) mxa = vmax2(mxa, MAXEXPR_);
+#endif
+#define PD_PV(STEP_, B_, MAXEXPR_)                                                                           \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < kDT; ++dt_) {                                                  \
+        const s16x8_t va_ = __builtin_shufflevector(vlo[B_][dt_], vhi[B_][dt_], 0, 1, 2, 3, 4, 5, 6, 7);     \
+        o[dt_] = T::mfma32(__builtin_bit_cast(vec8, va_), pb[STEP_], o[dt_]);                                \
+    }                                                                                                        \
+    PD_SHADOW_MAX(MAXEXPR_)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+
+#ifdef FINO_ATTN_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsm = 0, tse = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sa5 = 0, sa6 = 0;
+#endif
+    for (int t = 0; t < nt; ++t) {
+        ASTAMP(ts0)
+        // ================= softmax phase =================
+        const int w = t + grp;
+        PD_DMA_K(w + 3)
+        PD_DMA_V(w + 2)
+#if PD_MAX_SOFTMAX
+        {
+            MASK_RAGGED(t)
+            const float m0 = vmax2(vmax3(MAX8(sc0, 0), MAX8(sc0, 8), MAX8(sc1, 0)), MAX8(sc1, 8));
+            MAX_FINISH1(m0, mx_next)
+        }
+#endif
+        {
+            const float m_cand = fmaxf(m_run, mx_next * c2);
+            if (__any((m_cand - m_run) > rescale_thr<T>())) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+                m_run = m_cand;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < kDT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);
+            sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);
+        }
+        {
+            float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                psum0 += sc0[j];
+                psum1 += sc1[j];
+            }
+            l_run += psum0 + psum1;
+        }
+        vec8 pb[4];                                  // P(t) packed: pb[2*kt + s2]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pb[0][j] = (typename T::scalar)sc0[j];
+            pb[1][j] = (typename T::scalar)sc0[8 + j];
+            pb[2][j] = (typename T::scalar)sc1[j];
+            pb[3][j] = (typename T::scalar)sc1[8 + j];
+        }
+        {
+            u32x4_t p0 = __builtin_bit_cast(u32x4_t, pb[0]), p1 = __builtin_bit_cast(u32x4_t, pb[1]);
+            u32x4_t p2 = __builtin_bit_cast(u32x4_t, pb[2]), p3 = __builtin_bit_cast(u32x4_t, pb[3]);
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(l_run));
+            pb[0] = __builtin_bit_cast(vec8, p0); pb[1] = __builtin_bit_cast(vec8, p1);
+            pb[2] = __builtin_bit_cast(vec8, p2); pb[3] = __builtin_bit_cast(vec8, p3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ASTAMP(tse)
+#if PD_PREK
+        // K(t+1) was published a phase ago (vmcnt(4) below): the first two k-steps' fragments travel across the barrier
+        if (t + 1 < nt) {
+            PD_KISSUE(0, 0)
+            PD_KISSUE(1, 1)
+        }
+        // all DMAs this wave issued before this phase (4 per phase) have landed
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
+        // all but this wave's last two phases' DMAs (4 per phase) have landed: its pieces of K(t+1) and V(t), at the latest
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+        ASTAMP(ts1)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ASTAMP(ts2)
+        // ================= matrix phase =================
+#if PD_PRIO == 0
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < nt) {
+#if !PD_PREK
+            PD_KISSUE(0, 0)
+            PD_KISSUE(1, 1)
+#endif
+            PD_KISSUE(2, 2) PD_KWAIT(4, 0) PD_QK(0, 0, true)
+            PD_KISSUE(3, 0) PD_KWAIT(4, 1) PD_QK(1, 1, false)
+            PD_KISSUE(4, 1) PD_KWAIT(4, 2) PD_QK(2, 2, false)
+            PD_KISSUE(5, 2) PD_KWAIT(4, 0) PD_QK(3, 0, false)
+            PD_KISSUE(6, 0) PD_KWAIT(4, 1) PD_QK(4, 1, false)
+            PD_KISSUE(7, 1) PD_KWAIT(4, 2) PD_QK(5, 2, false)
+            PD_VISSUE(0, 0) PD_KWAIT(10, 0) PD_QK(6, 0, false)
+            PD_KWAIT(8, 1) PD_QK(7, 1, false)
+        } else {
+            PD_VISSUE(0, 0)
+        }
+        ASTAMP(tsm)
+#if !PD_MAX_SOFTMAX
+        MASK_RAGGED(t + 1)
+        float mxa = -INFINITY;
+#endif
+        PD_VISSUE(1, 1) PD_VWAIT(8, 0) PD_PV(0, 0, MAX8(sc0, 0))
+        PD_VISSUE(2, 0) PD_VWAIT(8, 1) PD_PV(1, 1, MAX8(sc0, 8))
+        PD_VISSUE(3, 1) PD_VWAIT(8, 0) PD_PV(2, 0, MAX8(sc1, 0))
+        PD_VWAIT(0, 1) PD_PV(3, 1, MAX8(sc1, 8))
+#if !PD_MAX_SOFTMAX
+        MAX_FINISH1(mxa, mx_next)
+#endif
+        ka0 = (ka0 + kTileBytes) & kRingMask;
+        vl0 = ((vl0 + kTileBytes) & kRingMask) | kVBase;
+        vh0 = ((vh0 + kTileBytes) & kRingMask) | kVBase;
+#if PD_PRIO == 0
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        ASTAMP(ts3)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef FINO_ATTN_STAMP
+        ASTAMP(ts4)
+        sa0 += ts1 - ts0; sa1 += ts2 - ts1; sa2 += ts3 - ts2; sa3 += ts4 - ts3; sa5 += tsm - ts2; sa6 += tse - ts0;
+#endif
+    }
+#ifdef FINO_ATTN_STAMP
+    if (blockIdx.x == 40 && lane == 0 && VAR == 0) {
+        fino_attn_dbg[wave * 8 + 0] = sa0; fino_attn_dbg[wave * 8 + 1] = sa1; fino_attn_dbg[wave * 8 + 2] = sa2;
+        fino_attn_dbg[wave * 8 + 3] = sa3; fino_attn_dbg[wave * 8 + 4] = (unsigned long long)nt;
+        fino_attn_dbg[wave * 8 + 5] = sa5; fino_attn_dbg[wave * 8 + 6] = sa6; fino_attn_dbg[wave * 8 + 7] = 0;
+    }
+#endif
+#if PD_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile (zeros) have landed too
+#undef PD_DMA_K
+#undef PD_DMA_V
+#undef PD_KISSUE
+#undef PD_KWAIT
+#undef PD_VISSUE
+#undef PD_VWAIT
+#undef PD_QK
+#undef PD_PV
+#undef PD_SHADOW_MAX
+#undef MASK_RAGGED
+#undef MAX8
+#undef MAX_FINISH1
+
+    // ---------------- epilogue: normalise, store O[q][d] (as attn_pp_kernel) ----------------
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (part >= 0) {
+        float* wsp = p.ws + (int64_t)part * partial_floats<D>();
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wsp[(dt * 16 + j) * (kWaves * 64) + tid] = o[dt][j];
+        wsp[kDT * 16 * (kWaves * 64) + tid] = m_run;
+        wsp[kDT * 16 * (kWaves * 64) + kWaves * 64 + tid] = l_run;
+        continue;
+    }
+    const float inv = 1.0f / l_run;
+    if (qrow < p.lq) {
+        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < kDT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
+                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) |
+                              ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
+            }
+        }
+    }
+  }   // piece
+}
+
 // Merge the key-range partials of each tail block: m = max m_s, O = sum O_s 2^(m_s-m), l likewise; store bf16.
 // grid = (8 * rem_x, D / 32): one workgroup per (tail block, 32-column d-tile) -- a block's 64 KB of fp32 partials per
 // piece are four independent column slices, so the few tail blocks (48 at the bench shape) become 4x the workgroups
@@ -1192,7 +1611,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     // sequences of the text cross-attention at head_dim 128 (whole blocks only: never for fino_attn_partial)
     {
         const int tk = fino_tune_get(FINO_TUNE_ATTN_KERNEL);
-        if (!p.all_partial && (tk == 3 || (tk == 0 && VAR == 1 && D == 128))) return launch_attn_fr<T, D>(p, st);
+        if (!p.all_partial && (tk == 3 || ((tk == 0 || tk == 5) && VAR == 1 && D == 128))) return launch_attn_fr<T, D>(p, st);
     }
     static FinoPerDeviceOnce once_a, once_b;
     if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
@@ -1213,7 +1632,8 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     if (p.all_partial) sp = SplitPlan{groups * p.nqb_v, 0, 0, 1};     // no tail split: every block is a partial anyway
     p.full_x = sp.full_x; p.rem_x = sp.rem_x; p.nwg = sp.nwg; p.per = sp.per;
     const dim3 grid((unsigned)(8 * (sp.full_x + sp.nwg)));
-    // head_dim 128 has two kernels.  On gaussian operands the 4-wave one is the faster standalone (B = 2, 24 heads, 12320^2:
+    // head_dim 128, long key sequences: the LDS-DMA-staged ping-pong kernel (round 4; same bits as the register-staged one,
+    // -2.3 ... -2.8 % per launch inside the denoise step, profiles/r04_step_ab_ppd.txt).  The 4-wave kernel: on gaussian operands the 4-wave one is the faster standalone (B = 2, 24 heads, 12320^2:
     // 1186 vs 1166 TFLOP/s, 1253 with the MFMA fold; tools/attn_w4_ab.py).  Inside the denoise step, on the bench's own
     // activations, rocprof says 3237 / 3070 (fold) vs 3114 us per launch for the 8-wave kernel and tools/step_ab.py a tie
     // per step: the default stays the 8-wave kernel, the 4-wave one is FINO_TUNE_ATTN_KERNEL = 2.
@@ -1223,8 +1643,18 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     // in bf16, 659 -> 619 with MXFP8 linears) and is the default whenever the caller folds the scale into q.
     const bool w4 = fino_attn_w4_supports(D, p.scale_log2) &&
                     (tune_k == 2 || (tune_k == 0 && D == 64 && p.scale_log2 == 1.0f && p.lk >= 2048));
+    bool ppd = false;
+    if constexpr (D == 128) ppd = pingpong && (tune_k == 4 || (tune_k == 0 && VAR == 0));   // 5: the round-3 policy (register-staged)
     if (w4) {
         if (int rc = fino_attn_launch_w4(p, T::kId, D, st)) return rc;
+    } else if (ppd) {
+        if constexpr (D == 128) {
+            constexpr int smem_d = 2 * kPdSlots * kKV * D * 2;
+            static FinoPerDeviceOnce once_d;
+            if (int rc = fino_max_smem_once(once_d, reinterpret_cast<const void*>(&attn_ppd_kernel<T, VAR>), smem_d, "fino_attn_fwd"))
+                return rc;
+            attn_ppd_kernel<T, VAR><<<grid, kWaves * 64, smem_d, st>>>(p);
+        }
     } else if (pingpong)
         attn_pp_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     else

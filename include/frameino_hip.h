@@ -42,9 +42,11 @@ const char* fino_last_error(void);
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
  * order.  FINO_TUNE_GEMM_RASTER: reserved.  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
  * ping-pong one.  FINO_TUNE_GEMM_TILE_M: 2 .. 7 = one launch of 32 x that many rows per tile, 8 = 256-row tiles only (the round-2 behaviour).
- * FINO_TUNE_ATTN_KERNEL: 1 = the 8-wave ping-pong kernel everywhere, 2 = the 4-wave one-wave-per-SIMD kernel (head_dim
- * 128), 3 = the free-running kernel (4 waves, two workgroups per CU) everywhere; 0 = the policy: free-running for Lk <= 1024
- * at head_dim 128 (text cross-attention), 4-wave for head_dim 64 with the folded scale, 8-wave otherwise.
+ * FINO_TUNE_ATTN_KERNEL: 1 = the register-staged 8-wave ping-pong kernel everywhere, 2 = the 4-wave one-wave-per-SIMD kernel
+ * (head_dim 128), 3 = the free-running kernel (4 waves, two workgroups per CU) everywhere, 4 = the LDS-DMA-staged 8-wave
+ * ping-pong kernel wherever head_dim is 128, 5 = the round-3 policy (as 0, but register-staged for Lk > 1024); 0 = the policy:
+ * free-running for Lk <= 1024 at head_dim 128 (text cross-attention), LDS-DMA-staged ping-pong for Lk > 1024 at head_dim
+ * 128, 4-wave for head_dim 64 with the folded scale, register-staged ping-pong otherwise.
  * FINO_TUNE_ATTN_FP8_KERNEL (fino_attn_fwd_fp8): 1 = the 8-wave ping-pong kernel instead of the free-running 4-wave one. */
 enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_TILE_M = 3,
        FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_ATTN_FP8_KERNEL = 5, FINO_TUNE_COUNT = 8 };

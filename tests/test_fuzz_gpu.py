@@ -109,7 +109,7 @@ def _split_cases(n, seed):
         lq = rng.choice([rng.randint(1, 300), rng.randint(300, 1600), 256 * rng.randint(1, 6)])
         nparts = rng.choice([1, 2, 3])
         lens = tuple(rng.choice([rng.randint(1, 70), rng.randint(64, 900), 64 * rng.randint(1, 12)]) for _ in range(nparts))
-        out.append((b, heads, dh, lq, lens, rng.choice([0, 2])))
+        out.append((b, heads, dh, lq, lens, rng.choice([0, 2, 4])))
     return out
 
 
@@ -117,7 +117,7 @@ def _split_cases(n, seed):
     c[0], c[1], c[2], c[3], "+".join(map(str, c[4])), c[5]))
 def test_attention_partials_random_key_splits(case):
     """what the token-sharded forward does (own K/V chunk, then the gathered chunks before / after it): 1-3 partials over
-    random disjoint key ranges, merged, against fp32 SDPA over all keys -- 8-wave and 4-wave kernels"""
+    random disjoint key ranges, merged, against fp32 SDPA over all keys -- the policy, the 4-wave kernel and the LDS-DMA-staged ping-pong kernel everywhere"""
     from frameino_amd import _lib, ops
     b, heads, dh, lq, lens, tune = case
     g = torch.Generator(device=DEV).manual_seed(hash(case) & 0xffff)

@@ -44,6 +44,10 @@ if "--tiles" in sys.argv:      # round 3: GEMM tile heights (FINO_TUNE_GEMM_TILE
 if "--cross" in sys.argv:      # round 3: text cross-attention on the 8-wave ping-pong kernel (tune 1) vs the free-running one (default policy)
     settings = {"cross-attention: 8-wave ping-pong kernel": (0, True, 1, False, 0),
                 "cross-attention: free-running kernel (default)": (0, True, 0, False, 0)}
+if "--ppd" in sys.argv:        # round 4: self-attention on the register-staged ping-pong kernel
+    # vs the LDS-DMA-staged one; the text cross-attention stays on the free-running kernel in both
+    settings = {"self-attention: register-staged ping-pong kernel (tune 5, the round-3 policy)": (0, True, 5, False, 0),
+                "self-attention: LDS-DMA-staged ping-pong kernel (the policy)": (0, True, 0, False, 0)}
 res = {k: [] for k in settings}
 
 
