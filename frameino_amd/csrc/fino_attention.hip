@@ -774,6 +774,9 @@ constexpr int kPdSlots = 4;
 #ifndef PD_PRIO
 #define PD_PRIO 1          /* 0: s_setprio 1 around every matrix phase; 1: static priority for waves 4-7, no flips; 2: none */
 #endif
+#ifndef PD_FINE
+#define PD_FINE 1          /* 1: the matrix phase issues its LDS reads BETWEEN the MFMAs that shadow them (two per gap), with per-fragment waits */
+#endif
 #ifndef PD_MAX_SOFTMAX
 #define PD_MAX_SOFTMAX 1   /* 1: the row maxima of S(t) open softmax(t) instead of riding in the P.V shadow of matrix(t-1) */
 #endif
@@ -952,6 +955,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         const uint32_t a_ = ka0 ^ ((KS_) << 5);                                                              \
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"                                  \
                      : "=&v"(ka[B_][0]), "=&v"(ka[B_][1]) : "v"(a_), "n"(32 * D * 2));                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
 #define PD_KWAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(ka[B_][0]), "+v"(ka[B_][1]));
 #define PD_VISSUE(STEP_, B_)                                                                                 \
@@ -975,6 +979,34 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][0]), qf[KS_], (FIRST_) ? zero16 : sc0);                  \
     sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][1]), qf[KS_], (FIRST_) ? zero16 : sc1);                  \
     __builtin_amdgcn_sched_barrier(0);
+    // PD_FINE: one MFMA, then the reads its 32 cycles shadow -- an in-order wave issues nothing while its MFMA waits for the
+    // pipe, so reads queued behind a run of MFMAs start late and the next run waits for them
+#define PD_MF0(KS_, B_, FIRST_)                                                                              \
+    sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][0]), qf[KS_], (FIRST_) ? zero16 : sc0);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#define PD_MF1(KS_, B_, FIRST_)                                                                              \
+    sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][1]), qf[KS_], (FIRST_) ? zero16 : sc1);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#define PD_VPAIR(STEP_, B_, DT_)                                                                             \
+    {                                                                                                        \
+        const uint32_t l_ = vl0 ^ ((DT_) << 6), h_ = vh0 ^ ((DT_) << 6);                                     \
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"            \
+                     : "=&v"(vlo[B_][DT_]), "=&v"(vhi[B_][DT_]) : "v"(l_), "v"(h_), "n"((STEP_) * 16 * D * 2)); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+#define PD_VW(N_, B_, DT_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(vlo[B_][DT_]), "+v"(vhi[B_][DT_]));
+#define PD_MFV(STEP_, B_, DT_)                                                                               \
+    {                                                                                                        \
+        const s16x8_t va_ = __builtin_shufflevector(vlo[B_][DT_], vhi[B_][DT_], 0, 1, 2, 3, 4, 5, 6, 7);     \
+        o[DT_] = T::mfma32(__builtin_bit_cast(vec8, va_), pb[STEP_], o[DT_]);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+    // one key step of P.V: d-tile DT_'s MFMA, then the next step's fragments for the same d-tile
+#define PD_PVSTEP(STEP_, B_, NB_, NSTEP_)                                                                    \
+    PD_VW(6, B_, 0) PD_MFV(STEP_, B_, 0) PD_VPAIR(NSTEP_, NB_, 0)                                            \
+    PD_VW(6, B_, 1) PD_MFV(STEP_, B_, 1) PD_VPAIR(NSTEP_, NB_, 1)                                            \
+    PD_VW(6, B_, 2) PD_MFV(STEP_, B_, 2) PD_VPAIR(NSTEP_, NB_, 2)                                            \
+    PD_VW(6, B_, 3) PD_MFV(STEP_, B_, 3) PD_VPAIR(NSTEP_, NB_, 3)
 #if PD_MAX_SOFTMAX
 #define PD_SHADOW_MAX(MAXEXPR_)
 #else
@@ -1068,6 +1100,40 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         __builtin_amdgcn_s_setprio(1);
 #endif
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if PD_FINE
+        if (t + 1 < nt) {
+#if !PD_PREK
+            PD_KISSUE(0, 0)
+            PD_KISSUE(1, 1)
+#endif
+            PD_KWAIT(2, 0) PD_MF0(0, 0, true) PD_KISSUE(2, 2) PD_MF1(0, 0, true)
+            PD_KWAIT(2, 1) PD_MF0(1, 1, false) PD_KISSUE(3, 0) PD_MF1(1, 1, false)
+            PD_KWAIT(2, 2) PD_MF0(2, 2, false) PD_KISSUE(4, 1) PD_MF1(2, 2, false)
+            PD_KWAIT(2, 0) PD_MF0(3, 0, false) PD_KISSUE(5, 2) PD_MF1(3, 0, false)
+            PD_KWAIT(2, 1) PD_MF0(4, 1, false) PD_KISSUE(6, 0) PD_MF1(4, 1, false)
+            PD_KWAIT(2, 2) PD_MF0(5, 2, false) PD_KISSUE(7, 1) PD_MF1(5, 2, false)
+            PD_KWAIT(2, 0) PD_MF0(6, 0, false) PD_VPAIR(0, 0, 0) PD_VPAIR(0, 0, 1) PD_MF1(6, 0, false)
+            PD_KWAIT(4, 1) PD_MF0(7, 1, false) PD_VPAIR(0, 0, 2) PD_VPAIR(0, 0, 3) PD_MF1(7, 1, false)
+        } else {
+            PD_VPAIR(0, 0, 0) PD_VPAIR(0, 0, 1) PD_VPAIR(0, 0, 2) PD_VPAIR(0, 0, 3)
+        }
+        ASTAMP(tsm)
+#if !PD_MAX_SOFTMAX
+        MASK_RAGGED(t + 1)
+        float mxa = -INFINITY;
+#endif
+        PD_PVSTEP(0, 0, 1, 1)
+        PD_SHADOW_MAX(MAX8(sc0, 0))
+        PD_PVSTEP(1, 1, 0, 2)
+        PD_SHADOW_MAX(MAX8(sc0, 8))
+        PD_PVSTEP(2, 0, 1, 3)
+        PD_SHADOW_MAX(MAX8(sc1, 0))
+        PD_VW(6, 1, 0) PD_MFV(3, 1, 0)
+        PD_VW(4, 1, 1) PD_MFV(3, 1, 1)
+        PD_VW(2, 1, 2) PD_MFV(3, 1, 2)
+        PD_VW(0, 1, 3) PD_MFV(3, 1, 3)
+        PD_SHADOW_MAX(MAX8(sc1, 8))
+#else
         if (t + 1 < nt) {
 #if !PD_PREK
             PD_KISSUE(0, 0)
@@ -1093,6 +1159,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         PD_VISSUE(2, 0) PD_VWAIT(8, 1) PD_PV(1, 1, MAX8(sc0, 8))
         PD_VISSUE(3, 1) PD_VWAIT(8, 0) PD_PV(2, 0, MAX8(sc1, 0))
         PD_VWAIT(0, 1) PD_PV(3, 1, MAX8(sc1, 8))
+#endif
 #if !PD_MAX_SOFTMAX
         MAX_FINISH1(mxa, mx_next)
 #endif
@@ -1132,6 +1199,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 #undef PD_QK
 #undef PD_PV
 #undef PD_SHADOW_MAX
+#undef PD_MF0
+#undef PD_MF1
+#undef PD_VPAIR
+#undef PD_VW
+#undef PD_MFV
+#undef PD_PVSTEP
 #undef MASK_RAGGED
 #undef MAX8
 #undef MAX_FINISH1
