@@ -774,9 +774,6 @@ constexpr int kPdSlots = 4;
 #ifndef PD_PRIO
 #define PD_PRIO 1          /* 0: s_setprio 1 around every matrix phase; 1: static priority for waves 4-7, no flips; 2: none */
 #endif
-#ifndef PD_FINE
-#define PD_FINE 1          /* 1: the matrix phase issues its LDS reads BETWEEN the MFMAs that shadow them (two per gap), with per-fragment waits */
-#endif
 #ifndef PD_MAX_SOFTMAX
 #define PD_MAX_SOFTMAX 1   /* 1: the row maxima of S(t) open softmax(t) instead of riding in the P.V shadow of matrix(t-1) */
 #endif
@@ -790,7 +787,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     constexpr int kVBase = kPdSlots * kTileBytes;            // V ring behind the K ring
     constexpr uint32_t kRingMask = kPdSlots * kTileBytes - 1;
     typedef typename T::vec8 vec8;
-    typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -950,6 +946,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 
     u32x4_t ka[3][2];
     s16x4_t vlo[2][kDT], vhi[2][kDT];
+#ifdef PD_X_NOREAD       /* timing experiment (wrong results): the matrix phase without its LDS reads */
+#define PD_KISSUE(KS_, B_) { asm volatile("" : "=v"(ka[B_][0]), "=v"(ka[B_][1])); __builtin_amdgcn_sched_barrier(0); }
+#else
 #define PD_KISSUE(KS_, B_)                                                                                   \
     {                                                                                                        \
         const uint32_t a_ = ka0 ^ ((KS_) << 5);                                                              \
@@ -957,36 +956,31 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
                      : "=&v"(ka[B_][0]), "=&v"(ka[B_][1]) : "v"(a_), "n"(32 * D * 2));                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
+#endif
 #define PD_KWAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(ka[B_][0]), "+v"(ka[B_][1]));
-#define PD_VISSUE(STEP_, B_)                                                                                 \
-    {                                                                                                        \
-        const uint32_t l1_ = vl0 ^ 64u, l2_ = vl0 ^ 128u, l3_ = vl0 ^ 192u;                                  \
-        const uint32_t h1_ = vh0 ^ 64u, h2_ = vh0 ^ 128u, h3_ = vh0 ^ 192u;                                  \
-        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%16\n\tds_read_b64_tr_b16 %1, %9 offset:%16\n\t"      \
-                     "ds_read_b64_tr_b16 %2, %10 offset:%16\n\tds_read_b64_tr_b16 %3, %11 offset:%16\n\t"    \
-                     "ds_read_b64_tr_b16 %4, %12 offset:%16\n\tds_read_b64_tr_b16 %5, %13 offset:%16\n\t"    \
-                     "ds_read_b64_tr_b16 %6, %14 offset:%16\n\tds_read_b64_tr_b16 %7, %15 offset:%16"        \
-                     : "=&v"(vlo[B_][0]), "=&v"(vhi[B_][0]), "=&v"(vlo[B_][1]), "=&v"(vhi[B_][1]),           \
-                       "=&v"(vlo[B_][2]), "=&v"(vhi[B_][2]), "=&v"(vlo[B_][3]), "=&v"(vhi[B_][3])            \
-                     : "v"(vl0), "v"(vh0), "v"(l1_), "v"(h1_), "v"(l2_), "v"(h2_), "v"(l3_), "v"(h3_),       \
-                       "n"((STEP_) * 16 * D * 2));                                                           \
-    }
-#define PD_VWAIT(N_, B_)                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(" #N_ ")"                                                                \
-                 : "+v"(vlo[B_][0]), "+v"(vhi[B_][0]), "+v"(vlo[B_][1]), "+v"(vhi[B_][1]), "+v"(vlo[B_][2]), \
-                   "+v"(vhi[B_][2]), "+v"(vlo[B_][3]), "+v"(vhi[B_][3]));
-#define PD_QK(KS_, B_, FIRST_)                                                                               \
-    sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][0]), qf[KS_], (FIRST_) ? zero16 : sc0);                  \
-    sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][1]), qf[KS_], (FIRST_) ? zero16 : sc1);                  \
-    __builtin_amdgcn_sched_barrier(0);
-    // PD_FINE: one MFMA, then the reads its 32 cycles shadow -- an in-order wave issues nothing while its MFMA waits for the
+    // one MFMA, then the reads its 32 cycles shadow -- an in-order wave issues nothing while its MFMA waits for the
     // pipe, so reads queued behind a run of MFMAs start late and the next run waits for them
+    // timing experiments (wrong results): PD_X_AOP 1 = the A operand of every MFMA is one fixed register set (reads kept: what
+    // the operands' bit flips cost), 2 = it rotates through the Q / P registers (with PD_X_NOREAD: what the reads cost)
+#if defined(PD_X_AOP) && PD_X_AOP == 1
+#define PD_A_S(KS_, B_, H_) qf[0]
+#define PD_A_V(STEP_, B_, DT_) qf[0]
+#elif defined(PD_X_AOP) && PD_X_AOP == 2
+#define PD_A_S(KS_, B_, H_) qf[((KS_) + 1 + 3 * (H_)) % kKS]
+#define PD_A_V(STEP_, B_, DT_) pb[((STEP_) + (DT_) + 1) % 4]
+#else
+#define PD_A_S(KS_, B_, H_) __builtin_bit_cast(vec8, ka[B_][H_])
+#define PD_A_V(STEP_, B_, DT_) __builtin_bit_cast(vec8, __builtin_shufflevector(vlo[B_][DT_], vhi[B_][DT_], 0, 1, 2, 3, 4, 5, 6, 7))
+#endif
 #define PD_MF0(KS_, B_, FIRST_)                                                                              \
-    sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][0]), qf[KS_], (FIRST_) ? zero16 : sc0);                  \
+    sc0 = T::mfma32(PD_A_S(KS_, B_, 0), qf[KS_], (FIRST_) ? zero16 : sc0);                                   \
     __builtin_amdgcn_sched_barrier(0);
 #define PD_MF1(KS_, B_, FIRST_)                                                                              \
-    sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][1]), qf[KS_], (FIRST_) ? zero16 : sc1);                  \
+    sc1 = T::mfma32(PD_A_S(KS_, B_, 1), qf[KS_], (FIRST_) ? zero16 : sc1);                                   \
     __builtin_amdgcn_sched_barrier(0);
+#ifdef PD_X_NOREAD
+#define PD_VPAIR(STEP_, B_, DT_) { asm volatile("" : "=v"(vlo[B_][DT_]), "=v"(vhi[B_][DT_])); __builtin_amdgcn_sched_barrier(0); }
+#else
 #define PD_VPAIR(STEP_, B_, DT_)                                                                             \
     {                                                                                                        \
         const uint32_t l_ = vl0 ^ ((DT_) << 6), h_ = vh0 ^ ((DT_) << 6);                                     \
@@ -994,11 +988,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
                      : "=&v"(vlo[B_][DT_]), "=&v"(vhi[B_][DT_]) : "v"(l_), "v"(h_), "n"((STEP_) * 16 * D * 2)); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
+#endif
 #define PD_VW(N_, B_, DT_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(vlo[B_][DT_]), "+v"(vhi[B_][DT_]));
 #define PD_MFV(STEP_, B_, DT_)                                                                               \
     {                                                                                                        \
-        const s16x8_t va_ = __builtin_shufflevector(vlo[B_][DT_], vhi[B_][DT_], 0, 1, 2, 3, 4, 5, 6, 7);     \
-        o[DT_] = T::mfma32(__builtin_bit_cast(vec8, va_), pb[STEP_], o[DT_]);                                \
+        o[DT_] = T::mfma32(PD_A_V(STEP_, B_, DT_), pb[STEP_], o[DT_]);                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
     // one key step of P.V: d-tile DT_'s MFMA, then the next step's fragments for the same d-tile
@@ -1012,13 +1006,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 #else
 #define PD_SHADOW_MAX(MAXEXPR_) mxa = vmax2(mxa, MAXEXPR_);
 #endif
-#define PD_PV(STEP_, B_, MAXEXPR_)                                                                           \
-    _Pragma("unroll") for (int dt_ = 0; dt_ < kDT; ++dt_) {                                                  \
-        const s16x8_t va_ = __builtin_shufflevector(vlo[B_][dt_], vhi[B_][dt_], 0, 1, 2, 3, 4, 5, 6, 7);     \
-        o[dt_] = T::mfma32(__builtin_bit_cast(vec8, va_), pb[STEP_], o[dt_]);                                \
-    }                                                                                                        \
-    PD_SHADOW_MAX(MAXEXPR_)                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);
 
 #ifdef FINO_ATTN_STAMP
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsm = 0, tse = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sa5 = 0, sa6 = 0;
@@ -1027,8 +1014,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         ASTAMP(ts0)
         // ================= softmax phase =================
         const int w = t + grp;
+#ifndef PD_X_NODMA       /* timing experiment (wrong results): no K / V staging at all after the prologue */
         PD_DMA_K(w + 3)
         PD_DMA_V(w + 2)
+#endif
 #if PD_MAX_SOFTMAX
         {
             MASK_RAGGED(t)
@@ -1050,8 +1039,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+#ifdef PD_X_NOEXP        /* timing experiment (wrong results): the softmax phase without its 32 exp2 */
+            sc0[j] = sc0[j] * c2 - m_run;
+            sc1[j] = sc1[j] * c2 - m_run;
+#else
             sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);
             sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);
+#endif
         }
         {
             float psum0 = 0.f, psum1 = 0.f;
@@ -1100,7 +1094,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         __builtin_amdgcn_s_setprio(1);
 #endif
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if PD_FINE
         if (t + 1 < nt) {
 #if !PD_PREK
             PD_KISSUE(0, 0)
@@ -1133,33 +1126,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         PD_VW(2, 1, 2) PD_MFV(3, 1, 2)
         PD_VW(0, 1, 3) PD_MFV(3, 1, 3)
         PD_SHADOW_MAX(MAX8(sc1, 8))
-#else
-        if (t + 1 < nt) {
-#if !PD_PREK
-            PD_KISSUE(0, 0)
-            PD_KISSUE(1, 1)
-#endif
-            PD_KISSUE(2, 2) PD_KWAIT(4, 0) PD_QK(0, 0, true)
-            PD_KISSUE(3, 0) PD_KWAIT(4, 1) PD_QK(1, 1, false)
-            PD_KISSUE(4, 1) PD_KWAIT(4, 2) PD_QK(2, 2, false)
-            PD_KISSUE(5, 2) PD_KWAIT(4, 0) PD_QK(3, 0, false)
-            PD_KISSUE(6, 0) PD_KWAIT(4, 1) PD_QK(4, 1, false)
-            PD_KISSUE(7, 1) PD_KWAIT(4, 2) PD_QK(5, 2, false)
-            PD_VISSUE(0, 0) PD_KWAIT(10, 0) PD_QK(6, 0, false)
-            PD_KWAIT(8, 1) PD_QK(7, 1, false)
-        } else {
-            PD_VISSUE(0, 0)
-        }
-        ASTAMP(tsm)
-#if !PD_MAX_SOFTMAX
-        MASK_RAGGED(t + 1)
-        float mxa = -INFINITY;
-#endif
-        PD_VISSUE(1, 1) PD_VWAIT(8, 0) PD_PV(0, 0, MAX8(sc0, 0))
-        PD_VISSUE(2, 0) PD_VWAIT(8, 1) PD_PV(1, 1, MAX8(sc0, 8))
-        PD_VISSUE(3, 1) PD_VWAIT(8, 0) PD_PV(2, 0, MAX8(sc1, 0))
-        PD_VWAIT(0, 1) PD_PV(3, 1, MAX8(sc1, 8))
-#endif
 #if !PD_MAX_SOFTMAX
         MAX_FINISH1(mxa, mx_next)
 #endif
@@ -1194,12 +1160,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 #undef PD_DMA_V
 #undef PD_KISSUE
 #undef PD_KWAIT
-#undef PD_VISSUE
-#undef PD_VWAIT
-#undef PD_QK
-#undef PD_PV
 #undef PD_SHADOW_MAX
 #undef PD_MF0
+#undef PD_A_S
+#undef PD_A_V
 #undef PD_MF1
 #undef PD_VPAIR
 #undef PD_VW
