@@ -767,6 +767,41 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
 // are attn_pp_kernel's: results are bit-identical (tests/test_kernels_gpu.py).
 constexpr int kPdSlots = 4;
 
+// One wave's O^T accumulators (32 query rows x 128 channels, scaled by `inv`) -> T rows, through 8 KiB of LDS at `lds_base`: the
+// lane that holds 4 consecutive channels of a row writes their 8 bytes into an XOR-swizzled [32 rows][256 B] image; then 16 lanes
+// read one whole row as 16-byte pieces, rows[k] = piece (lane & 15) of row 4 k + (lane >> 4).  A store of rows[k] covers 4
+// complete rows (8 whole cache lines); the direct form -- 16 stores of 8 bytes per lane -- touches 32 lines per instruction, and
+// cost the short-key kernel 4.7 us per q-block (profiles/r04_attn_ppw_nostore.txt).  All LDS traffic is inline asm (the compiler
+// would drain vmcnt in front of LDS accesses it can see while LDS-DMA is in flight); the wave reads only what it wrote.
+template <typename T>
+__device__ __forceinline__ void attn_rows_through_lds(const f32x16_t (&o)[4], float inv, uint32_t lds_base, int r, int h,
+                                                      int lane, u32x4_t (&rows)[8]) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const uint32_t wbase = lds_base + (uint32_t)(r * 256 + (h << 3));
+    const uint32_t rsw = (uint32_t)(r & 15);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) | ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
+            const uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) | ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
+            const uint32_t a = wbase + ((((uint32_t)(4 * dt + g)) ^ rsw) << 4);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(u32x2_t{w0, w1}) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t row0 = (uint32_t)(lane >> 4), c = (uint32_t)(lane & 15);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t row = 4 * k + row0;
+        const uint32_t a = lds_base + row * 256 + ((c ^ (row & 15)) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(rows[k]) : "v"(a) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(rows[0]), "+v"(rows[1]), "+v"(rows[2]), "+v"(rows[3]), "+v"(rows[4]), "+v"(rows[5]), "+v"(rows[6]), "+v"(rows[7])
+                 :: "memory");
+}
+
 // A/B knobs of attn_ppd_kernel (make variant VFLAGS=-DPD_...=x; results are the same bits for every setting):
 #ifndef PD_PREK
 #define PD_PREK 1          /* 1: the first two k-steps' K fragments are fetched BEFORE the barrier that opens the matrix phase */
@@ -1155,7 +1190,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     __builtin_amdgcn_s_setprio(0);
 #endif
     if (grp == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile (zeros) have landed too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile (zeros) have landed too ...
+    __builtin_amdgcn_s_barrier();                      // ... for EVERY wave: the epilogue stages its output rows in the rings
 #undef PD_DMA_K
 #undef PD_DMA_V
 #undef PD_KISSUE
@@ -1189,22 +1225,397 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         continue;
     }
     const float inv = 1.0f / l_run;
-    if (qrow < p.lq) {
-        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+    {
+        // every wave is past its last matrix phase (the barrier above): the K ring's first 64 KiB take the output rows, 8 KiB per wave
+        u32x4_t rows[8];
+        attn_rows_through_lds<T>(o, inv, (uint32_t)(wv * 8192), r, h, lane, rows);
+        const int qrow0 = qb * kQBlock + wave * kQRowsPerWave + (lane >> 4);
 #pragma unroll
-        for (int dt = 0; dt < kDT; ++dt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dt * 32 + 8 * g + 4 * h;
-                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) |
-                              ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
-                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) |
-                              ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
-                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
-            }
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int qr = qrow0 + 4 * k8;
+            if (qr < p.lq) *reinterpret_cast<u32x4_t*>(op + (int64_t)qr * p.o_rs + (lane & 15) * 8) = rows[k8];
         }
     }
   }   // piece
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// WALKING ping-pong kernel (round 4; head_dim 128, short key sequences: the text cross-attention, Lk = 512 = 8 key tiles per
+// q-block).  attn_ppd_kernel's loop, but ONE workgroup per CU walks a run of consecutive (head-major) q-blocks without ever
+// draining: the K / V rings keep streaming across block boundaries (the DMA streams carry their own block / tile position,
+// three and two tiles ahead), the next block's Q rows are prefetched into a second register set at the start of a block, and
+// a block's normalise + store happens at the end of its last matrix phase.  What a workgroup of the one-block kernels pays per
+// 8 tiles of work -- Q load 4 - 6 us, first tiles 3 us, output store 3 - 5 us with nothing else resident on the CU
+// (profiles/r03_attn_cross_stamp.txt) -- is paid once per run instead of once per block.
+// vmcnt is in issue order over DMAs, Q loads and stores alike; the invariant of attn_ppd_kernel ("at the end of a softmax phase
+// everything issued before that phase has landed") is kept by counting them: a block's first softmax phase issues 4 DMAs + 8 Q
+// loads behind the 16 stores of the previous block's epilogue and the 4 DMAs of the phase before.
+// Whole blocks only (no tail split, no partials), 2 <= key tiles; arithmetic and order as attn_pp_kernel: same bits.
+template <typename T>
+__global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = 128;
+    constexpr int kTileBytes = kKV * D * 2;                  // 16 KiB
+    constexpr int kKS = D / 16;
+    constexpr int kDT = D / 32;
+    constexpr int kVBase = kPdSlots * kTileBytes;
+    constexpr uint32_t kRingMask = kPdSlots * kTileBytes - 1;
+    typedef typename T::vec8 vec8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = wv >> 2;
+
+    // ---- my run of q-blocks, head-major: block B = (batch * heads + head) * nqb + q-block ----
+    const int total = p.batch * p.heads * p.nqb;
+    const int b_begin = (int)((int64_t)blockIdx.x * total / gridDim.x);
+    const int nblk = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x) - b_begin;
+    const int lk = p.lk;
+    const int nt = (lk + kKV - 1) / kKV;
+    const int TT = nblk * nt;                                // key tiles of the run
+
+    // position of a stream in the run: relative block, its (batch, head, q-block), tile inside the block
+    struct Pos { int blk, bi, head, qb, lt; };
+    Pos cp, kp_, vp_;                                        // compute, K DMA, V DMA
+    {
+        const int hb = b_begin / p.nqb;
+        cp.blk = 0; cp.qb = b_begin - hb * p.nqb; cp.bi = hb / p.heads; cp.head = hb - cp.bi * p.heads; cp.lt = 0;
+        kp_ = cp; vp_ = cp;
+    }
+#define PW_NEXT_BLOCK(P_)                                                                                    \
+    {                                                                                                        \
+        ++(P_).blk;                                                                                          \
+        if (++(P_).qb == p.nqb) { (P_).qb = 0; if (++(P_).head == p.heads) { (P_).head = 0; ++(P_).bi; } }   \
+    }
+
+    // ---- K / V staging by LDS-DMA (as attn_ppd_kernel): wave w moves pieces w and w + 8 of a tile ----
+    const int rip = lane >> 4, pos = lane & 15;
+    const int srow = wv * 4 + rip;
+    const int swz = (lds_off<D>(srow, 0) >> 4) & 15;
+    const uint32_t k_voff = (uint32_t)((srow * p.k_rs + ((pos ^ swz) << 3)) * 2);
+    const uint32_t v_voff = (uint32_t)((srow * p.v_rs + ((pos ^ swz) << 3)) * 2);
+    // ONE resource per operand over the whole tensor (the launch checks each spans < 2 GiB): a per-head resource would be loop
+    // state in vector registers and every DMA a waterfall loop.  The block's (batch, head) base rides in the scalar offset.
+    // Key rows past lk then read the next batch's rows (or zeros past the tensor) instead of zeros: they only ever meet
+    // P = exp2(-inf) = 0 in the ragged last tile, and finite x 0 = 0.
+    const int k_rec = (int)((((int64_t)p.batch - 1) * p.k_bs + ((int64_t)p.heads - 1) * p.k_hs + ((int64_t)lk - 1) * p.k_rs + D) * 2);
+    const int v_rec = (int)((((int64_t)p.batch - 1) * p.v_bs + ((int64_t)p.heads - 1) * p.v_hs + ((int64_t)lk - 1) * p.v_rs + D) * 2);
+    const int o_rec = (int)((((int64_t)p.batch - 1) * p.o_bs + ((int64_t)p.heads - 1) * p.o_hs + ((int64_t)p.lq - 1) * p.o_rs + D) * 2);
+    const int k_piece_bytes = (int)(32 * p.k_rs * 2), v_piece_bytes = (int)(32 * p.v_rs * 2);
+    const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, k_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, v_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.o, 0, o_rec, 0x00020000);
+    // (32-bit scalar arithmetic: the spans fit 31 bits; a 64-bit product would be computed in vector registers)
+    const int k_bs2 = (int)(p.k_bs * 2), k_hs2 = (int)(p.k_hs * 2), v_bs2 = (int)(p.v_bs * 2), v_hs2 = (int)(p.v_hs * 2);
+    const int o_bs2 = (int)(p.o_bs * 2), o_hs2 = (int)(p.o_hs * 2);
+    int k_boff = kp_.bi * k_bs2 + kp_.head * k_hs2, v_boff = vp_.bi * v_bs2 + vp_.head * v_hs2;
+    int k_slot = 0, v_slot = 0;                              // ring slots of the next tiles to issue
+    // the stream's next tile -> its ring slot; past the run's last tile: tile nt of the last block (wholly past the last key: zeros)
+#define PW_DMA_K()                                                                                           \
+    {                                                                                                        \
+        const int tl_ = kp_.blk < nblk ? kp_.lt : nt;                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+                k_rsrc, (FINO_LDS void*)(smem + k_slot * kTileBytes + (8 * i_ + wv) * 1024), 16, k_voff,     \
+                __builtin_amdgcn_readfirstlane(k_boff + tl_ * k_tile_bytes + i_ * k_piece_bytes), 0, 0);     \
+        k_slot = (k_slot + 1) & (kPdSlots - 1);                                                              \
+        if (kp_.blk < nblk && ++kp_.lt == nt) {                                                              \
+            kp_.lt = 0;                                                                                      \
+            PW_NEXT_BLOCK(kp_)                                                                               \
+            if (kp_.blk < nblk) k_boff = kp_.bi * k_bs2 + kp_.head * k_hs2;                                  \
+        }                                                                                                    \
+    }
+#define PW_DMA_V()                                                                                           \
+    {                                                                                                        \
+        const int tl_ = vp_.blk < nblk ? vp_.lt : nt;                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
+                v_rsrc, (FINO_LDS void*)(smem + kVBase + v_slot * kTileBytes + (8 * i_ + wv) * 1024), 16,    \
+                v_voff, __builtin_amdgcn_readfirstlane(v_boff + tl_ * v_tile_bytes + i_ * v_piece_bytes), 0, 0); \
+        v_slot = (v_slot + 1) & (kPdSlots - 1);                                                              \
+        if (vp_.blk < nblk && ++vp_.lt == nt) {                                                              \
+            vp_.lt = 0;                                                                                      \
+            PW_NEXT_BLOCK(vp_)                                                                               \
+            if (vp_.blk < nblk) v_boff = vp_.bi * v_bs2 + vp_.head * v_hs2;                                  \
+        }                                                                                                    \
+    }
+    // prologue: K(0..2), V(0..1) by everyone; group 1 (whose first softmax phase issues K(4) / V(3)) also K(3) / V(2)
+    PW_DMA_K() PW_DMA_V() PW_DMA_K() PW_DMA_V() PW_DMA_K()
+    if (grp == 1) { PW_DMA_K() PW_DMA_V() }
+
+    // ---- Q fragments of a block: lane holds Q[q0 + r][16*ks + 8h .. +7], loaded RAW (a select on the loaded value would
+    //      make the compiler wait for it on the spot, DMAs included); rows past Lq are zeroed when the set becomes current ----
+    //      The loads are inline asm: loads the compiler can see are loop-carried pending events to it (it cannot read the
+    //      counted waits), and it would drain the queue -- the previous block's 16 stores included -- before re-using qn.
+#define PW_LOAD_Q(DST_, P_)                                                                                  \
+    {                                                                                                        \
+        const int qrow_ = (P_).qb * kQBlock + wave * kQRowsPerWave + r;                                      \
+        const int qrc_ = qrow_ < p.lq ? qrow_ : p.lq - 1;                                                    \
+        const uint16_t* qp_ = p.q + (P_).bi * p.q_bs + (P_).head * p.q_hs + (int64_t)qrc_ * p.q_rs + 8 * h;  \
+        asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"      \
+                     "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t" \
+                     "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t" \
+                     "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224"  \
+                     : "=&v"(DST_[0]), "=&v"(DST_[1]), "=&v"(DST_[2]), "=&v"(DST_[3]), "=&v"(DST_[4]),       \
+                       "=&v"(DST_[5]), "=&v"(DST_[6]), "=&v"(DST_[7])                                        \
+                     : "v"(qp_) : "memory");                                                                 \
+    }
+#define PW_TAKE_Q(P_)                                                                                        \
+    {                                                                                                        \
+        const bool live_ = (P_).qb * kQBlock + wave * kQRowsPerWave + r < p.lq;                              \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < kKS; ++ks_)                                                \
+            qf[ks_] = __builtin_bit_cast(vec8, live_ ? qn[ks_] : u32x4_t{0u, 0u, 0u, 0u});                   \
+    }
+    vec8 qf[kKS];
+    u32x4_t qn[kKS];
+    PW_LOAD_Q(qn, cp)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qn[4]), "+v"(qn[5]), "+v"(qn[6]),
+                 "+v"(qn[7]) :: "memory");
+    PW_TAKE_Q(cp)
+
+    const int tq = (lane & 15) >> 2;
+    const int tp = lane & 3;
+    const int g1l = (lane >> 4) & 1;
+    f32x16_t o[kDT];
+#pragma unroll
+    for (int i = 0; i < kDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+    const float c2 = p.scale_log2;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // S(0) from K ring slot 0 (plain LDS reads: nothing is in flight here)
+    f32x16_t sc0, sc1;
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sc0[j] = 0.f; sc1[j] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(smem + lds_off<D>(r, 2 * ks + h));
+            const uint4 a1 = *reinterpret_cast<const uint4*>(smem + lds_off<D>(32 + r, 2 * ks + h));
+            sc0 = T::mfma32(__builtin_bit_cast(vec8, a0), qf[ks], sc0);
+            sc1 = T::mfma32(__builtin_bit_cast(vec8, a1), qf[ks], sc1);
+        }
+    }
+#define MAX8(S_, O_) vmax2(vmax3(vmax3(S_[O_], S_[O_ + 1], S_[O_ + 2]), vmax3(S_[O_ + 3], S_[O_ + 4], S_[O_ + 5]), \
+                                 S_[O_ + 6]), S_[O_ + 7])
+    float mx_next = 0.f;
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every age arbitration otherwise
+
+    if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
+    uint32_t ka0 = 1 * kTileBytes + lds_off<D>(r, h);
+    uint32_t vl0 = kVBase + lds_off<D>(4 * h + tq, 2 * g1l + (tp >> 1)) + 8 * (tp & 1);
+    uint32_t vh0 = kVBase + lds_off<D>(4 * h + tq + 8, 2 * g1l + (tp >> 1)) + 8 * (tp & 1);
+
+    u32x4_t ka[3][2];
+    s16x4_t vlo[2][kDT], vhi[2][kDT];
+#define PD_KISSUE(KS_, B_)                                                                                   \
+    {                                                                                                        \
+        const uint32_t a_ = ka0 ^ ((KS_) << 5);                                                              \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"                                  \
+                     : "=&v"(ka[B_][0]), "=&v"(ka[B_][1]) : "v"(a_), "n"(32 * D * 2));                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+#define PD_KWAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(ka[B_][0]), "+v"(ka[B_][1]));
+#define PD_MF0(KS_, B_, FIRST_)                                                                              \
+    sc0 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][0]), qf[KS_], (FIRST_) ? zero16 : sc0);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#define PD_MF1(KS_, B_, FIRST_)                                                                              \
+    sc1 = T::mfma32(__builtin_bit_cast(vec8, ka[B_][1]), qf[KS_], (FIRST_) ? zero16 : sc1);                  \
+    __builtin_amdgcn_sched_barrier(0);
+#define PD_VPAIR(STEP_, B_, DT_)                                                                             \
+    {                                                                                                        \
+        const uint32_t l_ = vl0 ^ ((DT_) << 6), h_ = vh0 ^ ((DT_) << 6);                                     \
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"            \
+                     : "=&v"(vlo[B_][DT_]), "=&v"(vhi[B_][DT_]) : "v"(l_), "v"(h_), "n"((STEP_) * 16 * D * 2)); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+#define PD_VW(N_, B_, DT_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(vlo[B_][DT_]), "+v"(vhi[B_][DT_]));
+#define PD_MFV(STEP_, B_, DT_)                                                                               \
+    {                                                                                                        \
+        o[DT_] = T::mfma32(__builtin_bit_cast(vec8, __builtin_shufflevector(vlo[B_][DT_], vhi[B_][DT_], 0, 1, 2, 3, 4, 5, 6, 7)), \
+                           pb[STEP_], o[DT_]);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+#define PD_PVSTEP(STEP_, B_, NB_, NSTEP_)                                                                    \
+    PD_VW(6, B_, 0) PD_MFV(STEP_, B_, 0) PD_VPAIR(NSTEP_, NB_, 0)                                            \
+    PD_VW(6, B_, 1) PD_MFV(STEP_, B_, 1) PD_VPAIR(NSTEP_, NB_, 1)                                            \
+    PD_VW(6, B_, 2) PD_MFV(STEP_, B_, 2) PD_VPAIR(NSTEP_, NB_, 2)                                            \
+    PD_VW(6, B_, 3) PD_MFV(STEP_, B_, 3) PD_VPAIR(NSTEP_, NB_, 3)
+
+    Pos np = cp;                                       // the block whose Q rows are in qn
+    for (int t = 0; t < TT; ++t) {
+        // ================= softmax phase of tile cp.lt of block cp.blk =================
+        PW_DMA_K()
+        PW_DMA_V()
+        if (cp.lt == 0) {                              // the next block's Q rows (the last block re-reads its own: a fixed count)
+            np = cp;
+            if (cp.blk + 1 < nblk) PW_NEXT_BLOCK(np)
+            PW_LOAD_Q(qn, np)
+        }
+        {
+            if (cp.lt == nt - 1 && (lk & (kKV - 1))) {   // keys past lk (zero K rows) stay out of the row max: p = exp2(-inf) = 0
+                const int kbase_ = cp.lt * kKV + 4 * h;
+#pragma unroll
+                for (int j_ = 0; j_ < 16; ++j_) {
+                    const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);
+                    if (key_ >= lk) sc0[j_] = -INFINITY;
+                    if (key_ + 32 >= lk) sc1[j_] = -INFINITY;
+                }
+            }
+            const float m0 = vmax2(vmax3(MAX8(sc0, 0), MAX8(sc0, 8), MAX8(sc1, 0)), MAX8(sc1, 8));
+            const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+            mx_next = vmax2(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+        }
+        {
+            const float m_cand = fmaxf(m_run, mx_next * c2);
+            if (__any((m_cand - m_run) > rescale_thr<T>())) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+                m_run = m_cand;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < kDT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);
+            sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);
+        }
+        {
+            float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                psum0 += sc0[j];
+                psum1 += sc1[j];
+            }
+            l_run += psum0 + psum1;
+        }
+        vec8 pb[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pb[0][j] = (typename T::scalar)sc0[j];
+            pb[1][j] = (typename T::scalar)sc0[8 + j];
+            pb[2][j] = (typename T::scalar)sc1[j];
+            pb[3][j] = (typename T::scalar)sc1[8 + j];
+        }
+        {
+            u32x4_t p0 = __builtin_bit_cast(u32x4_t, pb[0]), p1 = __builtin_bit_cast(u32x4_t, pb[1]);
+            u32x4_t p2 = __builtin_bit_cast(u32x4_t, pb[2]), p3 = __builtin_bit_cast(u32x4_t, pb[3]);
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(l_run));
+            pb[0] = __builtin_bit_cast(vec8, p0); pb[1] = __builtin_bit_cast(vec8, p1);
+            pb[2] = __builtin_bit_cast(vec8, p2); pb[3] = __builtin_bit_cast(vec8, p3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // Everything this wave issued before the PREVIOUS softmax phase has landed (a block's output stores get two tiles to be
+        // acknowledged: all CUs reach their block boundaries together, 16 MB of stores at once); before a block's last matrix
+        // phase, everything before THIS phase (the next block's Q rows, issued in the block's first phase, whatever nt is).
+        // Per phase, in issue order: 4 DMAs [+ 8 Q loads in a block's first phase] [+ 8 stores behind its last matrix phase].
+        if (cp.lt == nt - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (cp.lt == 0 && cp.blk == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#ifdef PW_X_NOSTORE      /* timing experiment (wrong results): no output stores */
+        else if (cp.lt == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#else
+        else if (cp.lt == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#endif
+        else if (cp.lt == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= matrix phase =================
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool last = cp.lt == nt - 1;
+        if (t + 1 < TT) {
+            PD_KISSUE(0, 0)
+            PD_KISSUE(1, 1)
+            if (last) PW_TAKE_Q(np)                    // S of the NEXT block's first tile: its Q rows have arrived (vmcnt(4) above)
+            PD_KWAIT(2, 0) PD_MF0(0, 0, true) PD_KISSUE(2, 2) PD_MF1(0, 0, true)
+            PD_KWAIT(2, 1) PD_MF0(1, 1, false) PD_KISSUE(3, 0) PD_MF1(1, 1, false)
+            PD_KWAIT(2, 2) PD_MF0(2, 2, false) PD_KISSUE(4, 1) PD_MF1(2, 2, false)
+            PD_KWAIT(2, 0) PD_MF0(3, 0, false) PD_KISSUE(5, 2) PD_MF1(3, 0, false)
+            PD_KWAIT(2, 1) PD_MF0(4, 1, false) PD_KISSUE(6, 0) PD_MF1(4, 1, false)
+            PD_KWAIT(2, 2) PD_MF0(5, 2, false) PD_KISSUE(7, 1) PD_MF1(5, 2, false)
+            PD_KWAIT(2, 0) PD_MF0(6, 0, false) PD_VPAIR(0, 0, 0) PD_VPAIR(0, 0, 1) PD_MF1(6, 0, false)
+            PD_KWAIT(4, 1) PD_MF0(7, 1, false) PD_VPAIR(0, 0, 2) PD_VPAIR(0, 0, 3) PD_MF1(7, 1, false)
+        } else {
+            PD_VPAIR(0, 0, 0) PD_VPAIR(0, 0, 1) PD_VPAIR(0, 0, 2) PD_VPAIR(0, 0, 3)
+        }
+        PD_PVSTEP(0, 0, 1, 1)
+        PD_PVSTEP(1, 1, 0, 2)
+        PD_PVSTEP(2, 0, 1, 3)
+        PD_VW(6, 1, 0) PD_MFV(3, 1, 0)
+        PD_VW(4, 1, 1) PD_MFV(3, 1, 1)
+        PD_VW(2, 1, 2) PD_MFV(3, 1, 2)
+        PD_VW(0, 1, 3) PD_MFV(3, 1, 3)
+        ka0 = (ka0 + kTileBytes) & kRingMask;
+        vl0 = ((vl0 + kTileBytes) & kRingMask) | kVBase;
+        vh0 = ((vh0 + kTileBytes) & kRingMask) | kVBase;
+        if (last) {
+            // ---- the block is complete: normalise, store O[q][d], start the next one ----
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+            const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+            // rows through this group's 32 KiB of LDS above the rings (the other group's epilogue is a phase -- a barrier -- away),
+            // then buffer stores, ALWAYS 8 per wave (the vmcnt bookkeeping counts them): rows past Lq get an offset beyond the
+            // resource's num_records and the hardware drops them
+            u32x4_t rows[8];
+            attn_rows_through_lds<T>(o, inv, 2 * kPdSlots * kTileBytes + (wv & 3) * 8192, r, h, lane, rows);
+            const int o_boff = __builtin_amdgcn_readfirstlane(cp.bi * o_bs2 + cp.head * o_hs2);
+            const int qrow0 = cp.qb * kQBlock + wave * kQRowsPerWave + (lane >> 4);
+            const uint32_t ocol = (uint32_t)((lane & 15) * 16);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int qrow = qrow0 + 4 * k8;
+                const uint32_t off = qrow < p.lq ? (uint32_t)((int64_t)qrow * p.o_rs * 2) + ocol : 0x80000000u;
+#ifdef PW_X_NOSTORE
+                asm volatile("" :: "v"(rows[k8]), "v"(off));
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(rows[k8], o_rsrc, off, o_boff, 0);
+#endif
+            }
+#pragma unroll
+            for (int i = 0; i < kDT; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+            m_run = -INFINITY;
+            l_run = 0.f;
+            cp.lt = 0;
+            PW_NEXT_BLOCK(cp)
+        } else {
+            ++cp.lt;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PW_NEXT_BLOCK
+#undef PW_DMA_K
+#undef PW_DMA_V
+#undef PW_LOAD_Q
+#undef PW_TAKE_Q
+#undef PD_KISSUE
+#undef PD_KWAIT
+#undef PD_MF0
+#undef PD_MF1
+#undef PD_VPAIR
+#undef PD_VW
+#undef PD_MFV
+#undef PD_PVSTEP
+#undef MAX8
 }
 
 // Merge the key-range partials of each tail block: m = max m_s, O = sum O_s 2^(m_s-m), l likewise; store bf16.
@@ -1637,6 +2048,20 @@ int launch_attn_fr(AttnParams p, hipStream_t st) {
     return FINO_OK;
 }
 
+template <typename T>
+int launch_attn_ppw(AttnParams p, hipStream_t st) {
+    constexpr int smem = 2 * kPdSlots * kKV * 128 * 2 + 32768;      // rings + 32 KiB for a group's output rows: all of the CU's 160 KiB
+    static FinoPerDeviceOnce once;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&attn_ppw_kernel<T>), smem, "fino_attn_fwd")) return rc;
+    p.ws = nullptr; p.all_partial = 0;
+    const int64_t blocks = (int64_t)p.batch * p.heads * p.nqb;
+    const int cap = fino_tune_get(FINO_TUNE_ATTN_WALK_GRID) > 0 ? fino_tune_get(FINO_TUNE_ATTN_WALK_GRID) : device_cus();
+    const int grid = blocks < cap ? (int)blocks : cap;
+    attn_ppw_kernel<T><<<dim3((unsigned)grid), kWaves * 64, smem, st>>>(p);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
 template <typename T, int D, int VAR>
 int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
@@ -1648,7 +2073,19 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     // sequences of the text cross-attention at head_dim 128 (whole blocks only: never for fino_attn_partial)
     {
         const int tk = fino_tune_get(FINO_TUNE_ATTN_KERNEL);
-        if (!p.all_partial && (tk == 3 || ((tk == 0 || tk == 5) && VAR == 1 && D == 128))) return launch_attn_fr<T, D>(p, st);
+        // the walking kernel (one workgroup per CU over a run of q-blocks): short key sequences at head_dim 128 with at least
+        // two blocks per CU (FINO_TUNE_ATTN_KERNEL = 6: wherever it can run)
+        if constexpr (D == 128) {
+            const int nt = (p.lk + kKV - 1) / kKV;
+            const int64_t blocks = (int64_t)p.batch * p.heads * p.nqb;
+            auto span = [&](int64_t bs, int64_t hs, int64_t rs, int64_t rows) {
+                return (((int64_t)p.batch - 1) * bs + ((int64_t)p.heads - 1) * hs + (rows - 1 + 2 * kKV) * rs + 128) * 2;
+            };
+            const bool can = !p.all_partial && nt >= 2 && blocks < (1 << 24) && span(p.k_bs, p.k_hs, p.k_rs, p.lk) < (1ll << 31) &&
+                             span(p.v_bs, p.v_hs, p.v_rs, p.lk) < (1ll << 31) && span(p.o_bs, p.o_hs, p.o_rs, p.lq) < (1ll << 31);
+            if (can && (tk == 6 || (tk == 0 && VAR == 1 && blocks >= 2 * device_cus()))) return launch_attn_ppw<T>(p, st);
+        }
+        if (!p.all_partial && (tk == 3 || ((tk == 0 || tk == 5 || tk == 7) && VAR == 1 && D == 128))) return launch_attn_fr<T, D>(p, st);
     }
     static FinoPerDeviceOnce once_a, once_b;
     if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
@@ -1681,7 +2118,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     const bool w4 = fino_attn_w4_supports(D, p.scale_log2) &&
                     (tune_k == 2 || (tune_k == 0 && D == 64 && p.scale_log2 == 1.0f && p.lk >= 2048));
     bool ppd = false;
-    if constexpr (D == 128) ppd = pingpong && (tune_k == 4 || (tune_k == 0 && VAR == 0));   // 5: the round-3 policy (register-staged)
+    if constexpr (D == 128) ppd = pingpong && (tune_k == 4 || ((tune_k == 0 || tune_k == 7) && VAR == 0));   // 5: the round-3 policy (register-staged)
     if (w4) {
         if (int rc = fino_attn_launch_w4(p, T::kId, D, st)) return rc;
     } else if (ppd) {

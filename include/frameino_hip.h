@@ -47,9 +47,13 @@ const char* fino_last_error(void);
  * ping-pong kernel wherever head_dim is 128, 5 = the round-3 policy (as 0, but register-staged for Lk > 1024); 0 = the policy:
  * free-running for Lk <= 1024 at head_dim 128 (text cross-attention), LDS-DMA-staged ping-pong for Lk > 1024 at head_dim
  * 128, 4-wave for head_dim 64 with the folded scale, register-staged ping-pong otherwise.
+ * 6 = the walking kernel (one workgroup per CU over a run of q-blocks) wherever it can run: head_dim 128, at least two key
+ * tiles, whole blocks; by policy it serves Lk <= 1024 when there are at least two q-blocks per CU, the free-running kernel the
+ * rest; 7 = the policy without the walking kernel.  FINO_TUNE_ATTN_WALK_GRID: workgroups of the walking kernel (0 = one per CU; tests use small counts to make runs of
+ * blocks cross heads and batches on small shapes).
  * FINO_TUNE_ATTN_FP8_KERNEL (fino_attn_fwd_fp8): 1 = the 8-wave ping-pong kernel instead of the free-running 4-wave one. */
 enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_TILE_M = 3,
-       FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_ATTN_FP8_KERNEL = 5, FINO_TUNE_COUNT = 8 };
+       FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_ATTN_FP8_KERNEL = 5, FINO_TUNE_ATTN_WALK_GRID = 6, FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);
 int fino_tune_get(int key);
 

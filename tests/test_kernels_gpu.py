@@ -671,3 +671,37 @@ def test_dma_staged_ping_pong_kernel_equals_the_register_staged_one(b, heads, lq
     finally:
         lib.fino_tune_set(4, 0)
         ops.SPLIT_ATTENTION_TAIL = split
+
+
+@pytest.mark.parametrize("b,heads,lq,lk,grid", [(2, 24, 3000, 512, 0), (1, 3, 300, 77, 2), (2, 2, 129, 1024, 1), (1, 8, 700, 200, 3),
+                                                (2, 5, 520, 128, 7), (1, 24, 1540, 512, 5), (2, 3, 1000, 640, 4), (1, 2, 64, 130, 1)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_walking_attention_kernel_equals_the_ping_pong_kernel(b, heads, lq, lk, grid, dtype):
+    """attn_ppw_kernel (FINO_TUNE_ATTN_KERNEL = 6: one workgroup walks a run of q-blocks, K / V rings streaming across block
+    boundaries, the next block's Q rows prefetched, stores counted into the vmcnt bookkeeping): bit-identical to the one-block
+    ping-pong kernel -- with runs that cross heads and batches (FINO_TUNE_ATTN_WALK_GRID caps the workgroup count), ragged
+    last key tiles, strided q / k / v, rows past Lq untouched"""
+    from frameino_amd import _lib, ops
+    dh = 128
+    d = heads * dh
+    g = torch.Generator(device=DEV).manual_seed(lq * 7 + lk)
+    q = torch.randn(b, lq, d + 64, device=DEV, generator=g).to(dtype)[:, :, :d]
+    kv = torch.randn(b, lk, 2 * d + 64, device=DEV, generator=g).to(dtype)
+    k, v = kv[:, :, :d], kv[:, :, d:2 * d]
+    lib = _lib.lib()
+    split = ops.SPLIT_ATTENTION_TAIL
+    try:
+        ops.SPLIT_ATTENTION_TAIL = False
+        lib.fino_tune_set(4, 1)
+        want = ops.attention(q, k, v, heads)
+        lib.fino_tune_set(4, 6)
+        lib.fino_tune_set(6, grid)
+        for _ in range(2):
+            out = torch.zeros(b, lq + 5, d, device=DEV, dtype=dtype)
+            got = ops.attention(q, k, v, heads, out=out[:, :lq])
+            assert torch.isfinite(got.float()).all() and not out[:, lq:].any()
+            assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    finally:
+        lib.fino_tune_set(4, 0)
+        lib.fino_tune_set(6, 0)
+        ops.SPLIT_ATTENTION_TAIL = split

@@ -25,7 +25,12 @@ def timeit(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-for b, lq, lk in [(2, 12320, 12320), (1, 12320, 12320), (2, 3080, 12320), (1, 1540, 12320), (2, 25088, 25088)]:
+SHAPES = [(2, 12320, 12320), (1, 12320, 12320), (2, 3080, 12320), (1, 1540, 12320), (2, 25088, 25088)]
+if os.environ.get("FINO_AB_CROSS"):      # the text cross-attention shapes (1 GPU, 4- and 8-way token shards)
+    SHAPES = [(2, 12320, 512), (1, 12320, 512), (2, 3080, 512), (2, 1540, 512), (2, 25088, 512)]
+if os.environ.get("FINO_AB_SHAPES"):     # "b,lq,lk;b,lq,lk;..."
+    SHAPES = [tuple(int(x) for x in t.split(",")) for t in os.environ["FINO_AB_SHAPES"].split(";")]
+for b, lq, lk in SHAPES:
     qkv = torch.randn(b, max(lq, lk), 3 * D, device="cuda").bfloat16()
     q, k, v = qkv[:, :lq, :D], qkv[:, :lk, D:2 * D], qkv[:, :lk, 2 * D:]
     o = torch.empty(b, lq, D, device="cuda", dtype=torch.bfloat16)

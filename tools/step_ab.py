@@ -41,9 +41,9 @@ settings = {"r01 (group_m 4, no dedup, 8-wave attention)": (4, False, 1, False),
             "+ 4-wave attention kernel": (0, True, 0, False), "+ softmax scale folded into q (MFMA fold)": (0, True, 0, True)}
 if "--tiles" in sys.argv:      # round 3: GEMM tile heights (FINO_TUNE_GEMM_TILE_M: 8 = 256-row tiles only, 0 = planned), default kernels otherwise
     settings = {"256-row GEMM tiles only": (0, True, 1, False, 8), "planned GEMM tile heights": (0, True, 1, False, 0)}
-if "--cross" in sys.argv:      # round 3: text cross-attention on the 8-wave ping-pong kernel (tune 1) vs the free-running one (default policy)
-    settings = {"cross-attention: 8-wave ping-pong kernel": (0, True, 1, False, 0),
-                "cross-attention: free-running kernel (default)": (0, True, 0, False, 0)}
+if "--cross" in sys.argv:      # round 4: text cross-attention on the free-running kernel vs the walking ping-pong kernel
+    settings = {"cross-attention: free-running kernel (tune 7, the round-3 choice)": (0, True, 7, False, 0),
+                "cross-attention: walking ping-pong kernel (the policy)": (0, True, 0, False, 0)}
 if "--ppd" in sys.argv:        # round 4: self-attention on the register-staged ping-pong kernel
     # vs the LDS-DMA-staged one; the text cross-attention stays on the free-running kernel in both
     settings = {"self-attention: register-staged ping-pong kernel (tune 5, the round-3 policy)": (0, True, 5, False, 0),
@@ -52,6 +52,7 @@ res = {k: [] for k in settings}
 
 
 attn = {}
+attn_c = {}
 
 
 def run(gm, dedup, attn_k, fold, steps, tile_m=0):
@@ -61,12 +62,14 @@ def run(gm, dedup, attn_k, fold, steps, tile_m=0):
     model.fold_softmax_scale = fold
     model.dedup_shared_prefix = dedup
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    with torch.no_grad(), ops.KernelTimer({"attn_self"}) as kt:
+    with torch.no_grad(), ops.KernelTimer({"attn_self", "attn_cross"}) as kt:
         for _ in range(steps):
             pipe._step(st)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    attn.setdefault((gm, dedup, attn_k, fold, tile_m)[:len(next(iter(settings.values())))], []).append(kt.summary()["attn_self"]["total_ms"] / steps)
+    key = (gm, dedup, attn_k, fold, tile_m)[:len(next(iter(settings.values())))]
+    attn.setdefault(key, []).append(kt.summary()["attn_self"]["total_ms"] / steps)
+    attn_c.setdefault(key, []).append(kt.summary()["attn_cross"]["total_ms"] / steps)
     return ms
 
 
@@ -80,5 +83,6 @@ lib.fino_tune_set(4, 0)
 lib.fino_tune_set(3, 0)
 for k, v in res.items():
     a_ms = statistics.median(attn[settings[k]][1:])
-    print(f"    self-attention launches {a_ms:7.2f} ms/step, everything else {statistics.median(v) - a_ms:7.2f}")
+    c_ms = statistics.median(attn_c[settings[k]][1:])
+    print(f"    self-attention launches {a_ms:7.2f} ms/step, text cross-attention launches {c_ms:6.2f}, everything else {statistics.median(v) - a_ms - c_ms:7.2f}")
     print(f"{k:44s} median {statistics.median(v):7.2f} ms/step  (min {min(v):.2f}, max {max(v):.2f})")
