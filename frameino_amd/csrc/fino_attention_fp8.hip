@@ -1093,19 +1093,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
         continue;
     }
     const float inv = 1.0f / lacc[0];
-    if (qrow < p.lq) {
-        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
+    {
+        // whole-row stores through the first 64 KiB of the (now idle) rings, 8 KiB per wave: attn_rows_through_lds
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile have landed ...
+        __builtin_amdgcn_s_barrier();                      // ... for every wave
+        u32x4_t rows[8];
+        attn_rows_through_lds<T>(o, inv, (uint32_t)((tid >> 6) * 8192), lane & 31, g, lane, rows);
+        const int qrow0 = qrow - (lane & 31) + (lane >> 4);
 #pragma unroll
-        for (int d4 = 0; d4 < 4; ++d4) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = d4 * 32 + 8 * gq + 4 * g;
-                uint32_t w0 = (uint32_t)T::from_f32(o[d4][4 * gq + 0] * inv) |
-                              ((uint32_t)T::from_f32(o[d4][4 * gq + 1] * inv) << 16);
-                uint32_t w1 = (uint32_t)T::from_f32(o[d4][4 * gq + 2] * inv) |
-                              ((uint32_t)T::from_f32(o[d4][4 * gq + 3] * inv) << 16);
-                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
-            }
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int qr = qrow0 + 4 * k8;
+            if (qr < p.lq) *reinterpret_cast<u32x4_t*>(op + (int64_t)qr * p.o_rs + (lane & 15) * 8) = rows[k8];
         }
     }
   }   // piece
