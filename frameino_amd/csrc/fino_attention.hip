@@ -1192,14 +1192,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     const float inv = 1.0f / l_run;
     {
         // every wave is past its last matrix phase (the barrier above): the K ring's first 64 KiB take the output rows, 8 KiB per wave
+        int le = lane;
+        asm volatile("" : "+v"(le));       // opaque: or the epilogue's per-lane offsets are computed before the loop and kept live
         u32x4_t rows[8];
-        attn_rows_through_lds<T>(o, inv, (uint32_t)(wv * 8192), r, h, lane, rows);
-        const int qrow0 = qb * kQBlock + wave * kQRowsPerWave + (lane >> 4);
-#pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const int qr = qrow0 + 4 * k8;
-            if (qr < p.lq) *reinterpret_cast<u32x4_t*>(op + (int64_t)qr * p.o_rs + (lane & 15) * 8) = rows[k8];
-        }
+        attn_rows_through_lds<T, D>(o, inv, (uint32_t)(wv * 8192), le & 31, le >> 5, le, rows);
+        attn_store_rows<D>(rows, op, p.o_rs, qb * kQBlock + wave * kQRowsPerWave, p.lq, le);
     }
   }   // piece
 }
@@ -1535,7 +1532,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnPara
             // then buffer stores, ALWAYS 8 per wave (the vmcnt bookkeeping counts them): rows past Lq get an offset beyond the
             // resource's num_records and the hardware drops them
             u32x4_t rows[8];
-            attn_rows_through_lds<T>(o, inv, 2 * kPdSlots * kTileBytes + (wv & 3) * 8192, r, h, lane, rows);
+            attn_rows_through_lds<T, D>(o, inv, 2 * kPdSlots * kTileBytes + (wv & 3) * 8192, r, h, lane, rows);
             const int o_boff = __builtin_amdgcn_readfirstlane(cp.bi * o_bs2 + cp.head * o_hs2);
             const int qrow0 = cp.qb * kQBlock + wave * kQRowsPerWave + (lane >> 4);
             const uint32_t ocol = (uint32_t)((lane & 15) * 16);

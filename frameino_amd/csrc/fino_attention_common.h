@@ -106,20 +106,22 @@ __device__ __forceinline__ int k_lds_off(int row, int ch) {
 }  // namespace fino_attn_ns
 
 #if defined(__HIPCC__)
-// One wave's O^T accumulators (32 query rows x 128 channels, scaled by `inv`) -> T rows, through 8 KiB of LDS at `lds_base`: the
-// lane that holds 4 consecutive channels of a row writes their 8 bytes into an XOR-swizzled [32 rows][256 B] image; then 16 lanes
-// read one whole row as 16-byte pieces, rows[k] = piece (lane & 15) of row 4 k + (lane >> 4).  A store of rows[k] covers 4
-// complete rows (8 whole cache lines); the direct form -- 16 stores of 8 bytes per lane -- touches 32 lines per instruction, and
-// cost the short-key kernel 4.7 us per q-block (profiles/r04_attn_ppw_nostore.txt).  All LDS traffic is inline asm (the compiler
-// would drain vmcnt in front of LDS accesses it can see while LDS-DMA is in flight); the wave reads only what it wrote.
-template <typename T>
-__device__ __forceinline__ void attn_rows_through_lds(const f32x16_t (&o)[4], float inv, uint32_t lds_base, int r, int h,
-                                                      int lane, u32x4_t (&rows)[8]) {
+// One wave's O^T accumulators (32 query rows x D channels, scaled by `inv`) -> T rows, through 32 x 2 D bytes of LDS at
+// `lds_base`: the lane that holds 4 consecutive channels of a row writes their 8 bytes into an XOR-swizzled [32 rows][2 D B]
+// image; then D / 8 lanes read one whole row as 16-byte pieces, rows[k] = piece (lane % (D / 8)) of row
+// k * (512 / D) + lane / (D / 8).  A store of rows[k] covers 4 (head_dim 128) or 8 (64) complete rows = 8 whole cache lines; the
+// direct form -- 16 (8) stores of 8 bytes per lane -- touches 32 lines per instruction, and cost the short-key kernel 4.7 us per
+// q-block (profiles/r04_attn_ppw.txt).  All LDS traffic is inline asm (the compiler would drain vmcnt in front of LDS accesses
+// it can see while LDS-DMA is in flight); the wave reads only what it wrote.
+template <typename T, int D>
+__device__ __forceinline__ void attn_rows_through_lds(const f32x16_t (&o)[D / 32], float inv, uint32_t lds_base, int r, int h,
+                                                      int lane, u32x4_t (&rows)[D / 16]) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-    const uint32_t wbase = lds_base + (uint32_t)(r * 256 + (h << 3));
-    const uint32_t rsw = (uint32_t)(r & 15);
+    constexpr int kC = D / 8;                         // 16-byte pieces per row
+    const uint32_t wbase = lds_base + (uint32_t)(r * (2 * D) + (h << 3));
+    const uint32_t rsw = (uint32_t)(r & (kC - 1));
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) | ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
@@ -129,18 +131,29 @@ __device__ __forceinline__ void attn_rows_through_lds(const f32x16_t (&o)[4], fl
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint32_t row0 = (uint32_t)(lane >> 4), c = (uint32_t)(lane & 15);
+    const uint32_t row0 = (uint32_t)(lane / kC), c = (uint32_t)(lane % kC);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t row = 4 * k + row0;
-        const uint32_t a = lds_base + row * 256 + ((c ^ (row & 15)) << 4);
+    for (int k = 0; k < D / 16; ++k) {
+        const uint32_t row = (uint32_t)(k * (64 / kC)) + row0;
+        const uint32_t a = lds_base + row * (2 * D) + ((c ^ (row & (kC - 1))) << 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(rows[k]) : "v"(a) : "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(rows[0]), "+v"(rows[1]), "+v"(rows[2]), "+v"(rows[3]), "+v"(rows[4]), "+v"(rows[5]), "+v"(rows[6]), "+v"(rows[7])
-                 :: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < D / 16; ++k) asm volatile("" : "+v"(rows[k]));
 }
-
+// the global side of it: rows[k] -> row (first_row + k * (512 / D) + lane / (D / 8)) of o, 16-byte piece lane % (D / 8)
+template <int D>
+__device__ __forceinline__ void attn_store_rows(const u32x4_t (&rows)[D / 16], uint16_t* op, int64_t o_rs, int first_row, int lq,
+                                                int lane) {
+    constexpr int kC = D / 8;
+    const int row0 = first_row + lane / kC;
+#pragma unroll
+    for (int k = 0; k < D / 16; ++k) {
+        const int qr = row0 + k * (64 / kC);
+        if (qr < lq) *reinterpret_cast<u32x4_t*>(op + (int64_t)qr * o_rs + (lane % kC) * 8) = rows[k];
+    }
+}
 #endif
 
 // the tail split's plan and the merge of its (O, m, l) partials, for kernels outside fino_attention.hip that write the same

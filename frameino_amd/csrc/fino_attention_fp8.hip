@@ -573,20 +573,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         continue;
     }
     const float inv = 1.0f / l_run;
-    if (qrow < p.lq) {
-        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
-#pragma unroll
-        for (int dt = 0; dt < kDT; ++dt) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = dt * 32 + 8 * gq + 4 * g;
-                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * gq + 0] * inv) |
-                              ((uint32_t)T::from_f32(o[dt][4 * gq + 1] * inv) << 16);
-                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * gq + 2] * inv) |
-                              ((uint32_t)T::from_f32(o[dt][4 * gq + 3] * inv) << 16);
-                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
-            }
-        }
+    {
+        // whole-row stores through the (now idle) rings, 4 KiB per wave: attn_rows_through_lds
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile have landed ...
+        __builtin_amdgcn_s_barrier();                      // ... for every wave of the workgroup
+        int le = lane;
+        asm volatile("" : "+v"(le));       // opaque: or the epilogue's per-lane offsets are computed before the loop and spilled
+        u32x4_t rows[kD8 / 16];
+        attn_rows_through_lds<T, kD8>(o, inv, (uint32_t)((tid >> 6) * 4096), le & 31, le >> 5, le, rows);
+        attn_store_rows<kD8>(rows, op, p.o_rs, qrow - (lane & 31), p.lq, le);
     }
   }   // piece
 }
@@ -814,6 +809,8 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
 #undef FR_MASK
 #undef FR_SWAPMAX
 
+    // (direct 8-byte stores: the staged whole-row form of the other kernels -- attn_rows_through_lds -- pushed this kernel, which
+    // lives at the 168-register limit of three workgroups per CU, into scratch spills inside its loop)
     const float inv = 1.0f / lacc[0];
     if (qrow < p.lq) {
         uint16_t* orow = op + (int64_t)qrow * p.o_rs;
@@ -1097,14 +1094,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
         // whole-row stores through the first 64 KiB of the (now idle) rings, 8 KiB per wave: attn_rows_through_lds
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile have landed ...
         __builtin_amdgcn_s_barrier();                      // ... for every wave
+        int le = lane;
+        asm volatile("" : "+v"(le));       // opaque: or the epilogue's per-lane offsets are computed before the loop and spilled
         u32x4_t rows[8];
-        attn_rows_through_lds<T>(o, inv, (uint32_t)((tid >> 6) * 8192), lane & 31, g, lane, rows);
-        const int qrow0 = qrow - (lane & 31) + (lane >> 4);
-#pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const int qr = qrow0 + 4 * k8;
-            if (qr < p.lq) *reinterpret_cast<u32x4_t*>(op + (int64_t)qr * p.o_rs + (lane & 15) * 8) = rows[k8];
-        }
+        attn_rows_through_lds<T, 128>(o, inv, (uint32_t)((tid >> 6) * 8192), le & 31, le >> 5, le, rows);
+        attn_store_rows<128>(rows, op, p.o_rs, qrow - r, p.lq, le);
     }
   }   // piece
 }

@@ -794,21 +794,24 @@ void attn_w4_kernel(const AttnParams p) {
             continue;
         }
         const float inv = 1.0f / l;
-        uint16_t* orow = op + (int64_t)(qrow[qs] < p.lq ? qrow[qs] : 0) * p.o_rs;
+        // whole-row stores through the (now idle) rings, 32 x 2 D bytes per wave: attn_rows_through_lds
+        if (qs == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile have landed ...
+            __builtin_amdgcn_s_barrier();                      // ... for every wave of the workgroup
+        }
+        f32x16_t ov[kDT];
 #pragma unroll
         for (int dt = 0; dt < kDT; ++dt) {
             float f[16];
             w4_o_read(4 * qs + dt, f);
-            if (qrow[qs] < p.lq) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = dt * 32 + 8 * g + 4 * h;
-                    const uint32_t w0 = w4_pack2<T>(f[4 * g + 0] * inv, f[4 * g + 1] * inv);
-                    const uint32_t w1 = w4_pack2<T>(f[4 * g + 2] * inv, f[4 * g + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
-                }
-            }
+            for (int j = 0; j < 16; ++j) ov[dt][j] = f[j];
         }
+        int le = lane;
+        asm volatile("" : "+v"(le));       // opaque: or the epilogue's per-lane offsets are computed before the loop and spilled
+        u32x4_t rows[D / 16];
+        attn_rows_through_lds<T, D>(ov, inv, (uint32_t)(wave * (64 * D)), le & 31, le >> 5, le, rows);
+        attn_store_rows<D>(rows, op, p.o_rs, qrow[qs] - (lane & 31), p.lq, le);
     }
   }   // piece
 }
