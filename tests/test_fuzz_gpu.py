@@ -140,3 +140,47 @@ def test_attention_partials_random_key_splits(case):
     assert torch.isfinite(merged.float()).all()
     assert rel_rms(merged, ref) < 2.0 ** -6, rel_rms(merged, ref)
     assert (merged.float() - ref).abs().max().item() < 0.06
+
+
+def _walk_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        heads = rng.choice([1, 2, 3, 5, 8, 12, 24])
+        b = rng.choice([1, 2, 3])
+        lq = rng.choice([rng.randint(1, 300), rng.randint(300, 2600), 256 * rng.randint(1, 9), 256 * rng.randint(1, 9) + 1])
+        lk = rng.choice([rng.randint(65, 200), rng.randint(200, 1024), 64 * rng.randint(2, 16), 512])
+        grid = rng.choice([0, 1, 2, 3, 5, 8, 13, 64])
+        out.append((b, heads, lq, lk, grid))
+    return out
+
+
+@pytest.mark.parametrize("case", _walk_cases(FUZZ_N, 4321 + FUZZ_SEED), ids=lambda c: "b%d_h%d_q%d_k%d_g%d" % c)
+def test_walking_attention_kernel_random_shapes_and_runs(case):
+    """attn_ppw_kernel (head_dim 128, whole q-blocks, 2 .. 16 key tiles) with random workgroup counts, so that a workgroup's
+    run of q-blocks starts, ends and crosses heads and batches anywhere: against fp32 SDPA, and bit-equal to the policy's
+    kernels on the same inputs"""
+    from frameino_amd import _lib, ops
+    b, heads, lq, lk, grid = case
+    dh = 128
+    g = torch.Generator(device=DEV).manual_seed(hash(case) & 0xffff)
+    q = torch.randn(b, lq, heads * dh, device=DEV, generator=g).bfloat16()
+    k = torch.randn(b, lk, heads * dh, device=DEV, generator=g).bfloat16()
+    v = torch.randn(b, lk, heads * dh, device=DEV, generator=g).bfloat16()
+    lib = _lib.lib()
+    split = ops.SPLIT_ATTENTION_TAIL
+    try:
+        ops.SPLIT_ATTENTION_TAIL = False
+        lib.fino_tune_set(4, 1)
+        want = ops.attention(q, k, v, heads)
+        lib.fino_tune_set(4, 6)
+        lib.fino_tune_set(6, grid)
+        o = ops.attention(q, k, v, heads)
+    finally:
+        lib.fino_tune_set(4, 0)
+        lib.fino_tune_set(6, 0)
+        ops.SPLIT_ATTENTION_TAIL = split
+    ref = sdpa_ref(q, k, v, heads)
+    assert torch.isfinite(o.float()).all()
+    assert rel_rms(o, ref) < 2.0 ** -6, rel_rms(o, ref)
+    assert torch.equal(o, want), (o.float() - want.float()).abs().max().item()
