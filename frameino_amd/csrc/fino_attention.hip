@@ -11,9 +11,12 @@
 //     ds_read_b64_tr_b16 in the same permuted order -- no cross-lane movement of P, no LDS round trip for P.
 //   * K/V tiles of 64 keys are register-staged (buffer/global_load_dwordx4, then ds_write_b128) into a double-buffered,
 //     XOR-swizzled LDS image that is conflict-free for both the row reads (K) and the transposed reads (V).
-//   * Two main loops: attn_pp_kernel (default) -- PING-PONG: the two waves of a SIMD alternate a softmax phase and a
-//     32-MFMA matrix phase, one phase apart, two barriers per tile -- and attn_fwd_kernel, the earlier one-barrier
-//     loop in which every wave interleaves S(t+1) MFMAs with the exp of S(t) (FINO_ATTN_PP=0, kept for A/B).
+//   * Main loops: attn_pp_kernel -- PING-PONG: the two waves of a SIMD alternate a softmax phase and a 32-MFMA matrix
+//     phase, one phase apart, two barriers per tile -- and attn_fwd_kernel, the earlier one-barrier loop in which every
+//     wave interleaves S(t+1) MFMAs with the exp of S(t) (FINO_ATTN_PP=0, kept for A/B).  Round 4, head_dim 128:
+//     attn_ppd_kernel (the default for long key sequences: the ping-pong loop with K/V by LDS-DMA into four-slot rings,
+//     LDS reads issued between the MFMAs) and attn_ppw_kernel (short key sequences: one workgroup per CU walks a run of
+//     q-blocks without draining).  attn_fr_kernel (round 3): 4 waves, two workgroups per CU.  All give the same bits.
 //   * Tail split: the key tiles of an XCD's last, partial round of blocks are dealt to all its CUs (fino_attn_fwd_ws).
 //   * q/k/v are read in place from the fused-QKV GEMM output ([L, 3*H*Dh], strides passed in), o is written
 //     token-major [L, H*Dh]: no transposes anywhere.
