@@ -763,8 +763,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
 // two), and 16 staging registers.  A slot is re-filled only after BOTH groups have passed the matrix phase that read it:
 //   K(j) is last read by group 1's matrix(j-1) (global phase 2j), V(j) by its matrix(j) (phase 2j+2); group g issues, in its
 //   softmax(t) (phase 2t+g), K(t+g+3) into the slot of K(t+g-1) and V(t+g+2) into the slot of V(t+g-2): both dead by then;
-//   every wave ends a softmax phase with vmcnt(8) -- all but its last two phases' DMAs have landed -- and the barrier
-//   publishes them one full tile before their first reader.
+//   every wave ends a softmax phase with vmcnt(4) -- everything it issued before this phase (4 DMAs per phase) has landed --
+//   so a tile is published a whole phase before its first reader, whose first K fragments are fetched across the barrier
+//   (PD_PREK; vmcnt(8) without it).  In the matrix phase the LDS reads are issued BETWEEN the MFMAs that shadow them: an
+//   in-order wave issues nothing while its MFMA waits for the pipe, so reads queued behind a run of MFMAs would start late.
+//   The row maxima of S(t) open softmax(t) (out of the P.V shadow, where they delayed MFMAs), waves 4-7 run at static
+//   priority 1, and the output rows leave through LDS as whole 256-byte rows (attn_rows_through_lds).
 // Every LDS read of the loop is inline asm with hand-counted lgkmcnt waits (the compiler would put vmcnt(0) in front of any
 // LDS read it can see while a DMA is in flight, see attn_fr_kernel).  Block map, tail split, partial layout and arithmetic
 // are attn_pp_kernel's: results are bit-identical (tests/test_kernels_gpu.py).
