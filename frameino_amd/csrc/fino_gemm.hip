@@ -510,8 +510,16 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(t2)
         // ---------------- COMPUTE(t): 8 MI MFMAs from registers ----------------
+#ifndef GP_ORDER
+#define GP_ORDER 3         /* A/B knob (same bits): 0 = the W fragment (MFMA A operand) changes with every MFMA, the activation fragment
+                              (B operand) every fourth; 1 = the activation fragment changes with every MFMA, the W fragment every MI-th;
+                              2 / 3 = serpentine walks in which exactly ONE operand changes between consecutive MFMAs.  Six block GEMMs
+                              at M = 24640 (profiles/r04_gemm_mfma_order.txt): 5500 / 5480 / 5460 / 5454 us -- fewer operand-register
+                              switches per MFMA draw less power, and the step is power-capped */
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+#if GP_ORDER == 0
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -519,6 +527,35 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
                     acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
                                           acc[i][j]);
             }
+#elif GP_ORDER == 1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
+                                          acc[i][j]);
+            }
+#elif GP_ORDER == 2        /* serpentine over i inside j: exactly ONE operand changes between consecutive MFMAs */
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int ii = 0; ii < MI; ++ii) {
+                    const int i = ((j + 4 * kk) & 1) ? MI - 1 - ii : ii;
+                    acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
+                                          acc[i][j]);
+                }
+            }
+#else                      /* 3: serpentine over j inside i */
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = ((i + MI * kk) & 1) ? 3 - jj : jj;
+                    acc[i][j] = T::mfma16(__builtin_bit_cast(vec8, wf[kk][j]), __builtin_bit_cast(vec8, af[kk][i]),
+                                          acc[i][j]);
+                }
+            }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my pieces of tile t+1, issued one phase ago

@@ -193,9 +193,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_mxfp8_kernel(const Fp8Params
         acc[I_][J_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv_, av_, acc[I_][J_], 0, 0, (J_), sw_pk,  \
                                                                        (I_) & 3, sa_pk[(I_) >> 2]);               \
     }
+        // serpentine over the columns: exactly one operand register set changes between consecutive MFMAs (as the bf16 loop,
+        // fino_gemm.hip GP_ORDER 3: fewer operand switches draw less power)
 #define F8_ROW(I_) F8_MMA(I_, 0) F8_MMA(I_, 1) F8_MMA(I_, 2) F8_MMA(I_, 3)
-        F8_ROW(0) F8_ROW(1) F8_ROW(2) F8_ROW(3) F8_ROW(4) F8_ROW(5) F8_ROW(6) F8_ROW(7)
+#define F8_WOR(I_) F8_MMA(I_, 3) F8_MMA(I_, 2) F8_MMA(I_, 1) F8_MMA(I_, 0)
+        F8_ROW(0) F8_WOR(1) F8_ROW(2) F8_WOR(3) F8_ROW(4) F8_WOR(5) F8_ROW(6) F8_WOR(7)
 #undef F8_ROW
+#undef F8_WOR
 #undef F8_MMA
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
