@@ -412,16 +412,19 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         w_off[q] = (uint32_t)((gn * p.ldw + sk) * 2);
     }
     // my A piece QI_ (a compile-time index; group 1 has NA1 <= NA0 of them)
+#ifndef GP_DMA_AUX
+#define GP_DMA_AUX 0       /* A/B knob: cache-policy bits of the operand DMAs (1 = sc0, 2 = nt, 16 = sc1) */
+#endif
 #define PP_DMA_A(STAGE_, KT_, QI_)                                                                                \
     if ((QI_) < NA1 || wm == 0)                                                                                   \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
             a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + ((aq0 + (QI_)) * 32 + wn * 8) * 128), 16,    \
-            a_off[QI_], CONV ? ck * (BK * 2) : (ABLK ? ablk_koff(p, kb + (KT_)) : (kb + (KT_)) * (BK * 2)), 0, 0);
+            a_off[QI_], CONV ? ck * (BK * 2) : (ABLK ? ablk_koff(p, kb + (KT_)) : (kb + (KT_)) * (BK * 2)), 0, GP_DMA_AUX);
 #define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
     if (!CONV || (Q_) < w_pieces)                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
             w_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + kTileBytes + ((Q_) * 32 + wn * 8) * 128), 16, \
-            w_off[CONV ? 0 : (Q_)], (kb + (KT_)) * (BK * 2) + (CONV ? (Q_) * w_piece_bytes : 0), 0, 0);
+            w_off[CONV ? 0 : (Q_)], (kb + (KT_)) * (BK * 2) + (CONV ? (Q_) * w_piece_bytes : 0), 0, GP_DMA_AUX);
 
     const int frow = lane & 15;
     const int pch0 = (lane >> 4) ^ (frow >> 1);
