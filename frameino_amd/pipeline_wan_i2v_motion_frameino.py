@@ -289,7 +289,7 @@ class WanImageToVideoPipeline:
                 z = self.vae.encode(ID_tensor[:, :, fi].unsqueeze(2)).latent_dist.mode().repeat(batch_size, 1, 1, 1, 1)
                 ids.append(self._norm_latents(z, dtype))
             id_cond = torch.cat(ids, dim=2)
-            traj_latents = torch.cat([traj_latents, torch.zeros_like(id_cond)], dim=2)
+            traj_latents = torch.cat([traj_latents, torch.zeros_like(id_cond[:traj_latents.shape[0]])], dim=2)
         mask = torch.ones(1, 1, nlf, lh, lw, dtype=dtype, device=device)
         mask[:, :, 0] = 0
         return latents, cond, traj_latents, id_cond, mask
@@ -411,7 +411,20 @@ class WanImageToVideoPipeline:
     def denoise(self, latents, condition, traj_latents, id_latent, first_frame_mask, prompt_embeds,
                 negative_prompt_embeds, guidance_scale, num_inference_steps, attention_kwargs=None,
                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), timesteps_set=False):
-        """reference :809-913 on batch-1 tensors.  Returns the final latents [1, C, F, h, w] fp32."""
+        """reference :809-913.  Returns the final latents [B, C, F, h, w] fp32.  The loop state is one sample's (the app
+        and the evaluation scripts run batch 1); a batch -- a list of prompts, num_videos_per_prompt > 1 -- runs sample by sample:
+        the samples of the reference's batched loop never meet, every one sees the noise row `prepare_latents` drew for it."""
+        if latents.shape[0] > 1:
+            def row(t, i):
+                return t if t is None or t.shape[0] == 1 else t[i:i + 1]
+            outs = []
+            for i in range(latents.shape[0]):
+                cb = callback_on_step_end
+                outs.append(self.denoise(latents[i:i + 1], row(condition, i), row(traj_latents, i), row(id_latent, i),
+                                         row(first_frame_mask, i), row(prompt_embeds, i), row(negative_prompt_embeds, i),
+                                         guidance_scale, num_inference_steps, attention_kwargs, cb,
+                                         callback_on_step_end_tensor_inputs, timesteps_set=True if timesteps_set or i > 0 else False))
+            return torch.cat(outs, dim=0)
         dev = latents.device
         if not timesteps_set:
             self.scheduler.set_timesteps(num_inference_steps, device=dev)

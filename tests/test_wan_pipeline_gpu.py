@@ -102,6 +102,39 @@ def test_full_call_image_to_video_vs_reference_run(golden):
     assert rel_rms(lat, a["out_latents"]) < 6e-2
 
 
+def test_a_batch_runs_sample_by_sample_and_equals_the_single_calls(golden):
+    """num_videos_per_prompt / lists of prompts (reference `__call__` :594, :475-480): the mirror's loop state is one sample's, a
+    batch runs sample by sample -- every row of a 2-sample call equals the call on that row's noise and prompt alone (the full
+    `__call__`: VAE encodes, loop, decode), and the denoise loop alone likewise"""
+    import PIL.Image
+    from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
+    from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from tests.test_wan_vae_gpu import _vae
+    cfg, sd, a = golden("wan_pipe_tiny")
+    m = hip_wan_model(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}, DEV)
+    vae, _ = _vae(golden, "wan_pipe_tiny", prefix="vae")
+    pipe = WanImageToVideoPipeline(vae=vae, scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=m,
+                                   expand_timesteps=True)
+    img = PIL.Image.fromarray(a["image"].numpy() if hasattr(a["image"], "numpy") else a["image"])
+    h, w = img.size[1], img.size[0]
+    g = torch.Generator().manual_seed(9)
+    lat2 = torch.cat([a["latents0"], torch.randn(a["latents0"].shape, generator=g)], dim=0)
+    pe2 = torch.cat([a["prompt_embeds"], a["prompt_embeds"].flip(1)], dim=0)
+    ne2 = torch.cat([a["negative_embeds"], a["negative_embeds"]], dim=0)
+    kw = dict(image=img, traj_tensor=a["traj"], ID_tensor=a["id_tensor"], height=h, width=w, num_frames=a["traj"].shape[0],
+              num_inference_steps=int(a["steps"]), guidance_scale=float(a["guidance"]), output_type="np")
+    both = pipe(prompt_embeds=pe2, negative_prompt_embeds=ne2, latents=lat2.clone(), **kw).frames
+    assert both.shape[0] == 2
+    for i in range(2):
+        one = pipe(prompt_embeds=pe2[i:i + 1], negative_prompt_embeds=ne2[i:i + 1], latents=lat2[i:i + 1].clone(), **kw).frames
+        assert (torch.from_numpy(both[i:i + 1]) == torch.from_numpy(one)).all()
+    assert not (torch.from_numpy(both[0]) == torch.from_numpy(both[1])).all()
+    # num_videos_per_prompt = 2 from one prompt: two noise rows drawn by one generator, two different videos
+    out = pipe(prompt_embeds=pe2[:1], negative_prompt_embeds=ne2[:1], num_videos_per_prompt=2,
+               generator=torch.Generator().manual_seed(3), **kw).frames
+    assert out.shape[0] == 2 and not (torch.from_numpy(out[0]) == torch.from_numpy(out[1])).all()
+
+
 def test_check_inputs_errors_match_reference_messages(golden):
     pipe, a = _pipe(golden)
     with pytest.raises(ValueError, match="divisible by 16"):
