@@ -784,11 +784,13 @@ constexpr int kPdSlots = 4;
 #ifndef PD_MAX_SOFTMAX
 #define PD_MAX_SOFTMAX 1   /* 1: the row maxima of S(t) open softmax(t) instead of riding in the P.V shadow of matrix(t-1) */
 #endif
-template <typename T, int VAR>
+template <typename T, int D, int VAR>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int D = 128;
-    constexpr int kTileBytes = kKV * D * 2;                  // 16 KiB
+    constexpr int kTileBytes = kKV * D * 2;                  // 16 KiB (head_dim 128) / 8 KiB (64)
+    constexpr int kC = D / 8;                                // 16-byte chunks per row
+    constexpr int kRPP = 1024 / (2 * D);                     // tile rows per 1-KiB DMA piece
+    constexpr int kPW = kTileBytes / 1024 / kWaves;          // DMA pieces per wave and tile, K and V each: 2 / 1
     constexpr int kKS = D / 16;
     constexpr int kDT = D / 32;
     constexpr int kVBase = kPdSlots * kTileBytes;            // V ring behind the K ring
@@ -843,22 +845,22 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     //      key fail the resource's range check and the DMA writes zeros (masked in the ragged last tile) ----
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int grp = wv >> 2;
-    const int rip = lane >> 4, pos = lane & 15;
-    const int srow = wv * 4 + rip;
-    const int swz = (lds_off<D>(srow, 0) >> 4) & 15;
-    const uint32_t k_voff = (uint32_t)((srow * p.k_rs + ((pos ^ swz) << 3)) * 2);
-    const uint32_t v_voff = (uint32_t)((srow * p.v_rs + ((pos ^ swz) << 3)) * 2);
+    const int rip = lane / kC, pos = lane % kC;
+    const int srow = wv * kRPP + rip;
+    const int kswz = (k_lds_off<D>(srow, 0) >> 4) & (kC - 1), vswz = (lds_off<D>(srow, 0) >> 4) & (kC - 1);
+    const uint32_t k_voff = (uint32_t)((srow * p.k_rs + ((pos ^ kswz) << 3)) * 2);
+    const uint32_t v_voff = (uint32_t)((srow * p.v_rs + ((pos ^ vswz) << 3)) * 2);
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)kp, 0, (int)((((int64_t)lk - 1) * p.k_rs + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)vp, 0, (int)((((int64_t)lk - 1) * p.v_rs + D) * 2), 0x00020000);
-    const int k_piece_bytes = (int)(32 * p.k_rs * 2), v_piece_bytes = (int)(32 * p.v_rs * 2);
+    const int k_piece_bytes = (int)(8 * kRPP * p.k_rs * 2), v_piece_bytes = (int)(8 * kRPP * p.v_rs * 2);
     const int k_tile_bytes = (int)(kKV * p.k_rs * 2), v_tile_bytes = (int)(kKV * p.v_rs * 2);
     // tile index clamped to nt: tile nt lies wholly past the last key (zeros), and the scalar offset stays inside 32 bits
 #define PD_DMA_K(TILE_)                                                                                      \
     {                                                                                                        \
         const int tl_ = (TILE_) < nt ? (TILE_) : nt;                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < kPW; ++i_)                                                   \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
                 k_rsrc, (FINO_LDS void*)(smem + ((TILE_) & (kPdSlots - 1)) * kTileBytes + (8 * i_ + wv) * 1024), 16, \
                 k_voff, tl_ * k_tile_bytes + i_ * k_piece_bytes, 0, 0);                                      \
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 #define PD_DMA_V(TILE_)                                                                                      \
     {                                                                                                        \
         const int tl_ = (TILE_) < nt ? (TILE_) : nt;                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < kPW; ++i_)                                                   \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                        \
                 v_rsrc, (FINO_LDS void*)(smem + kVBase + ((TILE_) & (kPdSlots - 1)) * kTileBytes + (8 * i_ + wv) * 1024), \
                 16, v_voff, tl_ * v_tile_bytes + i_ * v_piece_bytes, 0, 0);                                  \
@@ -909,8 +911,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         for (int j = 0; j < 16; ++j) { sc0[j] = 0.f; sc1[j] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
-            const uint4 a0 = *reinterpret_cast<const uint4*>(smem + lds_off<D>(r, 2 * ks + h));
-            const uint4 a1 = *reinterpret_cast<const uint4*>(smem + lds_off<D>(32 + r, 2 * ks + h));
+            const uint4 a0 = *reinterpret_cast<const uint4*>(smem + k_lds_off<D>(r, 2 * ks + h));
+            const uint4 a1 = *reinterpret_cast<const uint4*>(smem + k_lds_off<D>(32 + r, 2 * ks + h));
             sc0 = T::mfma32(__builtin_bit_cast(vec8, a0), qf[ks], sc0);
             sc1 = T::mfma32(__builtin_bit_cast(vec8, a1), qf[ks], sc1);
         }
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     // LDS fragment addresses of the matrix phase: k-step / d-tile flip address bits (one v_xor next to the read), the
     // +32 / +16-row operands are instruction offsets, the ring slot (K: (t+1) & 3, V: t & 3) advances once per tile.
     if ((uint32_t)(uintptr_t)(FINO_LDS char*)smem != 0u) __builtin_trap();
-    uint32_t ka0 = 1 * kTileBytes + lds_off<D>(r, h);
+    uint32_t ka0 = 1 * kTileBytes + k_lds_off<D>(r, h);
     uint32_t vl0 = kVBase + lds_off<D>(4 * h + tq, 2 * g1l + (tp >> 1)) + 8 * (tp & 1);
     uint32_t vh0 = kVBase + lds_off<D>(4 * h + tq + 8, 2 * g1l + (tp >> 1)) + 8 * (tp & 1);
 
@@ -1008,6 +1010,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     PD_VW(6, B_, 1) PD_MFV(STEP_, B_, 1) PD_VPAIR(NSTEP_, NB_, 1)                                            \
     PD_VW(6, B_, 2) PD_MFV(STEP_, B_, 2) PD_VPAIR(NSTEP_, NB_, 2)                                            \
     PD_VW(6, B_, 3) PD_MFV(STEP_, B_, 3) PD_VPAIR(NSTEP_, NB_, 3)
+    // head_dim 64: two d-tiles per key step (4 reads in flight per step instead of 8)
+#define PD_PVSTEP64(STEP_, B_, NB_, NSTEP_)                                                                  \
+    PD_VW(2, B_, 0) PD_MFV(STEP_, B_, 0) PD_VPAIR(NSTEP_, NB_, 0)                                            \
+    PD_VW(2, B_, 1) PD_MFV(STEP_, B_, 1) PD_VPAIR(NSTEP_, NB_, 1)
 #if PD_MAX_SOFTMAX
 #define PD_SHADOW_MAX(MAXEXPR_)
 #else
@@ -1087,10 +1093,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
             PD_KISSUE(1, 1)
         }
         // all DMAs this wave issued before this phase (4 per phase) have landed
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (kPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #else
         // all but this wave's last two phases' DMAs (4 per phase) have landed: its pieces of K(t+1) and V(t), at the latest
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (kPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #endif
         ASTAMP(ts1)
         __builtin_amdgcn_s_barrier();
@@ -1101,6 +1109,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         __builtin_amdgcn_s_setprio(1);
 #endif
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (D == 128) {
         if (t + 1 < nt) {
 #if !PD_PREK
             PD_KISSUE(0, 0)
@@ -1133,6 +1142,37 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         PD_VW(2, 1, 2) PD_MFV(3, 1, 2)
         PD_VW(0, 1, 3) PD_MFV(3, 1, 3)
         PD_SHADOW_MAX(MAX8(sc1, 8))
+      } else {                                     // head_dim 64: 4 k-steps of S, 4 key steps x 2 d-tiles of P.V
+        if (t + 1 < nt) {
+#if !PD_PREK
+            PD_KISSUE(0, 0)
+            PD_KISSUE(1, 1)
+#endif
+            PD_KWAIT(2, 0) PD_MF0(0, 0, true) PD_KISSUE(2, 2) PD_MF1(0, 0, true)
+            PD_KWAIT(2, 1) PD_MF0(1, 1, false) PD_KISSUE(3, 0) PD_MF1(1, 1, false)
+            PD_KWAIT(2, 2) PD_MF0(2, 2, false) PD_VPAIR(0, 0, 0) PD_VPAIR(0, 0, 1) PD_MF1(2, 2, false)
+            PD_KWAIT(4, 0) PD_MF0(3, 0, false) PD_MF1(3, 0, false)
+        } else {
+            PD_VPAIR(0, 0, 0) PD_VPAIR(0, 0, 1)
+        }
+        ASTAMP(tsm)
+#if !PD_MAX_SOFTMAX
+        MASK_RAGGED(t + 1)
+        float mxa = -INFINITY;
+#endif
+        PD_PVSTEP64(0, 0, 1, 1)
+        PD_SHADOW_MAX(MAX8(sc0, 0))
+        PD_PVSTEP64(1, 1, 0, 2)
+        PD_SHADOW_MAX(MAX8(sc0, 8))
+        PD_PVSTEP64(2, 0, 1, 3)
+        PD_SHADOW_MAX(MAX8(sc1, 0))
+        PD_VW(2, 1, 0) PD_MFV(3, 1, 0)
+        PD_VW(0, 1, 1) PD_MFV(3, 1, 1)
+        PD_SHADOW_MAX(MAX8(sc1, 8))
+#if !PD_MAX_SOFTMAX
+        MAX_FINISH1(mxa, mx_next)
+#endif
+      }
 #if !PD_MAX_SOFTMAX
         MAX_FINISH1(mxa, mx_next)
 #endif
@@ -1177,6 +1217,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 #undef PD_VW
 #undef PD_MFV
 #undef PD_PVSTEP
+#undef PD_PVSTEP64
 #undef MASK_RAGGED
 #undef MAX8
 #undef MAX_FINISH1
@@ -1201,8 +1242,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         // every wave is past its last matrix phase (the barrier above): the K ring's first 64 KiB take the output rows, 8 KiB per wave
         int le = lane;
         asm volatile("" : "+v"(le));       // opaque: or the epilogue's per-lane offsets are computed before the loop and kept live
-        u32x4_t rows[8];
-        attn_rows_through_lds<T, D>(o, inv, (uint32_t)(wv * 8192), le & 31, le >> 5, le, rows);
+        u32x4_t rows[D / 16];
+        attn_rows_through_lds<T, D>(o, inv, (uint32_t)(wv * (64 * D)), le & 31, le >> 5, le, rows);
         attn_store_rows<D>(rows, op, p.o_rs, qb * kQBlock + wave * kQRowsPerWave, p.lq, le);
     }
   }   // piece
@@ -2086,18 +2127,16 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     // in bf16, 659 -> 619 with MXFP8 linears) and is the default whenever the caller folds the scale into q.
     const bool w4 = fino_attn_w4_supports(D, p.scale_log2) &&
                     (tune_k == 2 || (tune_k == 0 && D == 64 && p.scale_log2 == 1.0f && p.lk >= 2048));
-    bool ppd = false;
-    if constexpr (D == 128) ppd = pingpong && (tune_k == 4 || ((tune_k == 0 || tune_k == 7) && VAR == 0));   // 5: the round-3 policy (register-staged)
+    // 5: the round-3 policy (register-staged).  head_dim 64: the LDS-DMA-staged kernel by tune 4 (the policy there: below)
+    const bool ppd = pingpong && (tune_k == 4 || (D == 128 && (tune_k == 0 || tune_k == 7) && VAR == 0));
     if (w4) {
         if (int rc = fino_attn_launch_w4(p, T::kId, D, st)) return rc;
     } else if (ppd) {
-        if constexpr (D == 128) {
-            constexpr int smem_d = 2 * kPdSlots * kKV * D * 2;
-            static FinoPerDeviceOnce once_d;
-            if (int rc = fino_max_smem_once(once_d, reinterpret_cast<const void*>(&attn_ppd_kernel<T, VAR>), smem_d, "fino_attn_fwd"))
-                return rc;
-            attn_ppd_kernel<T, VAR><<<grid, kWaves * 64, smem_d, st>>>(p);
-        }
+        constexpr int smem_d = 2 * kPdSlots * kKV * D * 2;
+        static FinoPerDeviceOnce once_d;
+        if (int rc = fino_max_smem_once(once_d, reinterpret_cast<const void*>(&attn_ppd_kernel<T, D, VAR>), smem_d, "fino_attn_fwd"))
+            return rc;
+        attn_ppd_kernel<T, D, VAR><<<grid, kWaves * 64, smem_d, st>>>(p);
     } else if (pingpong)
         attn_pp_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     else

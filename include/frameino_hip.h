@@ -44,7 +44,7 @@ const char* fino_last_error(void);
  * ping-pong one.  FINO_TUNE_GEMM_TILE_M: 2 .. 7 = one launch of 32 x that many rows per tile, 8 = 256-row tiles only (the round-2 behaviour).
  * FINO_TUNE_ATTN_KERNEL: 1 = the register-staged 8-wave ping-pong kernel everywhere, 2 = the 4-wave one-wave-per-SIMD kernel
  * (head_dim 128), 3 = the free-running kernel (4 waves, two workgroups per CU) everywhere, 4 = the LDS-DMA-staged 8-wave
- * ping-pong kernel wherever head_dim is 128, 5 = the round-3 policy (as 0, but register-staged for Lk > 1024); 0 = the policy:
+ * ping-pong kernel everywhere (head_dim 64 too), 5 = the round-3 policy (as 0, but register-staged for Lk > 1024); 0 = the policy:
  * free-running for Lk <= 1024 at head_dim 128 (text cross-attention), LDS-DMA-staged ping-pong for Lk > 1024 at head_dim
  * 128, 4-wave for head_dim 64 with the folded scale, register-staged ping-pong otherwise.
  * 6 = the walking kernel (one workgroup per CU over a run of q-blocks) wherever it can run: head_dim 128, at least two key

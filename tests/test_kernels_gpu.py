@@ -642,12 +642,12 @@ def test_free_running_attention_kernel_equals_the_ping_pong_kernel(b, heads, lq,
 @pytest.mark.parametrize("b,heads,lq,lk", [(2, 24, 1000, 512), (1, 3, 300, 77), (2, 2, 129, 1024), (1, 8, 700, 200),
                                            (1, 5, 64, 64), (1, 24, 3080, 12320), (2, 24, 2100, 4097)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_dma_staged_ping_pong_kernel_equals_the_register_staged_one(b, heads, lq, lk, dtype):
+@pytest.mark.parametrize("dh", [128, 64])
+def test_dma_staged_ping_pong_kernel_equals_the_register_staged_one(b, heads, lq, lk, dtype, dh):
     """attn_ppd_kernel (FINO_TUNE_ATTN_KERNEL = 4: K / V by LDS-DMA into rings of four slots, issued 2 - 4 tiles ahead):
     the arithmetic of attn_pp_kernel in the same order -- bit-identical outputs with and without the tail split, as key-range
     partials, on ragged shapes and strided q / k / v; rows past Lq untouched"""
     from frameino_amd import _lib, ops
-    dh = 128
     d = heads * dh
     g = torch.Generator(device=DEV).manual_seed(lq * 7 + lk)
     q = torch.randn(b, lq, d + 64, device=DEV, generator=g).to(dtype)[:, :, :d]

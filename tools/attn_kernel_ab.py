@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from frameino_amd import _lib, ops
 
-D, H = 3072, 24
+D, H = 3072, int(os.environ.get("FINO_AB_HEADS", 24))       # FINO_AB_HEADS=48: head_dim 64 (the CogVideoX-5B shape)
 ids = [int(x) for x in sys.argv[1:]] or [1, 4]
 lib = _lib.lib()
 torch.manual_seed(0)
