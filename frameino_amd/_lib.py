@@ -46,8 +46,8 @@ SIGNATURES = {
                         [c_float, c_int, c_void_p, c_i64, c_void_p],
     "fino_attn_workspace_bytes": [c_int, c_int, c_i64, c_i64, c_int],
     "fino_attn_fp8_kv_bytes": [c_int, c_int, c_i64, c_int],
-    "fino_attn_fwd_fp8": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 8 + [c_float, c_int, c_void_p, c_i64,
-                                                                                           c_void_p],
+    "fino_attn_fwd_fp8": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 8 + [c_float, c_int, c_int, c_void_p,
+                                                                                           c_i64, c_void_p],
     "fino_attn_partial_bytes": [c_int, c_int, c_i64, c_int],
     "fino_attn_partial": [c_void_p] * 3 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 9 + [c_float, c_int, c_void_p,
                                                                                                c_i64, c_void_p],
@@ -96,7 +96,7 @@ _RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_
 
 # the FINO_VERSION this table (argument lists, tune-knob meanings) was written for: a stale library found through
 # FINO_LIB_PATH would otherwise fail late (AttributeError on a new symbol) or silently misread an argument
-ABI_VERSION = 101
+ABI_VERSION = 102
 
 
 def declared_symbols(header_path=HEADER_PATH):

@@ -220,14 +220,16 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._fp8[(li, key)] = ops.quantize_mxfp8(w.detach().contiguous())
         return self
 
-    def enable_fp8_attention(self, enabled=True):
+    def enable_fp8_attention(self, enabled=True, p_mode=None):
         """The joint text + video self-attention (attention_processor.py:2863 of the reference, head_dim 64: 55 % of the
         CogVideoX-5B step) with fp8 e4m3 matrix operands -- K / V quantised per call with one scale per 32 elements, Q and
         P in registers, both products on the block-scaled fp8 MFMA, fp32 softmax and accumulation
         (`fino_attn_fwd_fp8`).  With `enable_mxfp8_linears()` this is BASELINE config 5's "fp8 MFMA path" end to end.
         No reference counterpart: tolerance stated in tests/test_attention_fp8_gpu.py and
-        tests/test_fullsize_oracle_gpu.py against fp32 and against this model's own bf16 forward."""
+        tests/test_fullsize_oracle_gpu.py against fp32 and against this model's own bf16 forward.
+        p_mode: "exp2" | "ramp" -- how a softmax weight becomes its e4m3 byte (ops.FP8_P_*; None = ops.FP8_P_DEFAULT)."""
         self.fp8_attention = bool(enabled)
+        self.fp8_p_mode = p_mode
         return self
 
     def _lin(self, li, key, x, w, b, epi=0, xq=None, **kw):
@@ -367,8 +369,11 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
                 nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
                 ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt, **qfold)
                 ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
-                attend = ops.attention_fp8 if (self.fp8_attention and dh == 64) else ops.attention
-                att = attend(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads, **afold)
+                if self.fp8_attention and dh == 64:
+                    att = ops.attention_fp8(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads,
+                                            p_mode=getattr(self, "fp8_p_mode", None), **afold)
+                else:
+                    att = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads, **afold)
                 self._lin(li, "out", att.view(b * L, d), blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
                           ops.EPI_GATED_RESIDUAL_STAGED, residual=x2, gate=t1[:, 2], sel=sel, out=x2)
             else:

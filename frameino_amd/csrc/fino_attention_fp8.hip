@@ -71,6 +71,59 @@ __device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d
     return w;
 }
 
+// ---- P: how a softmax weight becomes an e4m3 operand byte (template parameter PX of the main kernels) ----
+// PX = 0 (FINO_FP8_P_EXP2): p = exp2(s - m) on the transcendental unit, rounded to e4m3 by v_cvt_pk_fp8_f32 -- 32 + 16
+//   half-rate instructions per wave and key tile, 60 % of the tile's vector time (tools/ubench/fastexp_probe.hip).
+// PX = 1 (FINO_FP8_P_RAMP): the e4m3 byte of 2^x IS, to within 0.69 of a mantissa step, the integer 8 x + 56: the exponent field
+//   counts whole octaves and the three mantissa bits interpolate linearly between them (Schraudolph's exponential at 8-bit
+//   width).  So the logits are carried in units of 1/8 octave (q pre-multiplied by 8: an exact shift of its e8m0 block scales),
+//   the running maximum and the constant 55.5 ride into S through the same "ones" MFMA as before, and ONE v_cvt_pk_u8_f32 per
+//   value (round to nearest even, saturating at 0: -inf and underflow give the zero byte) writes the operand byte: 32
+//   instructions of the cheaper class instead of 48 of the dearer one.  The weight of a key is then g(s - m) with g(x) = 2^floor(x)
+//   (1 + frac(x)) read at a 3-bit mantissa instead of 2^(s - m): within +-3 % of it, the same function in numerator (P.V) and
+//   denominator (l sums the same bytes), and -- because g(x - n) = 2^-n g(x) for whole n only -- the running maximum moves in
+//   WHOLE octaves, so a deferred rescale and the merge of partials stay exact.  P's own share of the output error goes from
+//   2.6e-2 to 3.1e-2 rel-RMS on N(0, 1) logits (K / V / Q quantisation is the larger share either way): tests/test_attention_fp8_gpu.py.
+constexpr float kPxC = 55.5f;                // byte = rne(8 (s - m) + kPxC): 56 = (exponent bias 7) x 8, -0.5 centres the ramp's error
+template <int PX> struct PxUnit { static constexpr float kS = PX ? 8.0f : 1.0f; };     // S units per octave
+__device__ __forceinline__ uint32_t pack4_u8(float a, float b, float c, float d) {
+    uint32_t w;
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(w) : "v"(a));          // defines the word (other bytes 0), like pack4_fp8
+    asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(b));
+    asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(c));
+    asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(d));
+    return w;
+}
+template <int PX>
+__device__ __forceinline__ uint32_t p_bytes4(float a, float b, float c, float d) {
+    if constexpr (PX) return pack4_u8(a, b, c, d);
+    else return pack4_fp8(__builtin_amdgcn_exp2f(a), __builtin_amdgcn_exp2f(b), __builtin_amdgcn_exp2f(c), __builtin_amdgcn_exp2f(d));
+}
+// the value SUBTRACTED from the first tile's raw logits (S units), T-representable (it re-enters S through a T MFMA operand);
+// PX: a whole number of octaves
+template <typename T, int PX>
+__device__ __forceinline__ float px_first_m(float mxx) {
+    if constexpr (PX) return 8.0f * T::to_f32(T::from_f32(__builtin_rintf(mxx * 0.125f - (float)kPShift)));
+    else return T::to_f32(T::from_f32(mxx - (float)kPShift));
+}
+// what the first tile's S becomes: raw - m (+ the ramp's constant)
+template <int PX> __device__ __forceinline__ float px_first_off(float m_run) { return PX ? kPxC - m_run : -m_run; }
+// deferred rescale: S carries -m_run (+ kPxC); m moves only when a weight would pass 2^(kPShift + kThr8)
+template <int PX> __device__ __forceinline__ float px_thr() { return PX ? 8.0f * ((float)kPShift + kThr8) + kPxC : (float)kPShift + kThr8; }
+template <typename T, int PX>
+__device__ __forceinline__ float px_next_m(float m_run, float ex_next) {
+    if constexpr (PX)
+        return 8.0f * T::to_f32(T::from_f32(m_run * 0.125f + fmaxf(__builtin_rintf((ex_next - kPxC) * 0.125f - (float)kPShift), 0.f)));
+    else return T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
+}
+// operands of the "ones" x (-m) MFMA (k = 0, and for PX k = 1: the constant), dword 0 of the g = 0 lanes
+template <typename T, int PX> __device__ __forceinline__ uint32_t px_ones_word() {
+    return (uint32_t)T::from_f32(1.0f) | (PX ? (uint32_t)T::from_f32(1.0f) << 16 : 0u);
+}
+template <typename T, int PX> __device__ __forceinline__ uint32_t px_mneg_word(float m_run) {
+    return (uint32_t)T::from_f32(-m_run) | (PX ? (uint32_t)T::from_f32(kPxC) << 16 : 0u);
+}
+
 struct QuantParams {
     const uint16_t* k;
     const uint16_t* v;
@@ -238,7 +291,7 @@ __device__ __forceinline__ float max16_behind(const f32x16_t& s, float behind) {
 // one phase, anything further more -- with registers and one phase of distance the wait was 450 cycles per tile).  The
 // operands of a matrix phase (K(t+1) and V(t) fragments, their scale bytes: 12 LDS reads) are read at its top
 // (F8_READS_IN_MATRIX = 1): read in the softmax phase instead they lengthen the longer phase (1034 vs 1216 TFLOP/s-eq.).
-template <typename T, int VAR>
+template <typename T, int VAR, int PX>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnParams& p = fp.a;
@@ -334,7 +387,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     constexpr int kOne = 127, kPs = 127 - kPShift;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // "ones" x (-m): A[key][k = 0] = 1 (k = 0 lives in element 0 of the g = 0 lanes), B[k = 0][q] = -m[q]
-    uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
+    uint4 ones_u = make_uint4(g == 0 ? px_ones_word<T, PX>() : 0u, 0u, 0u, 0u);
     asm volatile("" : "+v"(ones_u.x));
 
     // K(tile in slot KS_) fragments -> registers; K . Q^T (+ C_) -> two 32-key halves
@@ -390,9 +443,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
         float mxx;
         F8_SWAPMAX(mx, mxx)
-        m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
+        m_run = px_first_m<T, PX>(mxx);
+        const float off0 = px_first_off<PX>(m_run);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { s0[j] -= m_run; s1[j] -= m_run; }
+        for (int j = 0; j < 16; ++j) { s0[j] += off0; s1[j] += off0; }
     }
     float ex_next = 0.f;                      // max over the tile of (s - m_run): what may exceed 8
     if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
@@ -432,11 +486,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         F8STAMP(tsa)
         {
             // deferred rescale: s already carries -m_run; move m only when P8 would pass 2^(kPShift + kThr8) = 256
-            if (__any(ex_next > (float)kPShift + kThr8)) {
-                const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
+            if (__any(ex_next > px_thr<PX>())) {
+                const float mn = px_next_m<T, PX>(m_run, ex_next);
                 const float dm = mn - m_run;
                 m_run = mn;
-                const float alpha = __builtin_amdgcn_exp2f(-dm);
+                const float alpha = __builtin_amdgcn_exp2f(-dm * (1.0f / PxUnit<PX>::kS));
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     s0[j] -= dm; s1[j] -= dm;
@@ -447,8 +501,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         i32x8_t pf;
 #if defined(F8_X_NOEXP)                       // timing experiments (wrong results; fino_common.h ties them to FINO_EXPERIMENT)
 #define F8_EXP(X_) (X_)
+#define F8_P4(A_, B_, C_, D_) pack4_fp8(A_, B_, C_, D_)
 #else
 #define F8_EXP(X_) __builtin_amdgcn_exp2f(X_)
+#define F8_P4(A_, B_, C_, D_) p_bytes4<PX>(A_, B_, C_, D_)
 #endif
 #if defined(F8_X_NOPACK)
 #pragma unroll
@@ -461,11 +517,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
 #else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pf[i] = (int)pack4_fp8(F8_EXP(s0[4 * i]), F8_EXP(s0[4 * i + 1]), F8_EXP(s0[4 * i + 2]), F8_EXP(s0[4 * i + 3]));
-            pf[4 + i] = (int)pack4_fp8(F8_EXP(s1[4 * i]), F8_EXP(s1[4 * i + 1]), F8_EXP(s1[4 * i + 2]), F8_EXP(s1[4 * i + 3]));
+            pf[i] = (int)F8_P4(s0[4 * i], s0[4 * i + 1], s0[4 * i + 2], s0[4 * i + 3]);
+            pf[4 + i] = (int)F8_P4(s1[4 * i], s1[4 * i + 1], s1[4 * i + 2], s1[4 * i + 3]);
         }
 #endif
 #undef F8_EXP
+#undef F8_P4
 #if !defined(F8_X_NOSTAGE)
         F8_DMA(t + 4)
 #endif
@@ -491,7 +548,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         F8_PREFETCH_V()
 #endif
         {
-            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
+            uint4 mn_u = make_uint4(g == 0 ? px_mneg_word<T, PX>(m_run) : 0u, 0u, 0u, 0u);
             const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
 #if defined(F8_X_NOOPENER)
             asm volatile("" :: "v"(mnegv), "v"(onesv));
@@ -568,7 +625,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         for (int dt = 0; dt < kDT; ++dt)
 #pragma unroll
             for (int j = 0; j < 16; ++j) w[(dt * 16 + j) * (kWaves * 64) + tid] = o[dt][j];
-        w[kDT * 16 * (kWaves * 64) + tid] = m_run;
+        w[kDT * 16 * (kWaves * 64) + tid] = m_run * (1.0f / PxUnit<PX>::kS);     // octaves, whatever the S unit
         w[kDT * 16 * (kWaves * 64) + kWaves * 64 + tid] = l_run;
         continue;
     }
@@ -601,7 +658,7 @@ constexpr int kFrRing = 4;
 constexpr int kFrLdsK = 0, kFrLdsV = kFrRing * kTileK8, kFrLdsKS = 2 * kFrRing * kTileK8, kFrLdsVS = kFrLdsKS + kFrRing * 128;
 constexpr int kFrSmem = kFrLdsVS + kFrRing * 128;       // 33 KiB
 
-template <typename T>
+template <typename T, int PX>
 __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8AttnParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnParams& p = fp.a;
@@ -666,7 +723,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
     asm volatile("" : "+v"(ones8));       // opaque: held in 8 registers for the whole loop instead of 7 moves per tile
     constexpr int kOne = 127, kPs = 127 - kPShift;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
+    uint4 ones_u = make_uint4(g == 0 ? px_ones_word<T, PX>() : 0u, 0u, 0u, 0u);
     asm volatile("" : "+v"(ones_u.x));
 
     // per-lane byte offsets of the two 16-byte chunks of row r inside a tile image (rows 32 + r: + 2048)
@@ -720,9 +777,10 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
         for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
         float mxx;
         FR_SWAPMAX(mx, mxx)
-        m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
+        m_run = px_first_m<T, PX>(mxx);
+        const float off0 = px_first_off<PX>(m_run);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { s0[j] -= m_run; s1[j] -= m_run; }
+        for (int j = 0; j < 16; ++j) { s0[j] += off0; s1[j] += off0; }
     }
     float ex_next = 0.f;
 
@@ -734,18 +792,54 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
             const i32x8_t vv_ = __builtin_shufflevector(vf0[DT_], vf1[DT_], 0, 1, 2, 3, 4, 5, 6, 7);         \
             o[DT_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv_, pf, o[DT_], 0, 0, 0, vsr[DT_], 0, kPs); \
         }
+    // drop-one timing switches (WRONG results; -DFINO_EXPERIMENT only: tools/debug/attn_fp8_fr_dropone.sh)
+#if defined(FR_X_NODMA)
+#define FRX_DMA(U_)
+#else
+#define FRX_DMA(U_) FR_DMA(U_)
+#endif
+#if defined(FR_X_NOREAD)
+#define FRX_KREAD(SL_) if (t == 0) FR_KREAD(SL_)
+#else
+#define FRX_KREAD(SL_) FR_KREAD(SL_)
+#endif
+#if defined(FR_X_NOCVT)
+#define FRX_P4(A_, B_, C_, D_) (__float_as_uint(A_) & 0x38383838u)
+#else
+#define FRX_P4(A_, B_, C_, D_) p_bytes4<PX>(A_, B_, C_, D_)
+#endif
+#if defined(FR_X_NOMAX)
+#define FRX_MAX(S_, B_) (S_)[0]
+#else
+#define FRX_MAX(S_, B_) max16_behind(S_, B_)
+#endif
+#if defined(FR_X_NOLACC)
+#define FRX_LACC() asm volatile("" : "+v"(lacc) : "v"(pf));
+#else
+#define FRX_LACC() lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
+#endif
+#if defined(FR_X_NOFOLD)
+#define FRX_FOLD(A_, B_) zero16; asm volatile("" :: "v"(A_), "v"(B_))
+#else
+#define FRX_FOLD(A_, B_) T::mfma32(A_, B_, zero16)
+#endif
+#if defined(FR_X_NOBAR)
+#define FRX_BARRIER() asm volatile("" ::: "memory")
+#else
+#define FRX_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #define FR_TILE(T_, SI0_, SI1_, SO0_, SO1_)                                                                  \
     {                                                                                                        \
         const int t = (T_);                                                                                  \
         /* tile t + 3 into the slot tile t - 1 left (its last reads ended before the previous barrier) */     \
-        FR_DMA(t + 3)                                                                                        \
+        FRX_DMA(t + 3)                                                                                       \
         /* K fragments of S(t+1): they land under the exp2 work */                                           \
-        FR_KREAD((t + 1) & (kFrRing - 1))                                                                    \
-        if (__any(ex_next > (float)kPShift + kThr8)) {        /* deferred rescale (see the ping-pong kernel) */ \
-            const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));           \
+        FRX_KREAD((t + 1) & (kFrRing - 1))                                                                   \
+        if (__any(ex_next > px_thr<PX>())) {                  /* deferred rescale (see the ping-pong kernel) */ \
+            const float mn = px_next_m<T, PX>(m_run, ex_next);                                               \
             const float dm = mn - m_run;                                                                     \
             m_run = mn;                                                                                      \
-            const float alpha = __builtin_amdgcn_exp2f(-dm);                                                 \
+            const float alpha = __builtin_amdgcn_exp2f(-dm * (1.0f / PxUnit<PX>::kS));                       \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                 \
                 /* s -= dm IN PLACE ("+v"): no fresh registers on this path, no copies at the join */        \
                 asm volatile("v_sub_f32 %0, %0, %2\n\tv_sub_f32 %1, %1, %2" : "+v"(SI0_[j]), "+v"(SI1_[j]) : "v"(dm)); \
@@ -754,15 +848,13 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
         }                                                                                                    \
         i32x8_t pf;                                                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(SI0_[4 * i]), __builtin_amdgcn_exp2f(SI0_[4 * i + 1]), \
-                                   __builtin_amdgcn_exp2f(SI0_[4 * i + 2]), __builtin_amdgcn_exp2f(SI0_[4 * i + 3])); \
-            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(SI1_[4 * i]), __builtin_amdgcn_exp2f(SI1_[4 * i + 1]), \
-                                       __builtin_amdgcn_exp2f(SI1_[4 * i + 2]), __builtin_amdgcn_exp2f(SI1_[4 * i + 3])); \
+            pf[i] = (int)FRX_P4(SI0_[4 * i], SI0_[4 * i + 1], SI0_[4 * i + 2], SI0_[4 * i + 3]);                 \
+            pf[4 + i] = (int)FRX_P4(SI1_[4 * i], SI1_[4 * i + 1], SI1_[4 * i + 2], SI1_[4 * i + 3]);             \
         }                                                                                                    \
         {                                                                                                    \
-            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);                \
+            uint4 mn_u = make_uint4(g == 0 ? px_mneg_word<T, PX>(m_run) : 0u, 0u, 0u, 0u);                \
             const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);     \
-            const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);                                             \
+            const f32x16_t c0 = FRX_FOLD(onesv, mnegv);                                                      \
             FR_QK(c0, c0, SO0_, SO1_)                                                                        \
         }                                                                                                    \
         /* V fragments only now: they take the registers the K fragments leave (168 registers per wave is the whole  \
@@ -781,15 +873,15 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
         }                                                                                                    \
         FR_PV(0)                                                                                             \
         FR_MASK(t + 1, SO0_, SO1_)                                                                           \
-        float mxa = max16_behind(SO0_, o[0][0]);                                                             \
+        float mxa = FRX_MAX(SO0_, o[0][0]);                                                                  \
         FR_PV(1)                                                                                             \
-        const float mxb = max16_behind(SO1_, o[1][0]);                                                       \
-        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);      \
+        const float mxb = FRX_MAX(SO1_, o[1][0]);                                                            \
+        FRX_LACC()                                                                                           \
         mxa = vmax2(mxa, mxb);                                                                               \
         FR_SWAPMAX(mxa, ex_next)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");     /* tile t + 2 has landed (t + 3 may be in flight) */ \
-        __builtin_amdgcn_s_barrier();                                                                        \
+        FRX_BARRIER();                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
     {
@@ -802,6 +894,13 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
         if (tt < nt) FR_TILE(tt, s0, s1, sb0, sb1)
     }
 #undef FR_TILE
+#undef FRX_DMA
+#undef FRX_KREAD
+#undef FRX_P4
+#undef FRX_MAX
+#undef FRX_LACC
+#undef FRX_FOLD
+#undef FRX_BARRIER
 #undef FR_PV
 #undef FR_DMA
 #undef FR_KREAD
@@ -842,7 +941,7 @@ constexpr int kTile128 = 2 * kTileK8;                        // K8 lo | K8 hi (a
 constexpr int kL128K = 0, kL128V = kRing128 * kTile128, kL128KS = 2 * kRing128 * kTile128, kL128VS = kL128KS + kRing128 * 256;
 constexpr int kSmem128 = kL128VS + kRing128 * 256;           // 132 KiB
 
-template <typename T>
+template <typename T, int PX>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8AttnParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnParams& p = fp.a;
@@ -937,7 +1036,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
     asm volatile("" : "+v"(ones8));       // opaque: held in registers instead of re-materialised every tile
     constexpr int kOne = 127, kPs = 127 - kPShift;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 ones_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(1.0f) : 0u, 0u, 0u, 0u);
+    uint4 ones_u = make_uint4(g == 0 ? px_ones_word<T, PX>() : 0u, 0u, 0u, 0u);
     asm volatile("" : "+v"(ones_u.x));
     const int la0 = r * 64 + 16 * (chunk0(g) ^ swz8(r));
     const int la1 = r * 64 + 16 * (chunk1(g) ^ swz8(r));
@@ -995,20 +1094,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
         for (int j = 1; j < 16; ++j) mx = fmaxf(mx, fmaxf(s0[j], s1[j]));
         float mxx;
         D8_SWAPMAX(mx, mxx)
-        m_run = T::to_f32(T::from_f32(mxx - (float)kPShift));
+        m_run = px_first_m<T, PX>(mxx);
+        const float off0 = px_first_off<PX>(m_run);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { s0[j] -= m_run; s1[j] -= m_run; }
+        for (int j = 0; j < 16; ++j) { s0[j] += off0; s1[j] += off0; }
     }
     float ex_next = 0.f;
     if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
 
     for (int t = 0; t < nt; ++t) {
         // ================= softmax phase =================
-        if (__any(ex_next > (float)kPShift + kThr8)) {
-            const float mn = T::to_f32(T::from_f32(m_run + fmaxf(ex_next - (float)kPShift, 0.f)));
+        if (__any(ex_next > px_thr<PX>())) {
+            const float mn = px_next_m<T, PX>(m_run, ex_next);
             const float dm = mn - m_run;
             m_run = mn;
-            const float alpha = __builtin_amdgcn_exp2f(-dm);
+            const float alpha = __builtin_amdgcn_exp2f(-dm * (1.0f / PxUnit<PX>::kS));
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 s0[j] -= dm; s1[j] -= dm;
@@ -1018,10 +1118,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
         i32x8_t pf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pf[i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s0[4 * i]), __builtin_amdgcn_exp2f(s0[4 * i + 1]),
-                                   __builtin_amdgcn_exp2f(s0[4 * i + 2]), __builtin_amdgcn_exp2f(s0[4 * i + 3]));
-            pf[4 + i] = (int)pack4_fp8(__builtin_amdgcn_exp2f(s1[4 * i]), __builtin_amdgcn_exp2f(s1[4 * i + 1]),
-                                       __builtin_amdgcn_exp2f(s1[4 * i + 2]), __builtin_amdgcn_exp2f(s1[4 * i + 3]));
+            pf[i] = (int)p_bytes4<PX>(s0[4 * i], s0[4 * i + 1], s0[4 * i + 2], s0[4 * i + 3]);
+            pf[4 + i] = (int)p_bytes4<PX>(s1[4 * i], s1[4 * i + 1], s1[4 * i + 2], s1[4 * i + 3]);
         }
         D8_DMA(t + 4)
         asm volatile("" : "+v"(pf));
@@ -1045,7 +1143,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
             }
         }
         {
-            uint4 mn_u = make_uint4(g == 0 ? (uint32_t)T::from_f32(-m_run) : 0u, 0u, 0u, 0u);
+            uint4 mn_u = make_uint4(g == 0 ? px_mneg_word<T, PX>(m_run) : 0u, 0u, 0u, 0u);
             const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
             const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
             D8_QK(c0, s0, s1)
@@ -1085,7 +1183,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_d128_kernel(const Fp8
         for (int d4 = 0; d4 < 4; ++d4)
 #pragma unroll
             for (int j = 0; j < 16; ++j) w[(d4 * 16 + j) * (kWaves * 64) + tid] = o[d4][j];
-        w[4 * 16 * (kWaves * 64) + tid] = m_run;
+        w[4 * 16 * (kWaves * 64) + tid] = m_run * (1.0f / PxUnit<PX>::kS);       // octaves, whatever the S unit
         w[4 * 16 * (kWaves * 64) + kWaves * 64 + tid] = lacc[0];
         continue;
     }
@@ -1116,8 +1214,9 @@ extern "C" int64_t fino_attn_fp8_kv_bytes(int batch, int heads, int64_t lk, int 
 
 extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
                                  int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
-                                 int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, float scale, int dtype,
+                                 int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, float scale, int dtype, int p_mode,
                                  void* kv_workspace, int64_t kv_workspace_bytes, void* stream) {
+    FINO_CHECK(p_mode == FINO_FP8_P_EXP2 || p_mode == FINO_FP8_P_RAMP, FINO_ERR_ARG, "fino_attn_fwd_fp8: p_mode %d", p_mode);
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_fwd_fp8: dtype %d", dtype);
     FINO_CHECK(head_dim == 64 || head_dim == 128, FINO_ERR_UNSUPPORTED, "fino_attn_fwd_fp8: head_dim %d not in {64, 128}", head_dim);
     FINO_CHECK(q && k && v && o && kv_workspace, FINO_ERR_ARG, "fino_attn_fwd_fp8: null pointer");
@@ -1152,6 +1251,8 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = head_dim; p.k_bs = p.k_rs = p.k_hs = p.v_bs = p.v_rs = p.v_hs = 0;
     p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = head_dim;
     p.scale_log2 = scale == FINO_ATTN_SCALE_FOLDED ? 1.0f : scale * 1.4426950408889634f;
+    const bool ramp = p_mode == FINO_FP8_P_RAMP;
+    if (ramp) p.scale_log2 *= 8.0f;          // logits in eighths of an octave: an exact shift of q's e8m0 block scales
     const bool free_running = head_dim == 64 && fino_tune_get(FINO_TUNE_ATTN_FP8_KERNEL) != 1;   // default at head_dim 64
     const int qblock = free_running ? kFrQBlock : kQBlock;
     p.nqb = (int)((lq + qblock - 1) / qblock);
@@ -1162,8 +1263,23 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     fp.k8 = qp.k8; fp.ks = qp.ks; fp.v8t = qp.v8t; fp.vs = qp.vs; fp.nt = nt;
     const dim3 grid((unsigned)(8 * p.full_x));
     if (free_running) {
-        if (dtype == FINO_BF16) attn_fp8_fr_kernel<BF16><<<grid, kFrWaves * 64, kFrSmem, st>>>(fp);
-        else attn_fp8_fr_kernel<F16><<<grid, kFrWaves * 64, kFrSmem, st>>>(fp);
+#define F8_LAUNCH(KERNEL_, GRID_, THREADS_, SMEM_)                                                                        \
+    {                                                                                                                     \
+        if (dtype == FINO_BF16) { if (ramp) KERNEL_(BF16, 1)<<<GRID_, THREADS_, SMEM_, st>>>(fp); else KERNEL_(BF16, 0)<<<GRID_, THREADS_, SMEM_, st>>>(fp); } \
+        else { if (ramp) KERNEL_(F16, 1)<<<GRID_, THREADS_, SMEM_, st>>>(fp); else KERNEL_(F16, 0)<<<GRID_, THREADS_, SMEM_, st>>>(fp); } \
+    }
+#define F8_SMEM_ONCE(KERNEL_, SMEM_)                                                                                      \
+    {                                                                                                                     \
+        static FinoPerDeviceOnce once_[4];                                                                                \
+        const void* fn_ = dtype == FINO_BF16 ? (ramp ? (const void*)KERNEL_(BF16, 1) : (const void*)KERNEL_(BF16, 0))     \
+                                             : (ramp ? (const void*)KERNEL_(F16, 1) : (const void*)KERNEL_(F16, 0));      \
+        const int rc_ = fino_max_smem_once(once_[(dtype == FINO_BF16 ? 0 : 2) + (ramp ? 1 : 0)], fn_, SMEM_, "fino_attn_fwd_fp8"); \
+        if (rc_ != FINO_OK) return rc_;                                                                                   \
+    }
+#define K_FR(T_, PX_) attn_fp8_fr_kernel<T_, PX_>
+#define K_D128(T_, PX_) attn_fp8_d128_kernel<T_, PX_>
+#define K_PP(T_, PX_) attn_fp8_kernel<T_, 0, PX_>
+        F8_LAUNCH(K_FR, grid, kFrWaves * 64, kFrSmem)
         FINO_LAUNCH_CHECK();
         return FINO_OK;
     }
@@ -1177,26 +1293,14 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
             p.full_x = full_x; p.rem_x = rem_x; p.nwg = nwg; p.per = per;
         }
         const dim3 grid128((unsigned)(8 * (p.full_x + p.nwg)));
-        static FinoPerDeviceOnce once_bf16, once_f16;
-        const int rc = dtype == FINO_BF16
-            ? fino_max_smem_once(once_bf16, (const void*)attn_fp8_d128_kernel<BF16>, kSmem128, "fino_attn_fwd_fp8")
-            : fino_max_smem_once(once_f16, (const void*)attn_fp8_d128_kernel<F16>, kSmem128, "fino_attn_fwd_fp8");
-        if (rc != FINO_OK) return rc;
-        if (dtype == FINO_BF16) attn_fp8_d128_kernel<BF16><<<grid128, kWaves * 64, kSmem128, st>>>(fp);
-        else attn_fp8_d128_kernel<F16><<<grid128, kWaves * 64, kSmem128, st>>>(fp);
+        F8_SMEM_ONCE(K_D128, kSmem128)
+        F8_LAUNCH(K_D128, grid128, kWaves * 64, kSmem128)
         FINO_LAUNCH_CHECK();
         return fino_attn_launch_combine(p, dtype, 128, st);
     }
     constexpr int smem = kSmem8;
-    {   // 66 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
-        static FinoPerDeviceOnce once_bf16, once_f16;
-        const int rc = dtype == FINO_BF16
-            ? fino_max_smem_once(once_bf16, (const void*)attn_fp8_kernel<BF16, 0>, smem, "fino_attn_fwd_fp8")
-            : fino_max_smem_once(once_f16, (const void*)attn_fp8_kernel<F16, 0>, smem, "fino_attn_fwd_fp8");
-        if (rc != FINO_OK) return rc;
-    }
-    if (dtype == FINO_BF16) attn_fp8_kernel<BF16, 0><<<grid, kWaves * 64, smem, st>>>(fp);
-    else attn_fp8_kernel<F16, 0><<<grid, kWaves * 64, smem, st>>>(fp);
+    F8_SMEM_ONCE(K_PP, smem)        // 66 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
+    F8_LAUNCH(K_PP, grid, kWaves * 64, smem)
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

@@ -237,9 +237,19 @@ def attention(q, k, v, heads, out=None, scale=None):
 _attn_fp8_ws = {}     # (device index, stream) -> byte workspace of the quantised K / V images of attention_fp8
 
 
-def attention_fp8(q, k, v, heads, out=None, scale=None):
+# how a softmax weight becomes its e4m3 operand byte (include/frameino_hip.h: FINO_FP8_P_*): exp2 + rounding on the
+# transcendental / conversion units, or the byte written directly as rne(8 (s - m) + 55.5) -- exp2 with a piecewise-linear
+# mantissa, a third of the vector-instruction time of a kernel that is bound by exactly those instructions
+FP8_P_EXP2, FP8_P_RAMP = 0, 1
+FP8_P_MODES = {"exp2": FP8_P_EXP2, "ramp": FP8_P_RAMP}
+FP8_P_DEFAULT = FP8_P_MODES[os.environ.get("FINO_FP8_P_MODE", "ramp")]
+
+
+def attention_fp8(q, k, v, heads, out=None, scale=None, p_mode=None):
     """attention() with fp8 (e4m3) matrix operands, head_dim 64 or 128: K / V quantised per call (block-scaled, V transposed), Q
-    and P in registers, both products on the block-scaled fp8 MFMA, softmax and accumulation in fp32 (fino_attn_fwd_fp8)."""
+    and P in registers, both products on the block-scaled fp8 MFMA, softmax and accumulation in fp32 (fino_attn_fwd_fp8).
+    p_mode: "exp2" | "ramp" (or the FP8_P_* integers); None = FP8_P_DEFAULT."""
+    p_mode = FP8_P_DEFAULT if p_mode is None else FP8_P_MODES.get(p_mode, p_mode)
     assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
     b, lq, hd = q.shape
     lk = k.shape[1]
@@ -259,7 +269,7 @@ def attention_fp8(q, k, v, heads, out=None, scale=None):
     ev = _timed("attn_self" if lk > 1024 else "attn_cross")
     _lib.check(_lib.lib().fino_attn_fwd_fp8(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh, q.stride(0), q.stride(1),
                                            k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
-                                           float(scale), _dt(q), _p(ws), need, _stream()), "fino_attn_fwd_fp8")
+                                           float(scale), _dt(q), int(p_mode), _p(ws), need, _stream()), "fino_attn_fwd_fp8")
     if ev is not None:
         ev.record()
         kt_ = KernelTimer.active

@@ -262,12 +262,14 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._fp8[(li, key)] = o.quantize_mxfp8(w.detach().contiguous())
         return self
 
-    def enable_fp8_attention(self, enabled=True):
+    def enable_fp8_attention(self, enabled=True, p_mode=None):
         """The 3-D self-attention (transformer_wan.py:108) with fp8 (e4m3) matrix operands -- q, k, v and P on the
         block-scaled fp8 MFMA, softmax and accumulation fp32 (fino_attn_fwd_fp8, head_dim 128 as two 64-channel sub-heads).
         Opt-in, single-GPU forward only; no reference counterpart: rel-RMS ~5e-2 per attention output on N(0, 1) inputs
-        (tests/test_attention_fp8_gpu.py).  The text cross-attention stays bf16."""
+        (tests/test_attention_fp8_gpu.py).  The text cross-attention stays bf16.
+        p_mode: "exp2" | "ramp" -- how a softmax weight becomes its e4m3 byte (ops.FP8_P_*; None = ops.FP8_P_DEFAULT)."""
         self.fp8_attention = bool(enabled)
+        self.fp8_p_mode = p_mode
         return self
 
     def _ln_q(self, li, key, mode, x, **ln):
@@ -488,7 +490,10 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         fold = self.fold_softmax_scale and hasattr(o, "SCALE_FOLDED")
         qfold = {"out_scale": dh ** -0.5 * o.LOG2E} if fold else {}
         afold = {"scale": o.SCALE_FOLDED} if fold else {}
-        attend = o.attention_fp8 if (self.fp8_attention and sh is None and hasattr(o, "attention_fp8")) else o.attention
+        attend = o.attention
+        if self.fp8_attention and sh is None and hasattr(o, "attention_fp8"):
+            def attend(q_, k_, v_, heads_, **kw_):
+                return o.attention_fp8(q_, k_, v_, heads_, p_mode=getattr(self, "fp8_p_mode", None), **kw_)
         yield
 
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):

@@ -22,7 +22,8 @@ extern "C" {
 #endif
 
 /* 101: fino_gemm_split_n / fino_gemm_blocked_a take a per-call tile_m; FINO_TUNE_GEMM_TILE_M is an A/B knob only. */
-#define FINO_VERSION 101
+/* 102: fino_attn_fwd_fp8 takes p_mode (how a softmax weight becomes an e4m3 byte: FINO_FP8_P_EXP2 | FINO_FP8_P_RAMP). */
+#define FINO_VERSION 102
 
 enum { FINO_BF16 = 0, FINO_F16 = 1 };
 enum {
@@ -160,12 +161,19 @@ int fino_attn_fwd(const void* q, const void* k, const void* v, void* o, int batc
  * head): no reference counterpart, SURVEY F11 -- compared with fp32 SDPA and with this library's bf16 kernel).  q / k / v / o as fino_attn_fwd (bf16 | fp16, head stride = head_dim).  K and V are quantised
  * once per call into `kv_workspace` (fino_attn_fp8_kv_bytes: caller-owned, 16-byte aligned; e4m3 tiles + one e8m0 scale
  * per 32 elements, V transposed and key-permuted for the second product), Q in registers, P = exp2(s - m) to e4m3 with a
- * fixed 2^-6 block scale; both products on v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 accumulation, softmax in fp32. */
+ * fixed 2^-6 block scale; both products on v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 accumulation, softmax in fp32.
+ * p_mode (an ARGUMENT, not a tune knob: it changes the bits) says how a weight becomes its operand byte:
+ *   FINO_FP8_P_EXP2  p = exp2(s - m) on the transcendental unit, then rounded to e4m3 (v_exp_f32 + v_cvt_pk_fp8_f32);
+ *   FINO_FP8_P_RAMP  the byte is rne(8 (s - m) + 55.5) written by one v_cvt_pk_u8_f32: e4m3's exponent field counts octaves and
+ *                    its 3 mantissa bits interpolate linearly, so this is exp2 with a piecewise-linear mantissa (within +-3 % of
+ *                    2^x, the same weight in numerator and denominator, running maximum in whole octaves so rescales and merges
+ *                    stay exact) at a third of the vector-instruction time: the kernels are bound by exactly those instructions. */
+enum { FINO_FP8_P_EXP2 = 0, FINO_FP8_P_RAMP = 1 };
 int64_t fino_attn_fp8_kv_bytes(int batch, int heads, int64_t lk, int head_dim);
 int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq, int64_t lk,
                       int head_dim, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs,
-                      int64_t o_bs, int64_t o_rs, float scale, int dtype, void* kv_workspace, int64_t kv_workspace_bytes,
-                      void* stream);
+                      int64_t o_bs, int64_t o_rs, float scale, int dtype, int p_mode, void* kv_workspace,
+                      int64_t kv_workspace_bytes, void* stream);
 
 /* Attention over ONE key range of several, for the same queries: fino_attn_partial leaves every (head, 256-row
  * q-block)'s unnormalised O, running max m and sum l in `partial` (fp32, fino_attn_partial_bytes(B, H, Lq, Dh) bytes)

@@ -5,6 +5,8 @@ counterpart for the precision; what is stated and checked:
   * against fp32 SDPA: rel-RMS <= 8e-2 on N(0, 1) q / k / v (an emulation of the same quantisation in torch -- block-scaled
     e4m3 q, k along the head, v along 32-key blocks, P = e4m3(exp2(s - m) 2^6) -- measures 5.5e-2: the kernel must not be
     worse than 1.2 x that emulation), and within 1.5 x of it on peaky logits;
+  * both ways a softmax weight becomes its e4m3 byte (include/frameino_hip.h: FINO_FP8_P_EXP2 = exp2 + rounding, FINO_FP8_P_RAMP = the
+    byte written as rne(8 (s - m) + 55.5): exp2 with a piecewise-linear mantissa), each against its own torch emulation;
   * exact properties the quantisation cannot break: V = 1 gives O = 1 (l sums the SAME rounded P that multiply V), keys past
     Lk and query rows past Lq never leak, batch / head strides, ragged tails."""
 import math
@@ -28,6 +30,16 @@ def fp8_kernel(request):
     _lib.lib().fino_tune_set(5, 0)
 
 
+@pytest.fixture(params=["exp2", "ramp"], autouse=True)
+def p_mode(request):
+    """both P modes of fino_attn_fwd_fp8 as the default of ops.attention_fp8"""
+    from frameino_amd import ops
+    old = ops.FP8_P_DEFAULT
+    ops.FP8_P_DEFAULT = ops.FP8_P_MODES[request.param]
+    yield request.param
+    ops.FP8_P_DEFAULT = old
+
+
 def _mxq(x, dim=-1, block=32):
     x = x.transpose(dim, -1)
     shp = x.shape
@@ -46,7 +58,7 @@ def _sdpa(q, k, v, heads):
     return (p @ vh).transpose(1, 2).reshape(b, lq, hd)
 
 
-def _emulated(q, k, v, heads):
+def _emulated(q, k, v, heads, p_mode="exp2"):
     """the kernel's quantisation in plain torch (fp32 everywhere else, exact running maximum)"""
     b, lq, hd = q.shape
     dh = hd // heads
@@ -58,8 +70,14 @@ def _emulated(q, k, v, heads):
     vp = torch.nn.functional.pad(vh, (0, 0, 0, pad))
     v8 = _mxq(vp, dim=2)[:, :, :lk]
     s = q8 @ k8.transpose(2, 3)
-    p = torch.exp2(s - s.amax(-1, keepdim=True))
-    p8 = (p * 64).to(torch.float8_e4m3fn).float() / 64
+    if p_mode == "ramp":
+        # the byte IS rne(8 (s - m) + 55.5) with m a whole number of octaves (the maximum lands near 2^6); 0 below, <= 0x7e above
+        m = torch.round(s.amax(-1, keepdim=True) - 6)
+        byte = torch.round(8 * (s - m) + 55.5).clamp(0, 126).to(torch.uint8)
+        p8 = byte.view(torch.float8_e4m3fn).float()
+    else:
+        p = torch.exp2(s - s.amax(-1, keepdim=True))
+        p8 = (p * 64).to(torch.float8_e4m3fn).float() / 64
     return ((p8 @ v8) / p8.sum(-1, keepdim=True)).transpose(1, 2).reshape(b, lq, hd)
 
 
@@ -67,7 +85,7 @@ def _emulated(q, k, v, heads):
                                            (1, 1, 33, 65)])
 @pytest.mark.parametrize("dh", [64, 128])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk, dtype, dh, fp8_kernel):
+def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk, dtype, dh, fp8_kernel, p_mode):
     from frameino_amd import ops
     if dh == 128:
         if fp8_kernel == 1:
@@ -82,9 +100,9 @@ def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk
     o = ops.attention_fp8(q, k, v, heads, out=out[:, :lq])
     assert torch.isfinite(o.float()).all() and not out[:, lq:].any()
     ref = _sdpa(q, k, v, heads)
-    emu = _emulated(q, k, v, heads)
+    emu = _emulated(q, k, v, heads, p_mode)
     r, re = rel_rms(o, ref), rel_rms(emu, ref)
-    record(f"attention_fp8[b{b}-h{heads}x{dh}-lq{lq}-lk{lk}-{str(dtype)[6:]}]", f"rel_rms vs fp32 SDPA (torch emulation of the "
+    record(f"attention_fp8[{p_mode}-b{b}-h{heads}x{dh}-lq{lq}-lk{lk}-{str(dtype)[6:]}]", f"rel_rms vs fp32 SDPA (torch emulation of the "
            f"quantisation: {re:.4f})", r, 8e-2)
     assert r < 8e-2 and r < 1.2 * re + 2e-3, (r, re)
     # V = 1: every row of P8 / sum(P8) sums to one whatever the rounding
@@ -92,7 +110,7 @@ def test_fp8_attention_vs_fp32_and_vs_the_emulated_quantisation(b, heads, lq, lk
     assert (o1.float() - 1).abs().max().item() < 4e-3
 
 
-def test_fp8_attention_peaky_logits_and_the_rescale_branch():
+def test_fp8_attention_peaky_logits_and_the_rescale_branch(p_mode):
     from frameino_amd import ops
     b, heads, lq, lk = 1, 4, 512, 3000
     d = heads * 64
@@ -102,13 +120,13 @@ def test_fp8_attention_peaky_logits_and_the_rescale_branch():
     k[:, 1500:] *= 1.5                                       # the running maximum keeps growing along the keys
     v = torch.randn(b, lk, d, device=DEV, generator=g).bfloat16()
     o = ops.attention_fp8(q, k, v, heads)
-    ref, emu = _sdpa(q, k, v, heads), _emulated(q, k, v, heads)
+    ref, emu = _sdpa(q, k, v, heads), _emulated(q, k, v, heads, p_mode)
     r, re = rel_rms(o, ref), rel_rms(emu, ref)
-    record("attention_fp8[peaky q x4]", f"rel_rms vs fp32 SDPA (emulation: {re:.4f})", r, 0.2)
+    record(f"attention_fp8[{p_mode}, peaky q x4]", f"rel_rms vs fp32 SDPA (emulation: {re:.4f})", r, 0.2)
     assert torch.isfinite(o.float()).all() and r < 1.5 * re + 5e-3, (r, re)
 
 
-def test_fp8_attention_full_size_config5_sampled_rows():
+def test_fp8_attention_full_size_config5_sampled_rows(p_mode):
     """CogVideoX-5B FrameINO, 49 f 480x720: [2, 19126, 48 x 64]; sampled query rows against fp32 on the device, and against
     the library's own bf16 kernel"""
     from frameino_amd import ops
@@ -125,14 +143,14 @@ def test_fp8_attention_full_size_config5_sampled_rows():
     for bi in range(b):
         ref = _sdpa(q[bi:bi + 1, rows], k[bi:bi + 1], v[bi:bi + 1], heads)[0]
         r, rb = rel_rms(o[bi, rows], ref), rel_rms(ob[bi, rows], ref)
-        record(f"attention_fp8_full_size_config5[batch {bi}]", f"rel_rms sampled rows vs fp32 SDPA (own bf16 kernel: {rb:.4f})",
+        record(f"attention_fp8_full_size_config5[{p_mode}, batch {bi}]", f"rel_rms sampled rows vs fp32 SDPA (own bf16 kernel: {rb:.4f})",
                r, 8e-2)
         assert r < 8e-2, r
     assert torch.isfinite(o.float()).all()
     assert (ops.attention_fp8(q, k, torch.ones_like(v), heads).float() - 1).abs().max().item() < 4e-3
 
 
-def test_fp8_attention_full_size_wan_shape_sampled_rows(fp8_kernel):
+def test_fp8_attention_full_size_wan_shape_sampled_rows(fp8_kernel, p_mode):
     """Wan2.2-5B self-attention, 49 f 704x1280: [2, 12320, 24 x 128] (the CFG-batched launch); sampled query rows against fp32
     on the device, and the library's own bf16 kernel beside it"""
     if fp8_kernel == 1:
@@ -151,7 +169,7 @@ def test_fp8_attention_full_size_wan_shape_sampled_rows(fp8_kernel):
     for bi in range(b):
         ref = _sdpa(q[bi:bi + 1, rows], k[bi:bi + 1], v[bi:bi + 1], heads)[0]
         r, rb = rel_rms(o[bi, rows], ref), rel_rms(ob[bi, rows], ref)
-        record(f"attention_fp8_full_size_wan[batch {bi}]", f"rel_rms sampled rows vs fp32 SDPA (own bf16 kernel: {rb:.4f})", r, 8e-2)
+        record(f"attention_fp8_full_size_wan[{p_mode}, batch {bi}]", f"rel_rms sampled rows vs fp32 SDPA (own bf16 kernel: {rb:.4f})", r, 8e-2)
         assert r < 8e-2, r
     assert torch.isfinite(o.float()).all()
     assert (ops.attention_fp8(q, k, torch.ones_like(v), heads).float() - 1).abs().max().item() < 4e-3

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.fino_version() == 101 == _lib.ABI_VERSION
+    assert lib.fino_version() == 102 == _lib.ABI_VERSION
     # bad dtype -> FINO_ERR_ARG before anything touches a device
     rc = lib.fino_gemm(1, 1, 0, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 0, 0, 7, 0)
     assert rc == -1 and b"dtype" in lib.fino_last_error()

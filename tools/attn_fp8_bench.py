@@ -18,12 +18,13 @@ qs = (q.float() * c).bfloat16()
 o = torch.empty_like(q)
 runs = {"bf16 8-wave": lambda: ops.attention(q, k, v, heads, out=o),
         "bf16 4-wave folded": lambda: ops.attention(qs, k, v, heads, out=o, scale=ops.SCALE_FOLDED),
-        "fp8 operands": lambda: ops.attention_fp8(q, k, v, heads, out=o)}
+        "fp8 operands, P = exp2": lambda: ops.attention_fp8(q, k, v, heads, out=o, p_mode="exp2"),
+        "fp8 operands, P = ramp": lambda: ops.attention_fp8(q, k, v, heads, out=o, p_mode="ramp")}
 if os.environ.get("FINO_FP8_KERNEL"):         # 1: the 8-wave ping-pong kernel instead of the free-running 4-wave one
     from frameino_amd import _lib
     _lib.lib().fino_tune_set(5, int(os.environ["FINO_FP8_KERNEL"]))
 if os.environ.get("FINO_FP8_ONLY"):           # timing-experiment builds (tools/attn_fp8_variants.sh): that kernel alone
-    runs = {"fp8 operands": runs["fp8 operands"]}
+    runs = {n: f for n, f in runs.items() if n.startswith("fp8")}
 rows = torch.tensor(sorted(set(torch.randint(0, L, (24,)).tolist()) | {0, L - 1}), device=dev)
 qh = q[0, rows].float().view(len(rows), heads, 64).transpose(0, 1)
 kh, vh = k[0].float().view(L, heads, 64).transpose(0, 1), v[0].float().view(L, heads, 64).transpose(0, 1)
@@ -32,7 +33,7 @@ t = {n: [] for n in runs}
 for n, f in runs.items():
     f(); f()
     e = ((o[0, rows].float() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
-    print(f"{n:20s} rel-RMS vs fp32 SDPA (sampled rows): {e:.4f}")
+    print(f"{n:24s} rel-RMS vs fp32 SDPA (sampled rows): {e:.4f}")
 for _ in range(5):
     for n, f in runs.items():
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,4 +43,4 @@ for _ in range(5):
 fl = 4.0 * b * L * L * d
 for n in runs:
     us = statistics.median(t[n])
-    print(f"{n:20s} {us:9.1f} us  {fl / us / 1e6:7.0f} TFLOP/s-equivalent")
+    print(f"{n:24s} {us:9.1f} us  {fl / us / 1e6:7.0f} TFLOP/s-equivalent")

@@ -12,7 +12,8 @@ q = torch.randn(b, L, d, device="cuda", generator=g).bfloat16()
 kv = torch.randn(b, L, 2 * d, device="cuda", generator=g).bfloat16()
 k, v = kv[:, :, :d], kv[:, :, d:]
 o = torch.empty_like(q)
-runs = {"bf16 8-wave": lambda: ops.attention(q, k, v, heads, out=o), "fp8 operands": lambda: ops.attention_fp8(q, k, v, heads, out=o)}
+runs = {"bf16 8-wave": lambda: ops.attention(q, k, v, heads, out=o), "fp8, P = exp2": lambda: ops.attention_fp8(q, k, v, heads, out=o, p_mode="exp2"),
+        "fp8, P = ramp": lambda: ops.attention_fp8(q, k, v, heads, out=o, p_mode="ramp")}
 rows = torch.tensor(sorted(set(torch.randint(0, L, (24,)).tolist()) | {0, L - 1}), device="cuda")
 qh = q[0, rows].float().view(len(rows), heads, 128).transpose(0, 1)
 kh, vh = k[0].float().view(L, heads, 128).transpose(0, 1), v[0].float().view(L, heads, 128).transpose(0, 1)
