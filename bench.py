@@ -591,13 +591,13 @@ def main():
     roofline = None
     ks = timer.summary().get("attn_self") if not a.graph else None
     if ks:
-        traffic, traffic_src = profiled_traffic("attn_ppd_kernel<BF16, 0>")
+        traffic, traffic_src = profiled_traffic("attn_ppd_kernel<BF16, 128, 0>")
         # algorithmic FLOPs of the timed launches (4.Lq.Lk.H.Dh per batch element) / their summed duration
         total_fl = timer.flops["attn_self"]
         ach = total_fl / (ks["total_ms"] * 1e-3) / 1e12
         batch = 2
         alg_bytes = batch * 4 * L * heads * dh * 2           # Q, K, V read + O written, bf16
-        roofline = {"bound": "mfma", "kernel": "attn_ppd_kernel<BF16,0> (3D self-attention, head_dim 128)",
+        roofline = {"bound": "mfma", "kernel": "attn_ppd_kernel<BF16,128,0> (3D self-attention, head_dim 128)",
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                     # what the matrix pipe ALONE sustains on THIS box on gaussian operands before the board's power cap
                     # takes the clock down: measured in this run (fino_diag_mfma_peak, 32x32x16 bf16, ~0.25 s launches)
