@@ -429,3 +429,18 @@ def test_baseline_config1_ten_steps_stage1_pipeline_vs_oracle_on_device():
     r = rel_rms(out, ref)
     record("baseline_config1_10_steps_stage1_cog_2_layers_full_width", "rel_rms hip bf16 loop vs oracle fp32 loop on device", r, 3e-2)
     assert out.shape == ref.shape == (1, F_, C_, h, w) and torch.isfinite(out.float()).all() and r < 3e-2, r
+
+
+@pytest.mark.parametrize("extra", [[], ["--frame-out", "--scheduler", "ddim"], ["--mxfp8", "--fp8-attention"]],
+                         ids=["frame-in-dpm", "frame-out-ddim", "fp8-path"])
+def test_cog_example_script_smoke(extra):
+    """examples/run_cogvideox_frameino.py --smoke (the evaluation scripts' call, test_code/run_cogvideox_FrameIn_mass_evaluation.py
+    :203-213): condition builders -> CogVideoX VAE encodes -> dynamic-CFG loop -> VAE decode -> PIL frames, tiny shapes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_cogvideox_frameino.py"), "--smoke"] + extra,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "clip (9 frames 64x96" in r.stdout and "cropped region (9, " in r.stdout
