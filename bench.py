@@ -32,13 +32,18 @@ WORKLOADS = {
 }
 
 
-def wan_flops_per_forward(L, cfg, text_len=512):
-    """algorithmic FLOPs of one DiT forward (2.M.N.K), time-MLP on 2 rows."""
+def wan_flops_per_forward(L, cfg, text_len=512, cross_keys=None, text_proj=True):
+    """algorithmic FLOPs of one DiT forward (2.M.N.K), time-MLP on 2 rows.  For the FLOPs actually ISSUED per step:
+    `cross_keys` = the keys the text cross-attention really attends to (the zero-padded tail of a prompt folded into one key:
+    WanTransformer3DModel.dedup_text_padding), `text_proj=False` = without the text embedder and the layers' text K / V
+    projections (step-invariant: computed once per prompt, outside the steps)."""
     d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
     f, nl = cfg["ffn_dim"], cfg["num_layers"]
     kin = cfg["in_channels"] * 4
-    per_layer = 8 * L * d * d + 4 * L * L * d + (4 * L * d * d + 4 * text_len * d * d) + 4 * L * text_len * d + 4 * L * d * f
-    return nl * per_layer + 2 * L * kin * d + 2 * L * d * cfg["out_channels"] * 4 + 2 * text_len * (cfg["text_dim"] * d + d * d)
+    ck = text_len if cross_keys is None else cross_keys
+    per_layer = 8 * L * d * d + 4 * L * L * d + (4 * L * d * d + (4 * text_len * d * d if text_proj else 0)) + 4 * L * ck * d + 4 * L * d * f
+    return nl * per_layer + 2 * L * kin * d + 2 * L * d * cfg["out_channels"] * 4 + \
+        (2 * text_len * (cfg["text_dim"] * d + d * d) if text_proj else 0)
 
 
 def wan_flops_shared_prefix(L, cfg):
@@ -407,7 +412,11 @@ def main():
         # FLOPs actually issued: on one GPU the two CFG branches are one batch-2 forward whose branch-invariant prefix
         # runs once (the N > 1 plans run two whole batch-1 forwards)
         shared = not multi and getattr(model, "dedup_shared_prefix", False) and not a.cfg_streams
-        flops_step = 2 * wan_flops_per_forward(L, cfg) - (wan_flops_shared_prefix(L, cfg) if shared else 0)
+        # ... the text K / V come from the per-prompt cache, and on one GPU the zero-padded tails of the two prompts (64 and 8
+        # tokens of 512: make_inputs) are one key each
+        fold = not multi and getattr(model, "dedup_text_padding", False)
+        flops_step = sum(wan_flops_per_forward(L, cfg, cross_keys=(ck if fold else None), text_proj=False) for ck in (65, 9)) \
+            - (wan_flops_shared_prefix(L, cfg) if shared else 0)
         out = {
             "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,
@@ -420,7 +429,8 @@ def main():
             "config": dict(base_cfg, hip_graph=bool(use_graph), parallelism=parallelism,
                            sec_per_50_step_clip_denoise_only=50 * ms_step / 1e3,
                            model_tflops_per_s=flops_step / (ms_step * 1e-3) / 1e12,
-                           model_flops_per_step_issued=flops_step, **extra_cfg),
+                           model_flops_per_step_issued=flops_step,
+                           model_flops_per_step_algorithmic=2 * wan_flops_per_forward(L, cfg), **extra_cfg),
         }
         if a.layers:
             out["config"]["INVALID_reduced_layers"] = a.layers

@@ -1261,7 +1261,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 // everything issued before that phase has landed") is kept by counting them: a block's first softmax phase issues 4 DMAs + 8 Q
 // loads behind the 16 stores of the previous block's epilogue and the 4 DMAs of the phase before.
 // Whole blocks only (no tail split, no partials), 2 <= key tiles; arithmetic and order as attn_pp_kernel: same bits.
-template <typename T>
+// TAIL (fino_attn_fwd_tail): per-batch key counts and a logit offset on a batch element's LAST key, which then stands for a run
+// of identical keys (the zero-padded tail of a prompt: every padding token has the same K and V row) -- softmax(q.[K; k x M])
+// [V; v x M] = softmax(q.[K; k] + [0; ln M]) [V; v].  Only the masking branch of the softmax phase differs; TAIL = false is
+// the kernel as it was, bit for bit.
+template <typename T, bool TAIL = false>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = 128;
@@ -1287,6 +1291,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnPara
     const int lk = p.lk;
     const int nt = (lk + kKV - 1) / kKV;
     const int TT = nblk * nt;                                // key tiles of the run
+    // TAIL: the per-batch key counts / offsets as scalars BEFORE the loop (a kernel-argument load inside it would share lgkmcnt
+    // with the loop's counted LDS reads)
+    int tlk0 = lk, tlk1 = lk, tlk2 = lk, tlk3 = lk;
+    float tb0 = 0.f, tb1 = 0.f, tb2 = 0.f, tb3 = 0.f;
+    if constexpr (TAIL) {
+        tlk0 = p.tail_lk[0]; tlk1 = p.tail_lk[1]; tlk2 = p.tail_lk[2]; tlk3 = p.tail_lk[3];
+        tb0 = p.tail_bias[0]; tb1 = p.tail_bias[1]; tb2 = p.tail_bias[2]; tb3 = p.tail_bias[3];
+        asm volatile("" : "+s"(tlk0), "+s"(tlk1), "+s"(tlk2), "+s"(tlk3), "+s"(tb0), "+s"(tb1), "+s"(tb2), "+s"(tb3));
+    }
 
     // position of a stream in the run: relative block, its (batch, head, q-block), tile inside the block
     struct Pos { int blk, bi, head, qb, lt; };
@@ -1474,7 +1487,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnPara
             PW_LOAD_Q(qn, np)
         }
         {
-            if (cp.lt == nt - 1 && (lk & (kKV - 1))) {   // keys past lk (zero K rows) stay out of the row max: p = exp2(-inf) = 0
+            if constexpr (TAIL) {
+                const int lk_c = cp.bi == 0 ? tlk0 : (cp.bi == 1 ? tlk1 : (cp.bi == 2 ? tlk2 : tlk3));
+                if ((cp.lt + 1) * kKV >= lk_c) {         // the tile holds this batch element's last key, or lies past it
+                    const float tb_ = cp.bi == 0 ? tb0 : (cp.bi == 1 ? tb1 : (cp.bi == 2 ? tb2 : tb3));
+                    const int kbase_ = cp.lt * kKV + 4 * h;
+#pragma unroll
+                    for (int j_ = 0; j_ < 16; ++j_) {
+                        const int key_ = kbase_ + (j_ & 3) + 8 * (j_ >> 2);
+                        sc0[j_] = key_ >= lk_c ? -INFINITY : (key_ == lk_c - 1 ? sc0[j_] + tb_ : sc0[j_]);
+                        sc1[j_] = key_ + 32 >= lk_c ? -INFINITY : (key_ + 32 == lk_c - 1 ? sc1[j_] + tb_ : sc1[j_]);
+                    }
+                }
+            } else if (cp.lt == nt - 1 && (lk & (kKV - 1))) {   // keys past lk (zero K rows) stay out of the row max: p = exp2(-inf) = 0
                 const int kbase_ = cp.lt * kKV + 4 * h;
 #pragma unroll
                 for (int j_ = 0; j_ < 16; ++j_) {
@@ -2058,16 +2083,16 @@ int launch_attn_fr(AttnParams p, hipStream_t st) {
     return FINO_OK;
 }
 
-template <typename T>
+template <typename T, bool TAIL = false>
 int launch_attn_ppw(AttnParams p, hipStream_t st) {
     constexpr int smem = 2 * kPdSlots * kKV * 128 * 2 + 32768;      // rings + 32 KiB for a group's output rows: all of the CU's 160 KiB
     static FinoPerDeviceOnce once;
-    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&attn_ppw_kernel<T>), smem, "fino_attn_fwd")) return rc;
+    if (int rc = fino_max_smem_once(once, reinterpret_cast<const void*>(&attn_ppw_kernel<T, TAIL>), smem, "fino_attn_fwd")) return rc;
     p.ws = nullptr; p.all_partial = 0;
     const int64_t blocks = (int64_t)p.batch * p.heads * p.nqb;
     const int cap = fino_tune_get(FINO_TUNE_ATTN_WALK_GRID) > 0 ? fino_tune_get(FINO_TUNE_ATTN_WALK_GRID) : device_cus();
     const int grid = blocks < cap ? (int)blocks : cap;
-    attn_ppw_kernel<T><<<dim3((unsigned)grid), kWaves * 64, smem, st>>>(p);
+    attn_ppw_kernel<T, TAIL><<<dim3((unsigned)grid), kWaves * 64, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
@@ -2231,6 +2256,7 @@ static int attn_common(const void* q, const void* k, const void* v, void* o, int
     p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
     p.ws = (workspace && workspace_bytes > 0) ? (float*)workspace : nullptr;
     p.all_partial = all_partial;
+    p.tail_n = 0;
     FINO_CHECK(((uintptr_t)workspace & 15) == 0, FINO_ERR_ARG, "fino_attn_fwd_ws: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int64_t wb = workspace_bytes;
@@ -2295,4 +2321,60 @@ extern "C" int fino_attn_fwd(const void* q, const void* k, const void* v, void* 
                              int64_t o_rs, int64_t o_hs, float scale, int dtype, void* stream) {
     return fino_attn_fwd_ws(q, k, v, o, batch, heads, lq, lk, head_dim, q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs,
                             v_hs, o_bs, o_rs, o_hs, scale, dtype, nullptr, 0, stream);
+}
+
+// Cross-attention over key sequences whose TAIL is one row repeated (a zero-padded prompt: every padding token yields the same
+// K and V row, transformer_wan.py:108 via attn2 with the 512-token text of pipeline_wan_i2v_motion_FrameINO.py:235-238): batch
+// element b attends to its first lk_b[b] rows of k / v, the last of which stands for tail_mult[b] identical keys; rows from
+// lk_b[b] on (up to `lk`, the allocated rows every batch element has) are ignored.  Exactly
+//     softmax(q.[K; k x M]^T) [V; v x M] = softmax(q.[K; k]^T + [0; ln M]) [V; v],
+// so the result equals fino_attn_fwd on the expanded sequences up to the rounding of one bf16 weight.  Runs on the walking
+// kernel (attn_ppw_kernel<T, true>): head_dim 128, batch <= 4, 64 < lk; FINO_ERR_UNSUPPORTED otherwise (fino_attn_tail_supported).
+extern "C" int fino_attn_tail_supported(int batch, int heads, int64_t lq, int64_t lk, int head_dim) {
+    return head_dim == 128 && batch >= 1 && batch <= 4 && heads > 0 && lq > 0 && lk > kKV && lk < (1 << 20) &&
+           (int64_t)batch * heads * ((lq + kQBlock - 1) / kQBlock) < (1 << 24);
+}
+
+extern "C" int fino_attn_fwd_tail(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq,
+                                  int64_t lk, int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs,
+                                  int64_t k_rs, int64_t k_hs, int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs,
+                                  int64_t o_rs, int64_t o_hs, float scale, int dtype, const int* lk_b,
+                                  const float* tail_mult, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_fwd_tail: dtype %d", dtype);
+    FINO_CHECK(q && k && v && o && lk_b && tail_mult, FINO_ERR_ARG, "fino_attn_fwd_tail: null pointer");
+    FINO_CHECK(fino_attn_tail_supported(batch, heads, lq, lk, head_dim), FINO_ERR_UNSUPPORTED,
+               "fino_attn_fwd_tail: needs head_dim 128, batch <= 4, lk > 64 (got head_dim %d, batch %d, lk %lld)", head_dim,
+               batch, (long long)lk);
+    FINO_CHECK(fino_aligned16(q) && fino_aligned16(k) && fino_aligned16(v) && fino_aligned16(o) && q_rs % 8 == 0 &&
+                   k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 &&
+                   v_hs % 8 == 0 && o_hs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0,
+               FINO_ERR_ARG, "fino_attn_fwd_tail: pointers and strides must be 16-byte aligned");
+    FINO_CHECK(scale > 0.f || scale == FINO_ATTN_SCALE_FOLDED, FINO_ERR_ARG, "fino_attn_fwd_tail: scale");
+    AttnParams p;
+    p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o;
+    p.batch = batch; p.heads = heads; p.lq = (int)lq; p.lk = (int)lk;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs;
+    p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs; p.o_bs = o_bs; p.o_rs = o_rs; p.o_hs = o_hs;
+    p.scale_log2 = scale == FINO_ATTN_SCALE_FOLDED ? 1.0f : scale * 1.4426950408889634f;
+    p.nqb = (int)((lq + kQBlock - 1) / kQBlock);
+    p.vsplit = 1; p.nqb_v = p.nqb; p.full_x = 0; p.rem_x = 0; p.nwg = 0; p.per = 1;
+    p.ws = nullptr; p.all_partial = 0;
+    // the walking kernel addresses each operand through ONE buffer resource over the whole tensor
+    auto span = [&](int64_t bs, int64_t hs, int64_t rs, int64_t rows) {
+        return (((int64_t)batch - 1) * bs + ((int64_t)heads - 1) * hs + (rows - 1 + 2 * kKV) * rs + 128) * 2;
+    };
+    FINO_CHECK(span(k_bs, k_hs, k_rs, lk) < (1ll << 31) && span(v_bs, v_hs, v_rs, lk) < (1ll << 31) &&
+                   span(o_bs, o_hs, o_rs, lq) < (1ll << 31),
+               FINO_ERR_UNSUPPORTED, "fino_attn_fwd_tail: an operand spans more than 2 GiB");
+    p.tail_n = batch;
+    for (int b = 0; b < 4; ++b) {
+        const int bb = b < batch ? b : batch - 1;
+        FINO_CHECK(lk_b[bb] >= 1 && lk_b[bb] <= lk && tail_mult[bb] >= 1.0f, FINO_ERR_ARG,
+                   "fino_attn_fwd_tail: lk_b[%d] = %d (of %lld), tail_mult %g", bb, lk_b[bb], (long long)lk, (double)tail_mult[bb]);
+        p.tail_lk[b] = lk_b[bb];
+        p.tail_bias[b] = log2f(tail_mult[bb]) / p.scale_log2;
+    }
+    if (lq == 0) return FINO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == FINO_BF16 ? launch_attn_ppw<BF16, true>(p, st) : launch_attn_ppw<F16, true>(p, st);
 }

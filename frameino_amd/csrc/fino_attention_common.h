@@ -38,6 +38,12 @@ struct AttnParams {
     // all_partial (fino_attn_partial): EVERY block leaves its (O, m, l) in ws[(head-batch * nqb + q-block)] instead of
     // storing O -- attention over one key range of several, merged by fino_attn_merge
     int all_partial;
+    // fino_attn_fwd_tail (the walking kernel only): batch element b attends to its first tail_lk[b] key rows, the last of which
+    // stands for a run of identical keys -- its logit gets tail_bias[b] = log2(multiplicity) / scale_log2 (raw q.k units) --
+    // and rows from tail_lk[b] on are ignored.  tail_n = 0: off.
+    int tail_n;
+    int tail_lk[4];
+    float tail_bias[4];
 };
 
 // (XCD, slot in that XCD's list of blocks) -> (head-batch, q-block); false: an empty slot.  The q-blocks of one head run on

@@ -1256,7 +1256,7 @@ extern "C" int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, vo
     const bool free_running = head_dim == 64 && fino_tune_get(FINO_TUNE_ATTN_FP8_KERNEL) != 1;   // default at head_dim 64
     const int qblock = free_running ? kFrQBlock : kQBlock;
     p.nqb = (int)((lq + qblock - 1) / qblock);
-    p.ws = nullptr; p.all_partial = 0;
+    p.ws = nullptr; p.all_partial = 0; p.tail_n = 0;
     attn_virtual_heads(p.batch, p.heads, p.nqb, p.vsplit, p.nqb_v);
     const int groups = (p.batch * p.heads * p.vsplit + 7) / 8;
     p.full_x = groups * p.nqb_v; p.rem_x = 0; p.nwg = 0; p.per = 1;

@@ -234,6 +234,41 @@ def attention(q, k, v, heads, out=None, scale=None):
     return out
 
 
+def attention_tail_supported(b, heads, lq, lk, dh):
+    return bool(_lib.lib().fino_attn_tail_supported(int(b), int(heads), int(lq), int(lk), int(dh)))
+
+
+def attention_tail(q, k, v, heads, lk_b, tail_mult, out=None, scale=None):
+    """attention() over key sequences whose tail is ONE row repeated (a zero-padded prompt): batch element i attends to its first
+    lk_b[i] rows of k / v [B, Lk, H*Dh]; the last of them stands for tail_mult[i] identical keys (its logit gets + ln mult), rows
+    from lk_b[i] on are ignored.  Equals attention() on the expanded sequences up to the rounding of one weight
+    (fino_attn_fwd_tail: the walking kernel; head_dim 128, B <= 4, Lk > 64 -- attention_tail_supported)."""
+    import ctypes
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3
+    b, lq, hd = q.shape
+    lk = k.shape[1]
+    dh = hd // heads
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.is_cuda
+    assert len(lk_b) == b and len(tail_mult) == b
+    if out is None:
+        out = torch.empty((b, lq, hd), dtype=q.dtype, device=q.device)
+    scale = dh ** -0.5 if scale is None else scale
+    lk_arr = (ctypes.c_int * b)(*[int(x) for x in lk_b])
+    mult_arr = (ctypes.c_float * b)(*[float(x) for x in tail_mult])
+    ev = _timed("attn_cross")
+    _lib.check(_lib.lib().fino_attn_fwd_tail(_p(q), _p(k), _p(v), _p(out), b, heads, lq, lk, dh,
+                                            q.stride(0), q.stride(1), dh, k.stride(0), k.stride(1), dh,
+                                            v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), dh,
+                                            float(scale), _dt(q), ctypes.cast(lk_arr, ctypes.c_void_p),
+                                            ctypes.cast(mult_arr, ctypes.c_void_p), _stream()), "fino_attn_fwd_tail")
+    if ev is not None:
+        ev.record()
+        kt_ = KernelTimer.active
+        kt_.flops["attn_cross"] = kt_.flops.get("attn_cross", 0.0) + 4.0 * lq * hd * sum(int(x) for x in lk_b)
+    return out
+
+
 _attn_fp8_ws = {}     # (device index, stream) -> byte workspace of the quantised K / V images of attention_fp8
 
 

@@ -151,6 +151,12 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         # scale applied to the logits -- inside the power-capped step the fold buys nothing.
         self.fold_softmax_scale = False
         self.fp8_attention = False        # see enable_fp8_attention
+        # The text cross-attention over a ZERO-PADDED prompt (pipeline_wan...FrameINO.py:235-238 pads every prompt to 512 tokens
+        # with zero rows): all padding tokens yield the same K and V row, so the real tokens + ONE key that stands for the run
+        # give the same softmax (ops.attention_tail: softmax(q.[K; k x M]) [V; v x M] = softmax(q.[K; k] + [0; ln M]) [V; v]).
+        # Found per prompt from the embeddings themselves (trailing all-zero rows), default processors and unsharded forwards
+        # only; False = attend to all 512 rows as the reference does.
+        self.dedup_text_padding = os.environ.get("FINO_TEXT_FOLD", "1") != "0"      # (the environment switch: A/B timing)
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -353,15 +359,38 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             o.rmsnorm_rope_(qkv[:, :d], a.norm_q.weight, a.norm_q.eps, cos, sin, dh, **qfold)
             o.rmsnorm_rope_(qkv[:, d:2 * d], a.norm_k.weight, a.norm_k.eps, cos, sin, dh)
 
-    def _text_kv(self, encoder_hidden_states, pk):
+    def _text_tail(self, ehs, lq):
+        """(rows to keep, per-sample key counts, per-sample multiplicities) when every sample of the prompt batch ends in a run of
+        all-zero rows worth folding into one key, else None.  One host read per prompt (the result is cached with the K / V)."""
+        o = self.ops
+        b, lt, _ = ehs.shape
+        if not (self.dedup_text_padding and hasattr(o, "attention_tail") and ehs.is_cuda):
+            return None
+        live = (ehs != 0).any(dim=-1)                                                  # [b, lt]
+        last = torch.where(live.any(dim=1), lt - 1 - live.flip(1).int().argmax(dim=1), torch.full((b,), -1, device=ehs.device))
+        n_real = [int(x) + 1 for x in last.tolist()]                                   # tokens before the zero run
+        if max(n_real) >= lt:                                                          # a prompt without padding
+            return None
+        keep = max(128, -(-(max(n_real) + 1) // 64) * 64)                              # >= 2 key tiles for the walking kernel
+        heads = self.config.num_attention_heads
+        if keep > lt - 64 or not o.attention_tail_supported(b, heads, lq, keep, self.inner_dim // heads):
+            return None
+        return keep, [n + 1 for n in n_real], [float(lt - n) for n in n_real]
+
+    def _text_kv(self, encoder_hidden_states, pk, lq=0, may_fold=False):
         """text_embedder (:185) + the 30 layers' attn2 K (after norm_k) and V: step-invariant, cached per
-        cache_context name for as long as the caller passes the SAME prompt tensor object, unmodified."""
+        cache_context name for as long as the caller passes the SAME prompt tensor object, unmodified.  `may_fold`: the
+        zero-padded tail of the prompt may be folded into one key (`dedup_text_padding`): then only the kept rows are embedded
+        and projected (row-wise operations: the kept rows come out bit-identical) and `.tail` carries (key counts, multiplicities)."""
         hit = self._text_cache.get(self._ctx_name)
-        if hit is not None and hit[0] is encoder_hidden_states and hit[1] == encoder_hidden_states._version:
+        if hit is not None and hit[0] is encoder_hidden_states and hit[1] == encoder_hidden_states._version \
+                and hit[3] == (bool(may_fold), int(lq) if may_fold else 0):
             return hit[2]
         ce = self.condition_embedder
         d = self.inner_dim
-        ctx = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1])
+        tail = self._text_tail(encoder_hidden_states, lq) if may_fold else None
+        kept = encoder_hidden_states if tail is None else encoder_hidden_states[:, :tail[0]].contiguous()
+        ctx = kept.reshape(-1, kept.shape[-1])
         h = self.ops.gemm(ctx, ce.text_embedder.linear_1.weight, ce.text_embedder.linear_1.bias, self.ops.EPI_GELU_TANH)
         txt = self.ops.gemm(h, ce.text_embedder.linear_2.weight, ce.text_embedder.linear_2.bias)
         kvs = []
@@ -369,10 +398,11 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             kv = self.ops.gemm(txt, e.wkv2, e.bkv2)                                     # [Lt, 2D]
             self.ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
             kvs.append(kv)
-        val = SimpleNamespace(txt=txt, kv=kvs)
+        val = SimpleNamespace(txt=txt, kv=kvs, lt=kept.shape[1], tail=None if tail is None else (tail[1], tail[2]))
         # the entry holds the prompt tensor itself: identity (`is`) + in-place version, never its address -- a freed
         # prompt's address is handed to the next same-shape prompt by the caching allocator
-        self._text_cache[self._ctx_name] = (encoder_hidden_states, encoder_hidden_states._version, val)
+        self._text_cache[self._ctx_name] = (encoder_hidden_states, encoder_hidden_states._version, val,
+                                            (bool(may_fold), int(lq) if may_fold else 0))
         return val
 
     # ------------------------------------------------------------------ forward
@@ -470,8 +500,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         mod = (pk.sst[None] + tproj.float()[:, None]).contiguous()
         head = (self.scale_shift_table.float() + temb.float()[:, None]).contiguous()     # [R, 2, D]  (:522/:527)
 
-        text = self._text_kv(encoder_hidden_states, pk)
-        lt = encoder_hidden_states.shape[1]
+        text = self._text_kv(encoder_hidden_states, pk, lq=n, may_fold=default_procs and sh is None)
+        lt = text.lt
 
         # ---- patch embedding (:486-487): gather + GEMM (the gather is 9 MB; every rank builds it, keeps its rows) ----
         # `shared`: the batch elements are the SAME latent (the pipeline's CFG-batched call passes x.expand(2, ...)) under
@@ -637,7 +667,11 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2, **tk)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)
-                o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
+                if text.tail is not None:
+                    o.attention_tail(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, text.tail[0], text.tail[1],
+                                     out=att.view(b, n, d))
+                else:
+                    o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
                 self._lin(li, "out2", att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
                           residual=x, out=x, **tk)
             else:

@@ -22,7 +22,8 @@ extern "C" {
 #endif
 
 /* 101: fino_gemm_split_n / fino_gemm_blocked_a take a per-call tile_m; FINO_TUNE_GEMM_TILE_M is an A/B knob only. */
-/* 102: fino_attn_fwd_fp8 takes p_mode (how a softmax weight becomes an e4m3 byte: FINO_FP8_P_EXP2 | FINO_FP8_P_RAMP). */
+/* 102: fino_attn_fwd_fp8 takes p_mode (how a softmax weight becomes an e4m3 byte: FINO_FP8_P_EXP2 | FINO_FP8_P_RAMP);
+ * fino_attn_fwd_tail / fino_attn_tail_supported added. */
 #define FINO_VERSION 102
 
 enum { FINO_BF16 = 0, FINO_F16 = 1 };
@@ -174,6 +175,20 @@ int fino_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int 
                       int head_dim, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs,
                       int64_t o_bs, int64_t o_rs, float scale, int dtype, int p_mode, void* kv_workspace,
                       int64_t kv_workspace_bytes, void* stream);
+
+/* Cross-attention over key sequences whose TAIL is one row repeated -- the zero-padded prompt of
+ * pipelines/pipeline_wan_i2v_motion_FrameINO.py:235-238: every padding token of the 512 the text cross-attention
+ * (architecture/transformer_wan.py:108 through attn2) attends to yields the SAME K and V row.  Batch element b attends to its first
+ * lk_b[b] rows of k / v (host arrays of `batch` entries, copied into the launch: nothing is read later); the last of them stands for
+ * tail_mult[b] identical keys, rows from lk_b[b] up to `lk` (the rows every batch element has allocated; finite values) are ignored:
+ *     softmax(q.[K; k x M]^T) [V; v x M] = softmax(q.[K; k]^T + [0; ln M]) [V; v]
+ * i.e. fino_attn_fwd on the expanded sequences up to the rounding of one weight.  Walking kernel only: head_dim 128, batch <= 4,
+ * lk > 64 -- fino_attn_tail_supported() says whether a shape qualifies, FINO_ERR_UNSUPPORTED otherwise. */
+int fino_attn_tail_supported(int batch, int heads, int64_t lq, int64_t lk, int head_dim);
+int fino_attn_fwd_tail(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t lq, int64_t lk,
+                       int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                       int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs, int64_t o_hs, float scale,
+                       int dtype, const int* lk_b, const float* tail_mult, void* stream);
 
 /* Attention over ONE key range of several, for the same queries: fino_attn_partial leaves every (head, 256-row
  * q-block)'s unnormalised O, running max m and sum l in `partial` (fp32, fino_attn_partial_bytes(B, H, Lq, Dh) bytes)

@@ -1,0 +1,89 @@
+"""fino_attn_fwd_tail (csrc/fino_attention.hip, attn_ppw_kernel<T, true>): cross-attention over key sequences whose tail is ONE
+row repeated -- the zero-padded prompt of pipelines/pipeline_wan_i2v_motion_FrameINO.py:235-238 seen through attn2's K / V
+projections (architecture/transformer_wan.py:108): every padding token yields the same K and V row, so
+    softmax(q.[K; k x M]^T) [V; v x M] = softmax(q.[K; k]^T + [0; ln M]) [V; v].
+Checked against the library's own attention on the EXPANDED sequences (what the reference computes) and against fp32 SDPA."""
+import pytest
+import torch
+
+from tests.parity import record, rel_rms
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _sdpa(q, k, v, heads):
+    b, lq, hd = q.shape
+    dh = hd // heads
+    qh, kh, vh = (t.float().view(b, -1, heads, dh).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(2, 3) * dh ** -0.5, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(b, lq, hd)
+
+
+def _case(b, heads, lq, n_real, total, lc, seed, dtype=torch.bfloat16, junk=True):
+    """expanded k / v [b, total, d] whose rows >= n_real[i] all equal one row, and the compact form [b, lc, d] (+ lk_b, mult)"""
+    d = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    q = torch.randn(b, lq, d, device=DEV, generator=g).to(dtype)
+    k = torch.randn(b, total, d, device=DEV, generator=g).to(dtype)
+    v = torch.randn(b, total, d, device=DEV, generator=g).to(dtype)
+    for i, n in enumerate(n_real):
+        k[i, n:] = k[i, n].clone()
+        v[i, n:] = v[i, n].clone()
+    kc, vc = k[:, :lc].clone(), v[:, :lc].clone()
+    if junk:                                   # rows past lk_b are never looked at (finite values)
+        for i, n in enumerate(n_real):
+            kc[i, n + 1:] = 37.0
+            vc[i, n + 1:] = -91.0
+    return q, k, v, kc, vc, [n + 1 for n in n_real], [total - n for n in n_real]
+
+
+@pytest.mark.parametrize("b,heads,lq,n_real,total,lc", [
+    (2, 24, 3000, (64, 8), 512, 128),          # the bench's prompt lengths, one ragged q-block at the end
+    (2, 4, 1111, (127, 0), 512, 128),          # the last key closes a tile; a prompt of padding only
+    (1, 6, 700, (100,), 512, 192),             # three key tiles, the second half of them masked
+    (3, 2, 513, (5, 190, 64), 256, 192),
+    (2, 24, 12320, (64, 8), 512, 128),         # the bench shape itself
+])
+def test_tail_attention_equals_attention_on_the_expanded_keys(b, heads, lq, n_real, total, lc):
+    from frameino_amd import ops
+    assert ops.attention_tail_supported(b, heads, lq, lc, 128)
+    q, k, v, kc, vc, lk_b, mult = _case(b, heads, lq, n_real, total, lc, seed=lq + total)
+    full = ops.attention(q, k, v, heads)
+    tail = ops.attention_tail(q, kc, vc, heads, lk_b, mult)
+    assert torch.isfinite(tail.float()).all()
+    rows = slice(None) if lq <= 3000 else torch.randint(0, lq, (512,), device=DEV)
+    ref = _sdpa(q[:, rows], k, v, heads)
+    r_tail, r_full, r_between = rel_rms(tail[:, rows], ref), rel_rms(full[:, rows], ref), rel_rms(tail, full)
+    record(f"attention_tail[b{b}-h{heads}-lq{lq}-real{'/'.join(map(str, n_real))}-of{total}]",
+           f"rel_rms vs fp32 SDPA on the expanded keys (plain kernel on them: {r_full:.5f}; tail vs plain: {r_between:.5f})",
+           r_tail, 2 ** -7.5)
+    assert r_tail < 2 ** -7.5 and r_tail < 1.3 * r_full + 1e-4 and r_between < 2 ** -7.5, (r_tail, r_full, r_between)
+
+
+def test_tail_attention_with_multiplicity_one_is_attention_on_the_first_keys():
+    """tail_mult = 1: nothing but per-batch key counts -- the same sums over the same keys"""
+    from frameino_amd import ops
+    b, heads, lq = 2, 4, 900
+    q, k, v, kc, vc, lk_b, _ = _case(b, heads, lq, (70, 20), 128, 128, seed=3)
+    out = ops.attention_tail(q, kc, vc, heads, lk_b, [1.0, 1.0])
+    for i in range(b):
+        ref = ops.attention(q[i:i + 1], kc[i:i + 1, :lk_b[i]], vc[i:i + 1, :lk_b[i]], heads)
+        assert rel_rms(out[i:i + 1], ref) < 1e-3, i
+
+
+def test_tail_attention_prompt_of_padding_only_returns_the_padding_value_row():
+    from frameino_amd import ops
+    heads, lq = 2, 300
+    q, k, v, kc, vc, lk_b, mult = _case(1, heads, lq, (0,), 512, 128, seed=9)
+    out = ops.attention_tail(q, kc, vc, heads, lk_b, mult)
+    assert torch.equal(out, vc[:, :1].expand(1, lq, heads * 128))
+
+
+def test_tail_attention_refuses_what_the_walking_kernel_cannot_run():
+    from frameino_amd import ops
+    q = torch.zeros(1, 64, 128, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(1, 64, 128, device=DEV, dtype=torch.bfloat16)
+    assert not ops.attention_tail_supported(1, 1, 64, 64, 128) and not ops.attention_tail_supported(1, 2, 64, 128, 64)
+    with pytest.raises(RuntimeError):
+        ops.attention_tail(q, kv, kv, 1, [3], [10.0])

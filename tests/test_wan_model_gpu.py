@@ -164,3 +164,41 @@ def test_cfg_batch_of_one_latent_runs_the_shared_prefix_once(golden):
         with m.cache_context(f"b{i}"):
             single = m(hidden_states=x, encoder_hidden_states=txt2[i:i + 1], **kw)[0]
         assert torch.equal(shared[i:i + 1], single)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_zero_padded_prompt_tail_folded_into_one_key_vs_all_rows_and_vs_oracle(batch):
+    """`dedup_text_padding`: a prompt zero-padded to 512 rows (pipeline_wan_i2v_motion_FrameINO.py:235-238) attended to as its
+    real tokens + ONE key standing for the padding run == the reference's attention over all 512 rows (oracle, fp32), and ==
+    this model's own forward over all 512 rows up to bf16 rounding; a prompt without padding takes the plain path."""
+    cfg = dict(W.WAN22_5B_CFG, num_attention_heads=4, attention_head_dim=128, in_channels=16, out_channels=8,
+               text_dim=256, ffn_dim=1024, num_layers=3)
+    sd = W.wan_random_state_dict(cfg, seed=7, dtype=torch.float32, std=0.04)
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(1, 16, 5, 16, 20, generator=g).expand(batch, -1, -1, -1, -1).contiguous()
+    txt = torch.randn(batch, 512, 256, generator=g)
+    for i, n in enumerate((64, 8)[:batch]):
+        txt[i, n:] = 0
+    ts = torch.tensor([811.0]).expand(batch).contiguous()
+    ref32 = torch.cat([W.wan_forward(sd, cfg, x[i:i + 1], ts[i:i + 1], txt[i:i + 1]) for i in range(batch)])
+    m = hip_wan_model(cfg, sd, DEV)
+    xd, td, tsd = x.to(DEV).bfloat16(), txt.to(DEV).bfloat16(), ts.to(DEV)
+    assert m.dedup_text_padding
+    folded = m(xd, tsd, td, return_dict=False)[0]
+    hit = next(iter(m._text_cache.values()))[2]
+    assert hit.tail is not None and hit.lt == 128 and hit.tail[0] == [65, 9][:batch] and hit.tail[1] == [448.0, 504.0][:batch]
+    m.dedup_text_padding = False
+    m.reset_caches()
+    plain = m(xd, tsd, td, return_dict=False)[0]
+    assert next(iter(m._text_cache.values()))[2].tail is None
+    r_f, r_p, r_fp = rel_rms(folded, ref32), rel_rms(plain, ref32), rel_rms(folded, plain)
+    from tests.parity import record
+    record(f"wan_midsize_text_padding_fold[b{batch}]", f"rel_rms vs oracle fp32 (all 512 rows: {r_p:.4f}; folded vs all rows: {r_fp:.4f})",
+           r_f, 3e-2)
+    assert r_f < 3e-2 and r_f < 1.2 * r_p + 1e-3 and r_fp < 1e-2, (r_f, r_p, r_fp)
+    # no padding -> nothing to fold
+    m.dedup_text_padding = True
+    m.reset_caches()
+    full = torch.randn(batch, 512, 256, generator=g).to(DEV).bfloat16()
+    m(xd, tsd, full, return_dict=False)
+    assert next(iter(m._text_cache.values()))[2].tail is None
