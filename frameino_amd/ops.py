@@ -269,6 +269,39 @@ def attention_tail(q, k, v, heads, lk_b, tail_mult, out=None, scale=None):
     return out
 
 
+def attention_probs_supported(b, heads, lq, lk, dh):
+    return bool(_lib.lib().fino_attn_probs_supported(int(b), int(heads), int(lq), int(lk), int(dh)))
+
+
+def attention_probs(q, k, heads, lk_b, tail_mult, kp, out=None, scale=None):
+    """P = softmax(scale q.K^T) per head over a short key sequence: q [B, Lq, H*128], k [B, Lk <= 128, H*128] (row-strided views)
+    -> p [B, Lq, H*kp] (kp a multiple of 8 >= every lk_b; columns from lk_b[i] on are zeros).  lk_b / tail_mult as attention_tail.
+    The A operand of the re-associated out-projection P.(V W_o^T) (fino_attn_probs)."""
+    import ctypes
+    assert q.dim() == 3 and k.dim() == 3
+    b, lq, hd = q.shape
+    lk = k.shape[1]
+    dh = hd // heads
+    for t in (q, k):
+        assert t.stride(2) == 1 and t.is_cuda
+    if out is None:
+        out = torch.empty((b, lq, heads * kp), dtype=q.dtype, device=q.device)
+    assert out.shape == (b, lq, heads * kp) and out.stride(2) == 1
+    scale = dh ** -0.5 if scale is None else scale
+    lk_arr = (ctypes.c_int * b)(*[int(x) for x in lk_b])
+    mult_arr = (ctypes.c_float * b)(*[float(x) for x in tail_mult])
+    ev = _timed("attn_cross")
+    _lib.check(_lib.lib().fino_attn_probs(_p(q), _p(k), _p(out), b, heads, lq, lk, dh, q.stride(0), q.stride(1), dh,
+                                         k.stride(0), k.stride(1), dh, int(kp), out.stride(0), out.stride(1), float(scale),
+                                         _dt(q), ctypes.cast(lk_arr, ctypes.c_void_p), ctypes.cast(mult_arr, ctypes.c_void_p),
+                                         _stream()), "fino_attn_probs")
+    if ev is not None:
+        ev.record()
+        kt_ = KernelTimer.active
+        kt_.flops["attn_cross"] = kt_.flops.get("attn_cross", 0.0) + 2.0 * lq * hd * sum(int(x) for x in lk_b)
+    return out
+
+
 _attn_fp8_ws = {}     # (device index, stream) -> byte workspace of the quantised K / V images of attention_fp8
 
 

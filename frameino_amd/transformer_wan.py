@@ -157,6 +157,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         # Found per prompt from the embeddings themselves (trailing all-zero rows), default processors and unsharded forwards
         # only; False = attend to all 512 rows as the reference does.
         self.dedup_text_padding = os.environ.get("FINO_TEXT_FOLD", "1") != "0"      # (the environment switch: A/B timing)
+        # ... and then the text cross-attention's out-projection re-associated as P.(V W_o^T) (see _text_out_weights)
+        self.reassociate_text_out = os.environ.get("FINO_TEXT_REASSOC", "1") != "0"
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -377,6 +379,31 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             return None
         return keep, [n + 1 for n in n_real], [float(lt - n) for n in n_real]
 
+    def _text_out_weights(self, val, b, lq, pk):
+        """(P.V) W_o^T = P.(V W_o^T): with the padding run folded a sample's text is lk <= ~130 keys, so per layer and sample
+        W2 = [W_o,h V_h^T]_h  ([D, heads x kp], kp = lk rounded up to 8) is a per-prompt constant and the out-projection of the
+        text cross-attention (:117 after :108) a GEMM over K = heads x kp (1728 / 384 at 64 / 8 prompt tokens) instead of 3072,
+        fed by the attention PROBABILITIES (ops.attention_probs).  One GEMM per layer and sample builds it: W_o against the
+        block-diagonal arrangement of V (row h kp + j = V[j] restricted to head h's channels)."""
+        o, d = self.ops, self.inner_dim
+        heads = self.config.num_attention_heads
+        dh = d // heads
+        lk_b = val.tail[0]
+        kps = [-(-lk // 8) * 8 for lk in lk_b]
+        dev, dt = val.txt.device, val.txt.dtype
+        hidx = torch.arange(heads, device=dev)
+        val.kp = kps
+        val.pbuf = [torch.empty((lq, heads * kp), dtype=dt, device=dev) for kp in kps]
+        val.w2 = []
+        for li, blk in enumerate(self.blocks):
+            kv = val.kv[li].view(b, val.lt, 2 * d)
+            per_sample = []
+            for i, kp in enumerate(kps):
+                vblk = torch.zeros((heads, kp, heads, dh), dtype=dt, device=dev)
+                vblk[hidx, :, hidx, :] = kv[i, :kp, d:].reshape(kp, heads, dh).permute(1, 0, 2)
+                per_sample.append(o.gemm(blk.attn2.to_out[0].weight, vblk.view(heads * kp, d)))       # [D, heads*kp]
+            val.w2.append(per_sample)
+
     def _text_kv(self, encoder_hidden_states, pk, lq=0, may_fold=False):
         """text_embedder (:185) + the 30 layers' attn2 K (after norm_k) and V: step-invariant, cached per
         cache_context name for as long as the caller passes the SAME prompt tensor object, unmodified.  `may_fold`: the
@@ -384,7 +411,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         and projected (row-wise operations: the kept rows come out bit-identical) and `.tail` carries (key counts, multiplicities)."""
         hit = self._text_cache.get(self._ctx_name)
         if hit is not None and hit[0] is encoder_hidden_states and hit[1] == encoder_hidden_states._version \
-                and hit[3] == (bool(may_fold), int(lq) if may_fold else 0):
+                and hit[3] == (bool(may_fold), int(lq) if may_fold else 0, bool(self._fp8) or self._fp8_pending, self.reassociate_text_out,
+                               self.dedup_text_padding):
             return hit[2]
         ce = self.condition_embedder
         d = self.inner_dim
@@ -398,11 +426,17 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             kv = self.ops.gemm(txt, e.wkv2, e.bkv2)                                     # [Lt, 2D]
             self.ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
             kvs.append(kv)
-        val = SimpleNamespace(txt=txt, kv=kvs, lt=kept.shape[1], tail=None if tail is None else (tail[1], tail[2]))
+        val = SimpleNamespace(txt=txt, kv=kvs, lt=kept.shape[1], tail=None if tail is None else (tail[1], tail[2]), w2=None)
+        if tail is not None and self.reassociate_text_out and not self._fp8 and not self._fp8_pending \
+                and hasattr(self.ops, "attention_probs") \
+                and self.ops.attention_probs_supported(1, self.config.num_attention_heads, lq, kept.shape[1],
+                                                       d // self.config.num_attention_heads):
+            self._text_out_weights(val, kept.shape[0], lq, pk)
         # the entry holds the prompt tensor itself: identity (`is`) + in-place version, never its address -- a freed
         # prompt's address is handed to the next same-shape prompt by the caching allocator
         self._text_cache[self._ctx_name] = (encoder_hidden_states, encoder_hidden_states._version, val,
-                                            (bool(may_fold), int(lq) if may_fold else 0))
+                                            (bool(may_fold), int(lq) if may_fold else 0, bool(self._fp8) or self._fp8_pending,
+                                             self.reassociate_text_out, self.dedup_text_padding))
         return val
 
     # ------------------------------------------------------------------ forward
@@ -667,13 +701,21 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2, **tk)
                 o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)
-                if text.tail is not None:
-                    o.attention_tail(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, text.tail[0], text.tail[1],
-                                     out=att.view(b, n, d))
+                if text.w2 is not None:
+                    # probabilities per sample, then x += P.(V W_o^T) + b: K = heads x keys instead of D
+                    for i in range(b):
+                        pr = o.attention_probs(q2[i * n:(i + 1) * n].view(1, n, d), kv[i:i + 1, :, :d], heads, text.tail[0][i:i + 1],
+                                               text.tail[1][i:i + 1], text.kp[i], out=text.pbuf[i].view(1, n, -1))
+                        xi = x[i * n:(i + 1) * n]
+                        o.gemm(pr.view(n, -1), text.w2[li][i], blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=xi, out=xi)
                 else:
-                    o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
-                self._lin(li, "out2", att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
-                          residual=x, out=x, **tk)
+                    if text.tail is not None:
+                        o.attention_tail(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, text.tail[0], text.tail[1],
+                                         out=att.view(b, n, d))
+                    else:
+                        o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
+                    self._lin(li, "out2", att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
+                              residual=x, out=x, **tk)
             else:
                 a = blk.attn2(nrm.view(b, n, d), encoder_hidden_states=text.txt.view(b, lt, d),
                               **(attention_kwargs or {}))

@@ -23,7 +23,7 @@ extern "C" {
 
 /* 101: fino_gemm_split_n / fino_gemm_blocked_a take a per-call tile_m; FINO_TUNE_GEMM_TILE_M is an A/B knob only. */
 /* 102: fino_attn_fwd_fp8 takes p_mode (how a softmax weight becomes an e4m3 byte: FINO_FP8_P_EXP2 | FINO_FP8_P_RAMP);
- * fino_attn_fwd_tail / fino_attn_tail_supported added. */
+ * fino_attn_fwd_tail / fino_attn_tail_supported, fino_attn_probs / fino_attn_probs_supported added. */
 #define FINO_VERSION 102
 
 enum { FINO_BF16 = 0, FINO_F16 = 1 };
@@ -189,6 +189,16 @@ int fino_attn_fwd_tail(const void* q, const void* k, const void* v, void* o, int
                        int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                        int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_rs, int64_t o_hs, float scale,
                        int dtype, const int* lk_b, const float* tail_mult, void* stream);
+
+/* Attention PROBABILITIES over a short key sequence (head_dim 128, lk <= 128 key rows allocated per sample, batch <= 4):
+ * p[b][row][head][0 .. kp) = softmax(scale q.K^T) of that head's keys (kp a multiple of 8, >= every lk_b; columns from lk_b[b] on
+ * are zeros; p_bs / p_rs in elements), lk_b / tail_mult as fino_attn_fwd_tail.  For the text cross-attention of
+ * architecture/transformer_wan.py:108 + :117 re-associated as P.(V W_o^T): the [rows, heads x kp] matrix is the A operand of a
+ * fino_gemm whose weight is the per-prompt constant V_h W_o,h^T -- K = heads x kp instead of 3072. */
+int fino_attn_probs_supported(int batch, int heads, int64_t lq, int64_t lk, int head_dim);
+int fino_attn_probs(const void* q, const void* k, void* p, int batch, int heads, int64_t lq, int64_t lk, int head_dim,
+                    int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs, int kp, int64_t p_bs,
+                    int64_t p_rs, float scale, int dtype, const int* lk_b, const float* tail_mult, void* stream);
 
 /* Attention over ONE key range of several, for the same queries: fino_attn_partial leaves every (head, 256-row
  * q-block)'s unnormalised O, running max m and sum l in `partial` (fp32, fino_attn_partial_bytes(B, H, Lq, Dh) bytes)

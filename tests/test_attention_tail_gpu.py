@@ -87,3 +87,31 @@ def test_tail_attention_refuses_what_the_walking_kernel_cannot_run():
     assert not ops.attention_tail_supported(1, 1, 64, 64, 128) and not ops.attention_tail_supported(1, 2, 64, 128, 64)
     with pytest.raises(RuntimeError):
         ops.attention_tail(q, kv, kv, 1, [3], [10.0])
+
+
+@pytest.mark.parametrize("b,heads,lq,n_real,total,lk_alloc", [
+    (1, 24, 3000, (64,), 512, 128), (1, 24, 2500, (8,), 512, 128), (2, 4, 1111, (127, 0), 512, 128),
+    (1, 6, 700, (30,), 512, 64), (3, 2, 513, (5, 100, 64), 256, 128),
+])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_probabilities_of_a_short_key_sequence(b, heads, lq, n_real, total, lk_alloc, dtype):
+    """fino_attn_probs: P = softmax(q.K^T) per head with the padding run as one key == the probabilities of fp32 softmax over the
+    expanded keys, the run's mass summed; rows sum to one; columns past a sample's key count are zeros."""
+    from frameino_amd import ops
+    q, k, v, kc, vc, lk_b, mult = _case(b, heads, lq, n_real, total, lk_alloc, seed=7 * lq + total, dtype=dtype)
+    kp = -(-max(lk_b) // 8) * 8
+    assert ops.attention_probs_supported(b, heads, lq, lk_alloc, 128)
+    p = ops.attention_probs(q, kc, heads, lk_b, mult, kp).float().view(b, lq, heads, kp)
+    qh = q.float().view(b, lq, heads, 128).transpose(1, 2)
+    kh = k.float().view(b, total, heads, 128).transpose(1, 2)
+    full = torch.softmax(qh @ kh.transpose(2, 3) * 128 ** -0.5, dim=-1).transpose(1, 2)          # [b, lq, heads, total]
+    worst = 0.0
+    for i, n in enumerate(n_real):
+        ref = torch.cat([full[i, :, :, :n], full[i, :, :, n:].sum(-1, keepdim=True)], dim=-1)      # the run's mass on key n
+        got = p[i, :, :, :n + 1]
+        worst = max(worst, (got - ref).abs().max().item())
+        assert not p[i, :, :, n + 1:].any()
+        assert (p[i].sum(-1) - 1).abs().max().item() < 2e-2
+    record(f"attention_probs[b{b}-h{heads}-lq{lq}-real{'/'.join(map(str, n_real))}-{str(dtype)[6:]}]",
+           "max abs error of a probability vs fp32 softmax over the expanded keys", worst, 6e-3)
+    assert worst < 6e-3, worst

@@ -187,15 +187,22 @@ def test_zero_padded_prompt_tail_folded_into_one_key_vs_all_rows_and_vs_oracle(b
     folded = m(xd, tsd, td, return_dict=False)[0]
     hit = next(iter(m._text_cache.values()))[2]
     assert hit.tail is not None and hit.lt == 128 and hit.tail[0] == [65, 9][:batch] and hit.tail[1] == [448.0, 504.0][:batch]
+    assert hit.w2 is not None and hit.kp == [72, 16][:batch]          # the out-projection re-associated: K = heads x keys
+    m.reassociate_text_out = False
+    folded_pv = m(xd, tsd, td, return_dict=False)[0]                  # same fold, attention output through the plain out-projection
+    hit2 = next(iter(m._text_cache.values()))[2]
+    assert hit2.tail is not None and hit2.w2 is None
+    r_re = rel_rms(folded, folded_pv)
+    m.reassociate_text_out = True
     m.dedup_text_padding = False
-    m.reset_caches()
     plain = m(xd, tsd, td, return_dict=False)[0]
     assert next(iter(m._text_cache.values()))[2].tail is None
     r_f, r_p, r_fp = rel_rms(folded, ref32), rel_rms(plain, ref32), rel_rms(folded, plain)
     from tests.parity import record
     record(f"wan_midsize_text_padding_fold[b{batch}]", f"rel_rms vs oracle fp32 (all 512 rows: {r_p:.4f}; folded vs all rows: {r_fp:.4f})",
            r_f, 3e-2)
-    assert r_f < 3e-2 and r_f < 1.2 * r_p + 1e-3 and r_fp < 1e-2, (r_f, r_p, r_fp)
+    record(f"wan_midsize_text_out_reassociated[b{batch}]", "rel_rms of P.(V Wo^T) vs (P.V) Wo^T forwards", r_re, 1e-2)
+    assert r_f < 3e-2 and r_f < 1.2 * r_p + 1e-3 and r_fp < 1e-2 and r_re < 1e-2, (r_f, r_p, r_fp, r_re)
     # no padding -> nothing to fold
     m.dedup_text_padding = True
     m.reset_caches()
