@@ -154,8 +154,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         # The text cross-attention over a ZERO-PADDED prompt (pipeline_wan...FrameINO.py:235-238 pads every prompt to 512 tokens
         # with zero rows): all padding tokens yield the same K and V row, so the real tokens + ONE key that stands for the run
         # give the same softmax (ops.attention_tail: softmax(q.[K; k x M]) [V; v x M] = softmax(q.[K; k] + [0; ln M]) [V; v]).
-        # Found per prompt from the embeddings themselves (trailing all-zero rows), default processors and unsharded forwards
-        # only; False = attend to all 512 rows as the reference does.
+        # Found per prompt from the embeddings themselves (trailing all-zero rows), default processors only; False = attend to
+        # all 512 rows as the reference does.
         self.dedup_text_padding = os.environ.get("FINO_TEXT_FOLD", "1") != "0"      # (the environment switch: A/B timing)
         # ... and then the text cross-attention's out-projection re-associated as P.(V W_o^T) (see _text_out_weights)
         self.reassociate_text_out = os.environ.get("FINO_TEXT_REASSOC", "1") != "0"
@@ -534,7 +534,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         mod = (pk.sst[None] + tproj.float()[:, None]).contiguous()
         head = (self.scale_shift_table.float() + temb.float()[:, None]).contiguous()     # [R, 2, D]  (:522/:527)
 
-        text = self._text_kv(encoder_hidden_states, pk, lq=n, may_fold=default_procs and sh is None)
+        text = self._text_kv(encoder_hidden_states, pk, lq=n, may_fold=default_procs)      # (token shards too: n = the shard's rows)
         lt = text.lt
 
         # ---- patch embedding (:486-487): gather + GEMM (the gather is 9 MB; every rank builds it, keeps its rows) ----
