@@ -34,7 +34,7 @@ struct ProbsParams {
 template <typename T, int NKB>
 __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
     typedef typename T::vec8 vec8;
-    __shared__ __attribute__((aligned(16))) char smem[NKB * 32 * 256];
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192];      // K image (NKB x 8 KiB), then 8 KiB of output rows per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
     const int bi = hb / p.heads;
     const int head = hb - bi * p.heads;
 
-    // ---- the head's K rows -> LDS (rows past lk: zeros; they only ever meet the -inf mask) ----
+    // ---- the head's K rows -> LDS: only the 32-key blocks this sample has keys in (rows past its count inside the last block are
+    //      whatever the caller left there -- finite -- and only ever meet the -inf mask) ----
+    const int lkc = p.lk_b[bi < 4 ? bi : 3];
+    const float lm = p.log2_mult[bi < 4 ? bi : 3];
+    const int nkb = (lkc + 31) >> 5;                     // uniform over the workgroup
     const uint16_t* kp_ = p.k + bi * p.k_bs + head * p.k_hs;
-#pragma unroll
-    for (int i = 0; i < NKB * 2; ++i) {
+    for (int i = 0; i < nkb * 2; ++i) {
         const int c = tid + 256 * i;
         const int row = c >> 4, ch = c & 15;
         uint4 u = make_uint4(0, 0, 0, 0);
@@ -69,18 +72,18 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[kb][j] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int kb = 0; kb < NKB; ++kb) {
+        if (kb < nkb) {                                  // (blocks without keys: their accumulators stay 0 and are masked below)
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            const int row = kb * 32 + r;
-            const uint4 a = *reinterpret_cast<const uint4*>(smem + row * 256 + (((2 * ks + h) ^ (row & 15)) << 4));
-            acc[kb] = T::mfma32(__builtin_bit_cast(vec8, a), qf[ks], acc[kb]);
+            for (int ks = 0; ks < 8; ++ks) {
+                const int row = kb * 32 + r;
+                const uint4 a = *reinterpret_cast<const uint4*>(smem + row * 256 + (((2 * ks + h) ^ (row & 15)) << 4));
+                acc[kb] = T::mfma32(__builtin_bit_cast(vec8, a), qf[ks], acc[kb]);
+            }
         }
     }
 
     // ---- softmax over the sample's keys (the last one stands for a run of identical keys: + log2 of its multiplicity) ----
-    const int lkc = p.lk_b[bi < 4 ? bi : 3];
-    const float lm = p.log2_mult[bi < 4 ? bi : 3];
     const float c2 = p.scale_log2;
     float m = -INFINITY;
 #pragma unroll
@@ -114,8 +117,10 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const float inv = 1.0f / l;
-    if (qrow >= p.lq) return;
-    uint16_t* prow = p.p + bi * p.p_bs + (int64_t)qrow * p.p_rs + head * p.kp;
+    // ---- P rows leave as 16-byte pieces of whole rows: the wave's 32 rows x kp columns go through its own 8 KiB of the (now idle)
+    //      K image -- the direct form is 8-byte stores that touch 32 cache lines per instruction ----
+    __syncthreads();                                     // every wave has read its K fragments
+    char* stage = smem + wave * 8192;                    // [32 rows][256 B]
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -124,9 +129,20 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
             if (key0 < p.kp) {
                 const uint32_t w0 = (uint32_t)T::from_f32(acc[kb][4 * g4 + 0] * inv) | ((uint32_t)T::from_f32(acc[kb][4 * g4 + 1] * inv) << 16);
                 const uint32_t w1 = (uint32_t)T::from_f32(acc[kb][4 * g4 + 2] * inv) | ((uint32_t)T::from_f32(acc[kb][4 * g4 + 3] * inv) << 16);
-                *reinterpret_cast<uint2*>(prow + key0) = make_uint2(w0, w1);
+                // 16-byte piece (key0 >> 3) of row r, XOR-swizzled by the row so that the 32 rows of a write spread over the banks
+                *reinterpret_cast<uint2*>(stage + r * 256 + ((((key0 >> 3)) ^ (r & 15)) << 4) + ((key0 & 4) << 1)) = make_uint2(w0, w1);
             }
         }
+    }
+    __syncthreads();
+    const int pieces = p.kp >> 3;                        // 16-byte pieces per row
+    const int total = 32 * pieces;
+    const int row_base = blockIdx.x * 128 + wave * 32;
+    uint16_t* pbase = p.p + bi * p.p_bs + head * p.kp;
+    for (int i = lane; i < total; i += 64) {
+        const int rr = i / pieces, pc = i - rr * pieces;
+        const uint4 u = *reinterpret_cast<const uint4*>(stage + rr * 256 + ((pc ^ (rr & 15)) << 4));
+        if (row_base + rr < p.lq) *reinterpret_cast<uint4*>(pbase + (int64_t)(row_base + rr) * p.p_rs + pc * 8) = u;
     }
 }
 

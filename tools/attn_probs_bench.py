@@ -23,4 +23,4 @@ for lk in (65, 9, 128):
         e.record(); torch.cuda.synchronize(); t.append(s.elapsed_time(e) / 10 * 1e3)
     us = statistics.median(t)
     mb = (q.numel() + out.numel()) * 2 / 1e6
-    print(f"{lk:4d} keys (kp {kp:3d}): {us:7.1f} us   {mb:6.1f} MB -> {mb / us / 1e3:5.2f} TB/s")
+    print(f"{lk:4d} keys (kp {kp:3d}): {us:7.1f} us   {mb:6.1f} MB -> {mb / us:5.2f} TB/s")
