@@ -50,7 +50,9 @@ SIGNATURES = {
                                                                                             c_void_p],
     "fino_attn_probs_supported": [c_int, c_int, c_i64, c_i64, c_int],
     "fino_attn_probs": [c_void_p] * 3 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 6 + [c_int, c_i64, c_i64, c_float, c_int,
-                                                                                         c_void_p, c_void_p, c_void_p],
+                                                                                         c_void_p, c_void_p, c_void_p, c_i64,
+                                                                                         c_void_p, c_void_p],
+    "fino_row_rrms": [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_int, c_void_p],
     "fino_attn_fp8_kv_bytes": [c_int, c_int, c_i64, c_int],
     "fino_attn_fwd_fp8": [c_void_p] * 4 + [c_int, c_int, c_i64, c_i64, c_int] + [c_i64] * 8 + [c_float, c_int, c_int, c_void_p,
                                                                                            c_i64, c_void_p],

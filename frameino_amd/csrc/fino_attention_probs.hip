@@ -26,6 +26,11 @@ struct ProbsParams {
     int batch, heads, lq, lk;          // lk: key rows allocated per sample (<= 32 NKB)
     int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, p_bs, p_rs;
     int kp;
+    // q_rrms != nullptr: q is the RAW projection; row i of sample b is normalised while it is loaded, T(T(q rrms[b q_rrms_bs + i]) w)
+    // with w = q_weight [heads x 128] -- the arithmetic and rounding points of fino_rmsnorm_rope (diffusers' RMSNorm)
+    const float* q_rrms;
+    const uint16_t* q_weight;
+    int64_t q_rrms_bs;
     float scale_log2;
     int lk_b[4];
     float log2_mult[4];
@@ -62,8 +67,22 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
     const int qrc = qrow < p.lq ? qrow : p.lq - 1;
     const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs + (int64_t)qrc * p.q_rs + 8 * h;
     vec8 qf[8];
+    if (p.q_rrms) {
+        const float rs = p.q_rrms[bi * p.q_rrms_bs + qrc];
+        const uint16_t* wp = p.q_weight + head * 128 + 8 * h;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4*>(qp + 16 * ks));
+        for (int ks = 0; ks < 8; ++ks) {
+            float f[8], ww[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(qp + 16 * ks), f);
+            unpack8<T>(*reinterpret_cast<const uint4*>(wp + 16 * ks), ww);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = round_to<T>(round_to<T>(f[j] * rs) * ww[j]);
+            qf[ks] = __builtin_bit_cast(vec8, pack8<T>(f));
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4*>(qp + 16 * ks));
+    }
     __syncthreads();
 
     f32x16_t acc[NKB];
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
 }  // namespace
 
 // P = softmax(scale q.K^T) per head over a short key sequence (head_dim 128, lk <= 128 allocated key rows per sample,
-// batch <= 4): p [batch][lq][heads][kp] (strides p_bs / p_rs in elements, kp a multiple of 8 with max lk_b <= kp <= lk rounded up
+// batch <= 4; q_rrms / q_weight: see ProbsParams -- NULL for a q that is already normalised): p [batch][lq][heads][kp] (strides p_bs / p_rs in elements, kp a multiple of 8 with max lk_b <= kp <= lk rounded up
 // to 8; columns from lk_b[b] on are zeros).  lk_b / tail_mult as fino_attn_fwd_tail.
 extern "C" int fino_attn_probs_supported(int batch, int heads, int64_t lq, int64_t lk, int head_dim) {
     return head_dim == 128 && batch >= 1 && batch <= 4 && heads > 0 && lq > 0 && lk >= 1 && lk <= 128 &&
@@ -159,7 +178,10 @@ extern "C" int fino_attn_probs_supported(int batch, int heads, int64_t lq, int64
 extern "C" int fino_attn_probs(const void* q, const void* k, void* p, int batch, int heads, int64_t lq, int64_t lk,
                                int head_dim, int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                                int kp, int64_t p_bs, int64_t p_rs, float scale, int dtype, const int* lk_b,
-                               const float* tail_mult, void* stream) {
+                               const float* tail_mult, const float* q_rrms, int64_t q_rrms_bs, const void* q_weight,
+                               void* stream) {
+    FINO_CHECK((q_rrms == nullptr) == (q_weight == nullptr) && fino_aligned16(q_weight), FINO_ERR_ARG,
+               "fino_attn_probs: q_rrms and q_weight come together (q_weight 16-byte aligned)");
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_attn_probs: dtype %d", dtype);
     FINO_CHECK(q && k && p && lk_b && tail_mult, FINO_ERR_ARG, "fino_attn_probs: null pointer");
     FINO_CHECK(fino_attn_probs_supported(batch, heads, lq, lk, head_dim), FINO_ERR_UNSUPPORTED,
@@ -177,6 +199,7 @@ extern "C" int fino_attn_probs(const void* q, const void* k, void* p, int batch,
     pp.batch = batch; pp.heads = heads; pp.lq = (int)lq; pp.lk = (int)lk;
     pp.q_bs = q_bs; pp.q_rs = q_rs; pp.q_hs = q_hs; pp.k_bs = k_bs; pp.k_rs = k_rs; pp.k_hs = k_hs; pp.p_bs = p_bs; pp.p_rs = p_rs;
     pp.kp = kp;
+    pp.q_rrms = q_rrms; pp.q_weight = (const uint16_t*)q_weight; pp.q_rrms_bs = q_rrms_bs;
     pp.scale_log2 = scale == FINO_ATTN_SCALE_FOLDED ? 1.0f : scale * 1.4426950408889634f;
     for (int b = 0; b < 4; ++b) {
         const int bb = b < batch ? b : batch - 1;

@@ -258,6 +258,25 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint1
                             head_off ? head_off + (int64_t)s * (dim / head_dim) : nullptr, head_ld, lane);
 }
 
+// The statistic of rmsnorm_rope_row alone: rrms[row] = 1 / sqrt(mean(x^2) + eps), the same loads, the same order of summation,
+// the same bits -- for a consumer that applies the normalisation itself (fino_attn_probs normalises q while it loads it).
+template <typename T, int NP>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void row_rrms_kernel(const uint16_t* __restrict__ x, int64_t rows, int dim,
+                                                                       int64_t ldx, float eps, float* __restrict__ rrms) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NP][8];
+    load_row<T, NP>(x + row * ldx, dim, lane, v);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q += v[i][j] * v[i][j];
+    const float var = wave_sum(q) / (float)dim;
+    if (lane == 0) rrms[row] = 1.0f / sqrtf(var + eps);
+}
+
 // CogVideoX: per-head LayerNorm(head_dim) (affine, T params; statistics fp32, output rounded to T) then RoPE
 // out = T(float(x)*cos + float(rot(x))*sin) on rows >= rope_row0.  One lane owns 8 channels; a head spans
 // head_dim/8 consecutive lanes (8 for 64, 16 for 128) -> xor-shuffle reduction inside the group.
@@ -709,6 +728,23 @@ static int rmsnorm_rope_impl(void* x, int64_t rows, int dim, int64_t ldx, int pa
                                                                  (uint16_t*)out, head_off, head_ld);
     });
     FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "fino_rmsnorm_rope: dim %d > %d unsupported", dim, kMaxPasses * 512);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_row_rrms(const void* x, int64_t rows, int dim, int64_t ldx, float eps, float* rrms, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_row_rrms: dtype %d", dtype);
+    FINO_CHECK(x && rrms && rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && fino_aligned16(x), FINO_ERR_ARG,
+               "fino_row_rrms: bad arguments");
+    if (rows == 0) return FINO_OK;
+    const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
+        constexpr int NP = decltype(np)::value;
+        if (dtype == FINO_BF16) row_rrms_kernel<BF16, NP><<<grid, block, 0, st>>>((const uint16_t*)x, rows, dim, ldx, eps, rrms);
+        else row_rrms_kernel<F16, NP><<<grid, block, 0, st>>>((const uint16_t*)x, rows, dim, ldx, eps, rrms);
+    });
+    FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "fino_row_rrms: dim %d > %d unsupported", dim, kMaxPasses * 512);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

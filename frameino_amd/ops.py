@@ -273,10 +273,21 @@ def attention_probs_supported(b, heads, lq, lk, dh):
     return bool(_lib.lib().fino_attn_probs_supported(int(b), int(heads), int(lq), int(lk), int(dh)))
 
 
-def attention_probs(q, k, heads, lk_b, tail_mult, kp, out=None, scale=None):
+def row_rrms(x, eps, out=None):
+    """rrms[row] = 1 / sqrt(mean(x[row]^2) + eps), fp32 [rows]: the statistic of rmsnorm_rope_ alone, bit for bit (fino_row_rrms)"""
+    x2, rows, dim, ldx = _rows2d(x)
+    if out is None:
+        out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= rows
+    _lib.check(_lib.lib().fino_row_rrms(_p(x2), rows, dim, ldx, float(eps), _p(out), _dt(x), _stream()), "fino_row_rrms")
+    return out
+
+
+def attention_probs(q, k, heads, lk_b, tail_mult, kp, out=None, scale=None, q_rrms=None, q_weight=None):
     """P = softmax(scale q.K^T) per head over a short key sequence: q [B, Lq, H*128], k [B, Lk <= 128, H*128] (row-strided views)
     -> p [B, Lq, H*kp] (kp a multiple of 8 >= every lk_b; columns from lk_b[i] on are zeros).  lk_b / tail_mult as attention_tail.
-    The A operand of the re-associated out-projection P.(V W_o^T) (fino_attn_probs)."""
+    The A operand of the re-associated out-projection P.(V W_o^T) (fino_attn_probs).  q_rrms [B, Lq] fp32 + q_weight [H*128]: q is
+    the RAW projection, RMS-normalised while it is loaded (rmsnorm_rope_'s arithmetic and rounding points, without its pass)."""
     import ctypes
     assert q.dim() == 3 and k.dim() == 3
     b, lq, hd = q.shape
@@ -294,7 +305,8 @@ def attention_probs(q, k, heads, lk_b, tail_mult, kp, out=None, scale=None):
     _lib.check(_lib.lib().fino_attn_probs(_p(q), _p(k), _p(out), b, heads, lq, lk, dh, q.stride(0), q.stride(1), dh,
                                          k.stride(0), k.stride(1), dh, int(kp), out.stride(0), out.stride(1), float(scale),
                                          _dt(q), ctypes.cast(lk_arr, ctypes.c_void_p), ctypes.cast(mult_arr, ctypes.c_void_p),
-                                         _stream()), "fino_attn_probs")
+                                         _p(q_rrms), q_rrms.stride(0) if q_rrms is not None else 0, _p(q_weight), _stream()),
+               "fino_attn_probs")
     if ev is not None:
         ev.record()
         kt_ = KernelTimer.active

@@ -394,6 +394,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         hidx = torch.arange(heads, device=dev)
         val.kp = kps
         val.pbuf = [torch.empty((lq, heads * kp), dtype=dt, device=dev) for kp in kps]
+        val.rrms = torch.empty(b * lq, dtype=torch.float32, device=dev)
         val.w2 = []
         for li, blk in enumerate(self.blocks):
             kv = val.kv[li].view(b, val.lt, 2 * d)
@@ -699,16 +700,19 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 nrm.copy_(x)
             if default_procs:
                 self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2, **tk)
-                o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                 kv = text.kv[li].view(b, lt, 2 * d)
                 if text.w2 is not None:
-                    # probabilities per sample, then x += P.(V W_o^T) + b: K = heads x keys instead of D
+                    # norm_q's statistic only (the probabilities kernel normalises q while it loads it: same rounding points, no
+                    # pass that rewrites q); probabilities per sample, then x += P.(V W_o^T) + b: K = heads x keys instead of D
+                    rr = o.row_rrms(q2, blk.attn2.norm_q.eps, out=text.rrms)
                     for i in range(b):
                         pr = o.attention_probs(q2[i * n:(i + 1) * n].view(1, n, d), kv[i:i + 1, :, :d], heads, text.tail[0][i:i + 1],
-                                               text.tail[1][i:i + 1], text.kp[i], out=text.pbuf[i].view(1, n, -1))
+                                               text.tail[1][i:i + 1], text.kp[i], out=text.pbuf[i].view(1, n, -1),
+                                               q_rrms=rr[i * n:(i + 1) * n].view(1, n), q_weight=blk.attn2.norm_q.weight)
                         xi = x[i * n:(i + 1) * n]
                         o.gemm(pr.view(n, -1), text.w2[li][i], blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=xi, out=xi)
                 else:
+                    o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                     if text.tail is not None:
                         o.attention_tail(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, text.tail[0], text.tail[1],
                                          out=att.view(b, n, d))

@@ -198,7 +198,13 @@ int fino_attn_fwd_tail(const void* q, const void* k, const void* v, void* o, int
 int fino_attn_probs_supported(int batch, int heads, int64_t lq, int64_t lk, int head_dim);
 int fino_attn_probs(const void* q, const void* k, void* p, int batch, int heads, int64_t lq, int64_t lk, int head_dim,
                     int64_t q_bs, int64_t q_rs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs, int kp, int64_t p_bs,
-                    int64_t p_rs, float scale, int dtype, const int* lk_b, const float* tail_mult, void* stream);
+                    int64_t p_rs, float scale, int dtype, const int* lk_b, const float* tail_mult, const float* q_rrms,
+                    int64_t q_rrms_bs, const void* q_weight, void* stream);
+/* q_rrms / q_weight (both or neither): q is the RAW q projection and row i of sample b is RMS-normalised while it is loaded,
+ * T(T(q x q_rrms[b * q_rrms_bs + i]) x q_weight[c]) -- fino_rmsnorm_rope's arithmetic and rounding points, without the pass
+ * that rewrites q.  fino_row_rrms writes that statistic: rrms[row] = 1 / sqrt(mean(x[row]^2) + eps) with the loads and the
+ * summation order of fino_rmsnorm_rope (the same bits). */
+int fino_row_rrms(const void* x, int64_t rows, int dim, int64_t ldx, float eps, float* rrms, int dtype, void* stream);
 
 /* Attention over ONE key range of several, for the same queries: fino_attn_partial leaves every (head, 256-row
  * q-block)'s unnormalised O, running max m and sum l in `partial` (fp32, fino_attn_partial_bytes(B, H, Lq, Dh) bytes)

@@ -115,3 +115,24 @@ def test_attention_probabilities_of_a_short_key_sequence(b, heads, lq, n_real, t
     record(f"attention_probs[b{b}-h{heads}-lq{lq}-real{'/'.join(map(str, n_real))}-{str(dtype)[6:]}]",
            "max abs error of a probability vs fp32 softmax over the expanded keys", worst, 6e-3)
     assert worst < 6e-3, worst
+
+
+def test_probabilities_with_q_normalised_on_load_equal_those_of_the_normalised_q():
+    """fino_row_rrms + fino_attn_probs(q_rrms, q_weight): RMS-normalising q inside the kernel (statistic from its own pass) gives the
+    bits of normalising q first with fino_rmsnorm_rope"""
+    from frameino_amd import ops
+    b, heads, lq = 2, 6, 1500
+    d = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(21)
+    q = (torch.randn(b * lq, d, device=DEV, generator=g) * 3).bfloat16()
+    w = (1 + 0.1 * torch.randn(d, device=DEV, generator=g)).bfloat16()
+    k = torch.randn(b, 128, d, device=DEV, generator=g).bfloat16()
+    lk_b, mult = [65, 9], [448.0, 504.0]
+    rr = ops.row_rrms(q, 1e-6)
+    ref_rr = torch.rsqrt(q.float().pow(2).mean(-1) + 1e-6)
+    assert (rr / ref_rr - 1).abs().max().item() < 1e-5
+    p_fused = ops.attention_probs(q.view(b, lq, d), k, heads, lk_b, mult, 72, q_rrms=rr.view(b, lq), q_weight=w)
+    qn = q.clone()
+    ops.rmsnorm_rope_(qn, w, 1e-6)
+    p_ref = ops.attention_probs(qn.view(b, lq, d), k, heads, lk_b, mult, 72)
+    assert torch.equal(p_fused, p_ref)
