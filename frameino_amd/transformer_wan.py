@@ -710,7 +710,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                                                text.tail[1][i:i + 1], text.kp[i], out=text.pbuf[i].view(1, n, -1),
                                                q_rrms=rr[i * n:(i + 1) * n].view(1, n), q_weight=blk.attn2.norm_q.weight)
                         xi = x[i * n:(i + 1) * n]
-                        o.gemm(pr.view(n, -1), text.w2[li][i], blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=xi, out=xi)
+                        o.gemm(pr.view(n, -1), text.w2[li][i], blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=xi, out=xi, **tk)
                 else:
                     o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
                     if text.tail is not None:

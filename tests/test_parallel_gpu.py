@@ -230,6 +230,18 @@ def _loopback_shard(board, rank, exchange):
                                                   (8, "kv", (44, 80)), (2, "kv", (44, 80)),
                                                   (8, "heads", (64, 112)), (8, "kv", (64, 112))])
 def test_full_size_token_shards_in_one_process(ways, exchange, lat_hw):
+    _run_full_size_token_shards(ways, exchange, lat_hw, 512)
+
+
+@pytest.mark.parametrize("ways,exchange", [(4, "kv"), (8, "heads")])
+def test_full_size_token_shards_with_a_zero_padded_prompt(ways, exchange):
+    """the same with a 64-token prompt zero-padded to 512 rows: every rank folds the padding run into one key and runs the text
+    cross-attention's out-projection re-associated on its shard's rows (frameino_amd/transformer_wan.py: _text_tail,
+    _text_out_weights) -- as the unsharded forward does"""
+    _run_full_size_token_shards(ways, exchange, (44, 80), 64)
+
+
+def _run_full_size_token_shards(ways, exchange, lat_hw, prompt_tokens):
     """Wan2.2-5B width, L = 12320, 2 layers: the forwards of all P simulated ranks (threads, loopback exchanges) against
     the unsharded forward -- the real kernels on the real shard shapes (1540 / 3080 / 6160 tokens per rank; 3 / 6 heads
     per rank after the heads exchange), which no multi-process test on one GPU reaches.  (64, 112): BASELINE config 4's
@@ -246,6 +258,7 @@ def test_full_size_token_shards_in_one_process(ways, exchange, lat_hw):
     lh, lw = lat_hw
     x = torch.randn(1, 96, 14, lh, lw, device=dev, generator=g).bfloat16()
     pe = torch.randn(1, 512, cfg["text_dim"], device=dev, generator=g).bfloat16()
+    pe[:, prompt_tokens:] = 0
     L = 14 * (lh // 2) * (lw // 2)
     sel = (torch.arange(L, device=dev) >= (lh // 2) * (lw // 2)).to(torch.int32)
     t_rows = torch.tensor([0.0, 700.0], device=dev)
@@ -283,3 +296,6 @@ def test_full_size_token_shards_in_one_process(ways, exchange, lat_hw):
         e = rel_rms(outs[r], ref)
         assert e < 5e-3, (r, e)
     assert all(torch.equal(outs[0], outs[r]) for r in range(1, ways))
+    if prompt_tokens < 512:
+        folded = [v[2] for v in m._text_cache.values()]
+        assert folded and all(t.tail is not None and t.w2 is not None for t in folded)
