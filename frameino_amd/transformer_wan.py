@@ -366,7 +366,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         all-zero rows worth folding into one key, else None.  One host read per prompt (the result is cached with the K / V)."""
         o = self.ops
         b, lt, _ = ehs.shape
-        if not (self.dedup_text_padding and hasattr(o, "attention_tail") and ehs.is_cuda):
+        if not (self.dedup_text_padding and hasattr(o, "attention_tail")):
             return None
         live = (ehs != 0).any(dim=-1)                                                  # [b, lt]
         last = torch.where(live.any(dim=1), lt - 1 - live.flip(1).int().argmax(dim=1), torch.full((b,), -1, device=ehs.device))

@@ -147,3 +147,74 @@ def test_step_graph_policy_and_schedule():
     assert not G.StepGraph(lambda: None, False, True, 50).enabled
     with pytest.raises(RuntimeError, match="cannot be captured"):
         G.StepGraph(lambda: None, True, False, 50)
+
+
+def test_text_padding_fold_and_reassociated_out_projection_are_exact_algebra_in_fp32():
+    """The host logic of DESIGN.md 4.6 / 4.7 without a GPU: `_text_tail` (the zero run found per sample, rows kept, key counts,
+    multiplicities) and `_text_out_weights` (W2 = [W_o,h V_h^T]_h from the block-diagonal V) driven through torch stand-ins of
+    fino_attn_fwd_tail / fino_attn_probs / fino_row_rrms in fp32: the folded forward and the folded + re-associated forward equal
+    the forward over all text rows up to fp32 rounding -- the identities are exact, only bf16 rounding separates them on the GPU."""
+    import math
+    import types
+    from tests import cpu_ops
+    torch.manual_seed(11)
+    m = _tiny().float().eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape) * (0.5 if p_.ndim == 1 else p_.shape[-1] ** -0.5))
+    m.reset_caches()
+    ops = types.SimpleNamespace(**{k: getattr(cpu_ops, k) for k in dir(cpu_ops) if not k.startswith("_")})
+
+    def logits(q, k, heads, lk_b, mult):
+        b, lq, hd = q.shape
+        dh = hd // heads
+        s = (q.reshape(b, lq, heads, dh).transpose(1, 2).float() @ k.reshape(b, -1, heads, dh).transpose(1, 2).float().transpose(2, 3)) * dh ** -0.5
+        for i in range(b):
+            s[i, :, :, lk_b[i] - 1] += math.log(mult[i])
+            s[i, :, :, lk_b[i]:] = -math.inf
+        return s
+
+    def attention_tail(q, k, v, heads, lk_b, tail_mult, out=None, scale=None):
+        b, lq, hd = q.shape
+        p = torch.softmax(logits(q, k, heads, lk_b, tail_mult), dim=-1)
+        o = (p @ v.reshape(b, -1, heads, hd // heads).transpose(1, 2).float()).transpose(1, 2).reshape(b, lq, hd).to(q.dtype)
+        return o if out is None else out.copy_(o)
+
+    def attention_probs(q, k, heads, lk_b, tail_mult, kp, out=None, scale=None, q_rrms=None, q_weight=None):
+        b, lq, hd = q.shape
+        if q_rrms is not None:
+            q = q * q_rrms.reshape(b, lq, 1) * q_weight
+        p = torch.softmax(logits(q, k, heads, lk_b, tail_mult), dim=-1)[..., :kp]          # [b, heads, lq, kp]
+        p = p.transpose(1, 2).reshape(b, lq, heads * kp).to(q.dtype)
+        return p if out is None else out.copy_(p)
+
+    ops.attention_tail, ops.attention_probs = attention_tail, attention_probs
+    ops.attention_tail_supported = ops.attention_probs_supported = lambda *a: True
+    ops.row_rrms = lambda x, eps, out=None: out.copy_(torch.rsqrt(x.float().pow(2).mean(-1) + eps)) if out is not None \
+        else torch.rsqrt(x.float().pow(2).mean(-1) + eps)
+    m.ops = ops
+    x = torch.randn(1, 8, 2, 4, 4).expand(2, -1, -1, -1, -1).contiguous()
+    txt = torch.randn(2, 256, 16)
+    txt[0, 5:] = 0
+    txt[1, 3:] = 0
+    ts = torch.tensor([700.0, 700.0])
+
+    def run(fold, reassoc):
+        m.dedup_text_padding, m.reassociate_text_out = fold, reassoc
+        m.reset_caches()
+        y = m(x, ts, txt, return_dict=False)[0]
+        return y, next(iter(m._text_cache.values()))[2]
+
+    plain, t0 = run(False, False)
+    folded, t1 = run(True, False)
+    both, t2 = run(True, True)
+    assert t0.tail is None and t0.lt == 256
+    assert t1.tail == ([6, 4], [251.0, 253.0]) and t1.lt == 128 and t1.w2 is None
+    assert t2.w2 is not None and t2.kp == [8, 8] and t2.w2[0][0].shape == (48, 2 * 8)
+    assert (folded - plain).abs().max().item() < 1e-4 * plain.abs().max().item()
+    assert (both - plain).abs().max().item() < 1e-4 * plain.abs().max().item()
+    # a prompt without a zero run is left alone
+    m.dedup_text_padding, m.reassociate_text_out = True, True
+    m.reset_caches()
+    m(x, ts, torch.randn(2, 256, 16), return_dict=False)
+    assert next(iter(m._text_cache.values()))[2].tail is None
