@@ -136,3 +136,20 @@ def test_probabilities_with_q_normalised_on_load_equal_those_of_the_normalised_q
     ops.rmsnorm_rope_(qn, w, 1e-6)
     p_ref = ops.attention_probs(qn.view(b, lq, d), k, heads, lk_b, mult, 72)
     assert torch.equal(p_fused, p_ref)
+
+
+@pytest.mark.parametrize("grid", [1, 3, 7])
+def test_tail_attention_runs_that_walk_across_samples_with_different_key_counts(grid):
+    """FINO_TUNE_ATTN_WALK_GRID small: one workgroup walks a run of q-blocks that crosses heads AND samples, i.e. the per-sample key
+    count and logit offset change inside a run (and the K / V streams, three tiles ahead, are already in the next sample)"""
+    from frameino_amd import _lib, ops
+    b, heads, lq, n_real, total, lc = 3, 2, 700, (5, 190, 64), 256, 192
+    q, k, v, kc, vc, lk_b, mult = _case(b, heads, lq, n_real, total, lc, seed=grid)
+    ref = ops.attention_tail(q, kc, vc, heads, lk_b, mult)
+    _lib.lib().fino_tune_set(6, grid)
+    try:
+        out = ops.attention_tail(q, kc, vc, heads, lk_b, mult)
+    finally:
+        _lib.lib().fino_tune_set(6, 0)
+    assert torch.equal(out, ref)
+    assert rel_rms(out, _sdpa(q, k, v, heads)) < 2 ** -7.5
