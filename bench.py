@@ -412,9 +412,9 @@ def main():
         # FLOPs actually issued: on one GPU the two CFG branches are one batch-2 forward whose branch-invariant prefix
         # runs once (the N > 1 plans run two whole batch-1 forwards)
         shared = not multi and getattr(model, "dedup_shared_prefix", False) and not a.cfg_streams
-        # ... the text K / V come from the per-prompt cache, and on one GPU the zero-padded tails of the two prompts (64 and 8
-        # tokens of 512: make_inputs) are one key each
-        fold = not multi and getattr(model, "dedup_text_padding", False)
+        # ... the text K / V come from the per-prompt cache, and the zero-padded tails of the two prompts (64 and 8 tokens of 512:
+        # make_inputs) are one key each (token shards included)
+        fold = getattr(model, "dedup_text_padding", False)
         flops_step = sum(wan_flops_per_forward(L, cfg, cross_keys=(ck if fold else None), text_proj=False) for ck in (65, 9)) \
             - (wan_flops_shared_prefix(L, cfg) if shared else 0)
         out = {
