@@ -94,6 +94,17 @@ def test_wan_call_with_prompt_strings_vs_the_reference_run(golden):
     r = rel_rms(lat, a["out_latents_prompt"])
     record("wan_call[prompt strings]", "rel_rms hip bf16 __call__(prompt=...) latents vs reference fp32 run", r, 6e-2)
     assert lat.shape == a["out_latents_prompt"].shape and r < 6e-2, r
+    # the reference zero-pads the prompt to 512 rows (:235-238) and attends to all of them; this run folded the padding of both
+    # prompts into one key each and re-associated the text out-projection -- against the REFERENCE's latents
+    folded = [v[2] for v in m._text_cache.values()]
+    assert folded and all(t.tail is not None and t.w2 is not None and t.lt == 128 for t in folded)
+    m.dedup_text_padding = False
+    lat_all_rows = pipe(prompt=str(a["prompt"]), negative_prompt=str(a["negative_prompt"]), latents=a["latents0"].clone(), **kw).frames
+    m.dedup_text_padding = True
+    assert all(v[2].tail is None for v in m._text_cache.values())
+    r_all = rel_rms(lat_all_rows, a["out_latents_prompt"])
+    record("wan_call[prompt strings, all 512 text rows]", "rel_rms hip bf16 latents vs reference fp32 run (padding NOT folded)", r_all, 6e-2)
+    assert r < 1.2 * r_all + 2e-3, (r, r_all)
     # the text really went in: the run with the recorded random embeddings is a different clip
     assert rel_rms(a["out_latents_prompt"], a["out_latents"]) > 5 * r
     with pytest.raises(ValueError, match="Cannot forward both `prompt` and `prompt_embeds`"):
