@@ -61,6 +61,16 @@ def test_tail_attention_equals_attention_on_the_expanded_keys(b, heads, lq, n_re
     assert r_tail < 2 ** -7.5 and r_tail < 1.3 * r_full + 1e-4 and r_between < 2 ** -7.5, (r_tail, r_full, r_between)
 
 
+def test_tail_attention_fp16():
+    from frameino_amd import ops
+    b, heads, lq, n_real, total, lc = 2, 4, 1000, (64, 8), 512, 128
+    q, k, v, kc, vc, lk_b, mult = _case(b, heads, lq, n_real, total, lc, seed=4, dtype=torch.float16)
+    tail = ops.attention_tail(q, kc, vc, heads, lk_b, mult)
+    r = rel_rms(tail, _sdpa(q, k, v, heads))
+    record("attention_tail[fp16]", "rel_rms vs fp32 SDPA on the expanded keys", r, 2 ** -10)
+    assert r < 2 ** -10, r
+
+
 def test_tail_attention_with_multiplicity_one_is_attention_on_the_first_keys():
     """tail_mult = 1: nothing but per-batch key counts -- the same sums over the same keys"""
     from frameino_amd import ops
