@@ -211,14 +211,19 @@ extern "C" int fino_attn_probs(const void* q, const void* k, void* p, int batch,
     }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((lq + 127) / 128), (unsigned)(batch * heads));
-    const bool two = lk <= 64 && kp <= 64;
-    if (dtype == FINO_BF16) {
-        if (two) attn_probs_kernel<BF16, 2><<<grid, 256, 0, st>>>(pp);
-        else attn_probs_kernel<BF16, 4><<<grid, 256, 0, st>>>(pp);
-    } else {
-        if (two) attn_probs_kernel<F16, 2><<<grid, 256, 0, st>>>(pp);
-        else attn_probs_kernel<F16, 4><<<grid, 256, 0, st>>>(pp);
+    int max_lk = 0;
+    for (int b = 0; b < batch; ++b) max_lk = lk_b[b] > max_lk ? lk_b[b] : max_lk;
+    // as many 32-key blocks of accumulators as the keys and the output columns need: 72 / ~100 / 130 registers
+    const int need = max_lk > kp ? max_lk : kp;
+    const int nkb = need <= 64 ? 2 : (need <= 96 ? 3 : 4);
+#define PROBS_LAUNCH(T_)                                                                                      \
+    {                                                                                                         \
+        if (nkb == 2) attn_probs_kernel<T_, 2><<<grid, 256, 0, st>>>(pp);                                     \
+        else if (nkb == 3) attn_probs_kernel<T_, 3><<<grid, 256, 0, st>>>(pp);                                \
+        else attn_probs_kernel<T_, 4><<<grid, 256, 0, st>>>(pp);                                              \
     }
+    if (dtype == FINO_BF16) PROBS_LAUNCH(BF16) else PROBS_LAUNCH(F16)
+#undef PROBS_LAUNCH
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }
