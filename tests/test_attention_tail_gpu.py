@@ -163,3 +163,30 @@ def test_tail_attention_runs_that_walk_across_samples_with_different_key_counts(
         _lib.lib().fino_tune_set(6, 0)
     assert torch.equal(out, ref)
     assert rel_rms(out, _sdpa(q, k, v, heads)) < 2 ** -7.5
+
+
+def test_tail_and_probabilities_random_shapes():
+    """random (samples, heads, rows, prompt lengths, allocated rows): the tail kernel against fp32 SDPA over the expanded keys, the
+    probabilities against fp32 softmax, P.V of the probabilities against the tail kernel's output"""
+    import os
+    import random
+    from frameino_amd import ops
+    rng = random.Random(int(os.environ.get("FINO_FUZZ_SEED", "20240")))
+    for case in range(int(os.environ.get("FINO_FUZZ_CASES", "16"))):
+        b = rng.randint(1, 4)
+        heads = rng.choice([1, 2, 3, 6])
+        lq = rng.randint(1, 1400)
+        lc = rng.choice([128, 128, 192])
+        total = rng.choice([256, 512])
+        n_real = tuple(rng.randint(0, min(lc, total) - 2) for _ in range(b))
+        q, k, v, kc, vc, lk_b, mult = _case(b, heads, lq, n_real, total, lc, seed=1000 + case)
+        ref = _sdpa(q, k, v, heads)
+        tail = ops.attention_tail(q, kc, vc, heads, lk_b, mult)
+        r = rel_rms(tail, ref)
+        assert r < 2 ** -7.5, (case, b, heads, lq, lc, total, n_real, r)
+        if lc <= 128:
+            kp = -(-max(lk_b) // 8) * 8
+            p = ops.attention_probs(q, kc, heads, lk_b, mult, kp).float().view(b, lq, heads, kp)
+            vh = vc[:, :kp].float().view(b, kp, heads, 128)
+            o = torch.einsum("blhk,bkhd->blhd", p, vh).reshape(b, lq, heads * 128)
+            assert rel_rms(o, ref) < 2 ** -7, (case, "probs", rel_rms(o, ref))
