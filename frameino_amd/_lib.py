@@ -91,6 +91,10 @@ SIGNATURES = {
     "fino_cfg_dpm_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_void_p],
     "fino_conv3d": [c_void_p] * 4 + [c_int] * 19 + [c_void_p, c_void_p, c_int, c_void_p],
     "fino_rmsnorm_silu_cl": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "fino_split_bf16": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, ctypes.c_uint, c_void_p],
+    "fino_rmsnorm_silu_cl_f32": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_uint, c_void_p],
+    "fino_conv3d_split": [c_void_p] * 4 + [c_int] * 20 + [c_void_p, c_void_p, c_void_p],
+    "fino_vae_blend_tiles": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
     "fino_softmax_rows": [c_void_p, c_i64, c_int, c_i64, c_float, c_int, c_void_p],
     "fino_dup_up3d_add": [c_void_p] * 3 + [c_int] * 10 + [c_void_p],
     "fino_avg_down3d_add": [c_void_p] * 3 + [c_int] * 10 + [c_void_p],
@@ -104,7 +108,7 @@ _RESTYPES = {"fino_last_error": ctypes.c_char_p, "fino_attn_workspace_bytes": c_
 
 # the FINO_VERSION this table (argument lists, tune-knob meanings) was written for: a stale library found through
 # FINO_LIB_PATH would otherwise fail late (AttributeError on a new symbol) or silently misread an argument
-ABI_VERSION = 102
+ABI_VERSION = 103
 
 
 def declared_symbols(header_path=HEADER_PATH):

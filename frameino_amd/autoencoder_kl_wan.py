@@ -31,6 +31,15 @@ class _Config(dict):
     __getattr__ = dict.__getitem__
 
 
+class _Planes:
+    """an activation already cut into the bf16 planes a split-bf16 convolution reads ([T, H, W, planes * Cpad], hi | mid | lo
+    side by side): what the fp32-compute mode's norm kernel emits, so that the convolution behind it needs no split pass"""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
 class DiagonalGaussianDistribution:
     """diffusers' posterior object for the two calls the pipelines make (mode / sample)."""
 
@@ -130,8 +139,9 @@ class AutoencoderKLWan(FromPretrainedMixin):
                               scale_factor_temporal=scale_factor_temporal, scale_factor_spatial=scale_factor_spatial)
         self._sd = None
         self._pk = None
-        self._dtype = torch.bfloat16           # compute dtype of the convolutions (bf16 | fp16)
+        self._dtype = torch.bfloat16           # MFMA operand dtype of the convolutions (bf16 | fp16)
         self._io_dtype = None                  # what `.dtype` reports when fp32 was asked for (reference app.py:157)
+        self._planes = 0                       # 0: convolutions in `_dtype`; 2 | 3: fp32-compute mode on split-bf16 products
         self._device = torch.device("cpu")
         self.use_slicing = self.use_tiling = False
         self.tile_sample_min_height = self.tile_sample_min_width = 256            # reference :1070-1075 (recorded only)
@@ -152,9 +162,33 @@ class AutoencoderKLWan(FromPretrainedMixin):
 
     @property
     def compute_dtype(self):
-        """the dtype the convolutions run in (bf16 | fp16 MFMA operands, fp32 accumulation) -- differs from `.dtype` when
-        fp32 was asked for"""
-        return self._dtype
+        """the precision the convolutions compute in: bf16 | fp16 (MFMA operands of that type, fp32 accumulation; differs from
+        `.dtype` when fp32 was asked for), or float32 after `set_compute_dtype(torch.float32)`"""
+        return torch.float32 if self._planes else self._dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, dtype):
+        self.set_compute_dtype(dtype)
+
+    def set_compute_dtype(self, dtype, planes=3):
+        """`torch.float32`: compute like the fp32 the reference app runs this VAE in (app.py:157, decode :1198-1227).  Activations
+        stay fp32 between layers, norms / SiLU / the mid-block softmax are fp32 arithmetic, and every convolution and matrix
+        product is a SPLIT-BF16 product on the matrix pipe: each fp32 operand is three bf16 planes (hi + mid + lo, 24 significant
+        bits), the six cross terms >= 2^-16 relative are accumulated in the MFMA's fp32 accumulator (fino_conv3d_split;
+        include/frameino_hip.h has the arithmetic) -- fp32-faithful at 1/6 of the bf16 rate (the fp32-input MFMA: 1/16).
+        `planes=2`: hi + lo, three terms, ~2^-16 relative, 1/3 of the bf16 rate.  `torch.bfloat16` / `torch.float16`: back to
+        16-bit convolutions (the default).  The interface dtype (`.dtype`, inputs, outputs) is not touched.
+        Measured (tests/test_fullsize_oracle_gpu.py, tests/test_wan_vae_gpu.py): see DESIGN.md section 4.8."""
+        if dtype == torch.float32:
+            if planes not in (2, 3):
+                raise ValueError("planes must be 2 (hi + lo) or 3 (hi + mid + lo)")
+            self._planes, self._dtype = int(planes), torch.bfloat16
+        elif dtype in (torch.bfloat16, torch.float16):
+            self._planes, self._dtype = 0, dtype
+        else:
+            raise ValueError(f"compute dtype {dtype}: float32, bfloat16 or float16")
+        self._pk = None
+        return self
 
     @property
     def device(self):
@@ -174,9 +208,11 @@ class AutoencoderKLWan(FromPretrainedMixin):
                 warnings.warn("AutoencoderKLWan(torch_dtype=float32): inputs, outputs and `.dtype` are fp32 as asked "
                               "(reference app.py:157), but the convolutions compute in bf16 with fp32 accumulation "
                               "(`.compute_dtype`); measured against an fp32 decode at 704x1280: PSNR 50.5 dB, rel-RMS "
-                              "1.1e-2 (tests/test_fullsize_oracle_gpu.py)", RuntimeWarning, stacklevel=3)
+                              "1.1e-2 (tests/test_fullsize_oracle_gpu.py).  `vae.set_compute_dtype(torch.float32)` computes "
+                              "like fp32 (split-bf16 products, ~6x the decode time)", RuntimeWarning, stacklevel=3)
         else:
             self._io_dtype, self._dtype = None, dtype
+            self._planes = 0
 
     # ---- diffusers' memory switches (architecture/autoencoder_kl_wan.py:1084-1133) ----
     def enable_slicing(self):
@@ -290,6 +326,17 @@ class AutoencoderKLWan(FromPretrainedMixin):
             for s in range(halves):
                 w2[s * cop:s * cop + coh, :, :ci] = wt[s * coh:(s + 1) * coh]
                 b2[s * cop:s * cop + coh] = b[s * coh:(s + 1) * coh]
+            if self._planes:
+                # fp32-compute mode: one bf16 weight plane per PRODUCT of the split expansion, per tap ([Cout, tap, product,
+                # Cin]: the order the convolution's K walk visits, ops.SPLIT_PRODUCTS); bias stays fp32.  1 x 1 layers used as
+                # plain matrix products (the mid-block attention) also keep the A-side expansion of their weight.
+                w6 = ops.split_bf16(w2.reshape(halves * cop * kt * kh * kw, cip).contiguous(), "W", self._planes)
+                e = SimpleNamespace(w=w6.reshape(halves * cop, -1), b=b2.contiguous(), k=(kt, kh, kw), ci=ci, co=coh, cip=cip,
+                                    cop=cop)
+                if kt * kh * kw == 1:
+                    e.w_a = ops.split_bf16(w2.reshape(halves * cop, cip).contiguous(), "A", self._planes)
+                pk[name] = e
+                return
             pk[name] = SimpleNamespace(w=w2.reshape(halves * cop, -1).to(dt).contiguous(), b=b2.to(dt), k=(kt, kh, kw),
                                        ci=ci, co=coh, cip=cip, cop=cop)
 
@@ -316,6 +363,9 @@ class AutoencoderKLWan(FromPretrainedMixin):
     # ---- layer helpers (all on channels-last [T, H, W, Cpad]) ----
     def _conv(self, x, name, pad, stride=(1, 1, 1), up=False, residual=None, out_thw=None):
         e = self._pk[name]
+        if self._planes:
+            xp = x.t if isinstance(x, _Planes) else ops.split_bf16(x, "planes", self._planes)
+            return ops.conv3d_split_cl(xp, e.w, e.b, e.k, self._planes, stride, pad, out_thw, up, residual)
         return ops.conv3d_cl(x, e.w, e.b, e.k, stride, pad, out_thw, up, residual)
 
     def _causal3(self, x, name, residual=None, caches=None):
@@ -326,15 +376,21 @@ class AutoencoderKLWan(FromPretrainedMixin):
         kt, kh, kw = e.k
         if caches is None or kt == 1:
             return self._conv(x, name, (kt - 1, kh // 2, kw // 2), residual=residual)
+        if self._planes and not isinstance(x, _Planes):          # (the history is kept as the planes the convolution reads)
+            x = _Planes(ops.split_bf16(x, "planes", self._planes))
+        xt = x.t if isinstance(x, _Planes) else x
         prev = caches.get(name)
         if prev is None:                               # first chunk: the history is zeros (same as the front padding)
-            prev = torch.zeros((kt - 1,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        xin = torch.cat([prev, x], dim=0)
+            prev = torch.zeros((kt - 1,) + tuple(xt.shape[1:]), dtype=xt.dtype, device=xt.device)
+        xin = torch.cat([prev, xt], dim=0)
         caches[name] = xin[-(kt - 1):].clone()
-        return self._conv(xin, name, (0, kh // 2, kw // 2), residual=residual)
+        return self._conv(_Planes(xin) if isinstance(x, _Planes) else xin, name, (0, kh // 2, kw // 2), residual=residual)
 
-    def _norm(self, x, name, silu=True):
+    def _norm(self, x, name, silu=True, split="planes"):
         e = self._pk[name]
+        if self._planes:
+            y = ops.rmsnorm_silu_cl_f32(x, e.g, e.c, silu, split, self._planes)
+            return _Planes(y) if split == "planes" else y
         return ops.rmsnorm_silu_cl(x, e.g, e.c, silu)
 
     def _res(self, x, p, caches=None):
@@ -342,8 +398,45 @@ class AutoencoderKLWan(FromPretrainedMixin):
         y = self._causal3(self._norm(x, p + ".norm1.gamma"), p + ".conv1", caches=caches)
         return self._causal3(self._norm(y, p + ".norm2.gamma"), p + ".conv2", residual=h, caches=caches)
 
+    def _attn_f32(self, x, p):
+        """WanAttentionBlock (:402-427) in the fp32-compute mode: every matrix product a split-bf16 product with fp32 output
+        (ops.gemm_f32 on operands expanded by ops.split_bf16), norm and softmax in fp32."""
+        t, h, w, cp = x.shape
+        e, pr, np_ = self._pk[p + ".to_qkv"], self._pk[p + ".proj"], self._planes
+        nprod = len(ops.SPLIT_PRODUCTS[np_])
+        c, hw = e.co, h * w
+        hwp = (hw + 63) // 64 * 64                               # K of the P.V product: whole 64-wide K-tiles
+        n = self._norm(x, p + ".norm.gamma", silu=False, split=None).view(t, hw, cp)
+        k6 = nprod * cp
+        wq, wk = e.w[:cp], e.w[cp:2 * cp]                         # W-side expansions [cp, products * cp]
+        wv_a = e.w_a[2 * cp:]                                     # A-side expansion of W_v: V^T = W_v . n^T
+        bq, bk, bv = e.b[:cp], e.b[cp:2 * cp], e.b[2 * cp:]
+        assert wq.shape[1] == k6
+        out = torch.empty_like(x).view(t, hw, cp)
+        scale = c ** -0.5
+        for f in range(t):
+            nf = n[f]
+            if hwp != hw:
+                nf = torch.zeros(hwp, cp, dtype=torch.float32, device=x.device)
+                nf[:hw] = n[f]
+            n_a, n_w = ops.split_bf16(nf, "A", np_), ops.split_bf16(nf, "W", np_)
+            q = ops.gemm_f32(n_a[:hw], wq, bq)                                       # [hw, cp]
+            k = ops.gemm_f32(n_a, wk, bk)                                            # [hwp, cp]
+            if hwp != hw:
+                k[hw:] = 0
+            vt = ops.gemm_f32(wv_a, n_w)                                             # V^T [cp, hwp]; bias after P.V (rows of P sum to 1)
+            s_ = ops.gemm_f32(ops.split_bf16(q, "A", np_), ops.split_bf16(k, "W", np_))      # [hw, hwp]
+            ops.softmax_rows_(s_, hw, scale)
+            if hwp != hw:
+                s_[:, hw:] = 0
+            o = ops.gemm_f32(ops.split_bf16(s_, "A", np_), ops.split_bf16(vt, "W", np_), bv)
+            ops.gemm_f32(ops.split_bf16(o, "A", np_), pr.w, pr.b, residual=x.view(t, hw, cp)[f], out=out[f])
+        return out.view(t, h, w, cp)
+
     def _attn(self, x, p):
         """WanAttentionBlock (:402-427): one head of dim C over the h.w tokens of each frame."""
+        if self._planes:
+            return self._attn_f32(x, p)
         t, h, w, cp = x.shape
         e = self._pk[p + ".to_qkv"]
         c, hw = e.co, h * w
@@ -391,6 +484,8 @@ class AutoencoderKLWan(FromPretrainedMixin):
         tup = cfg.temperal_downsample[::-1]
         zc = cfg.z_dim
         _, _, t, h, w = z.shape
+        if self._planes:
+            dt = torch.float32                          # fp32-compute mode: activations stay fp32 between the layers
         x = torch.zeros(t, h, w, cpad(zc), dtype=dt, device=z.device)
         x[..., :zc] = z[0].permute(1, 2, 3, 0).to(dt)
         x = self._causal3(x, "post_quant_conv")
@@ -439,6 +534,8 @@ class AutoencoderKLWan(FromPretrainedMixin):
             # measured: the whole-sequence peak is ~6.4 tensors of [T, H/2, W/2, decoder_base_dim] at the output size
             sp = 2 ** (nb - 1 - (last_temporal + 1))
             est = 6.4 * tt * x.shape[1] * sp * x.shape[2] * sp * cpad(cfg.decoder_base_dim) * 2 / 2 ** 30
+            if self._planes:
+                est *= 2 + self._planes                 # fp32 activations + their bf16 planes
             chunk = 8 if est > self.decode_memory_budget_gib else 0
         if not chunk or chunk >= tt or last_temporal + 1 >= nb:
             for i in range(last_temporal + 1, nb):
@@ -466,6 +563,8 @@ class AutoencoderKLWan(FromPretrainedMixin):
         enc = [cfg.base_dim * u for u in [1] + mult]
         tdown = cfg.temperal_downsample
         ps = cfg.patch_size or 1
+        if self._planes:
+            dt = torch.float32
         x = ops.vae_patchify(x[0].float().contiguous(), cpad(cfg.in_channels), ps, dt)
         x = self._causal3(x, "encoder.conv_in")
         nb = len(mult)

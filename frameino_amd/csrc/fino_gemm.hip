@@ -340,6 +340,9 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     // CONV state: packed output position of my 4 A rows; the tap (dt, dh, dw) and channel chunk of the NEXT tile to stage
     uint32_t pos[CONV ? 4 : 1];
     int ck = 0, tap_t = 0, tap_h = 0, tap_w = 0, t_first = 0, t_in_first = 0;
+    // split-bf16 convolution (GemmParams::a_cc > 0): the product (segment) and the chunk inside it of the NEXT tile to stage, and
+    // that tile's byte offset inside an A row -- plane {0,0,1}[seg] or {0,0,0,1,1,2}[seg] of the side-by-side planes
+    int cseg = 0, seg = 0, a_koff = 0;
     const uint16_t* a_base_ptr = p.a;
     int64_t a_bytes = ((p.m - 1) * p.lda + p.k) * 2;
     if constexpr (ABLK)
@@ -381,13 +384,20 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     };
     // state -> the K-tile after the one just staged
     auto conv_next = [&]() {
+        if (p.a_cc > 0 && ++cseg == p.a_cc) { cseg = 0; ++seg; }
         if (++ck == p.cin_chunks) {
-            ck = 0;
+            ck = 0; cseg = 0; seg = 0;
             if (++tap_w == p.kw) {
                 tap_w = 0;
                 if (++tap_h == p.kh) { tap_h = 0; ++tap_t; }
             }
             conv_offsets();
+        }
+        if (p.a_cc > 0) {
+            const int plane = p.a_nplanes == 3 ? (seg >= 3) + (seg >= 5) : (seg >= 2);
+            a_koff = (plane * p.a_cc + cseg) * (BK * 2);
+        } else {
+            a_koff = ck * (BK * 2);
         }
     };
     if constexpr (CONV) {
@@ -419,7 +429,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
     if ((QI_) < NA1 || wm == 0)                                                                                   \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
             a_rsrc, (FINO_LDS void*)(smem + (STAGE_) * kStageBytes + ((aq0 + (QI_)) * 32 + wn * 8) * 128), 16,    \
-            a_off[QI_], CONV ? ck * (BK * 2) : (ABLK ? ablk_koff(p, kb + (KT_)) : (kb + (KT_)) * (BK * 2)), 0, GP_DMA_AUX);
+            a_off[QI_], CONV ? a_koff : (ABLK ? ablk_koff(p, kb + (KT_)) : (kb + (KT_)) * (BK * 2)), 0, GP_DMA_AUX);
 #define PP_DMA_W(STAGE_, KT_, Q_)                                                                                 \
     if (!CONV || (Q_) < w_pieces)                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                 \
@@ -689,27 +699,30 @@ inline double plan_launch_cost(int64_t rows, int mi, int tiles_n, int cus) {
 // `tile_m`: the caller's per-call choice (fino_gemm_split_n / fino_gemm_blocked_a: 2..7 -> one launch of 32 x that many rows
 // per tile, 8 -> 256-row tiles only); 0 = planned, or what the A/B knob FINO_TUNE_GEMM_TILE_M says (tools/ only).
 // The search is (M / 256) x 7 cost evaluations and depends on (m, tiles_n, cus) only: memoised in a small direct-mapped
-// table (a step makes ~240 GEMM calls of a handful of shapes; a racing writer can at worst make a reader recompute).
-struct PlanSlot { std::atomic<uint64_t> key; std::atomic<uint64_t> val; };
+// table (a step makes ~240 GEMM calls of a handful of shapes).  Key AND plan live in ONE 64-bit atomic word per slot --
+// [m : 24 | tiles_n : 9 | cus : 9 | rows1 / 256 (0xffff = all rows) : 16 | mi2 - 1 : 3 | unused : 2 | valid : 1] -- so two host threads that
+// race on a slot (ctypes releases the GIL: a VAE thread beside a DiT thread) can only replace a whole entry, never pair one
+// shape's key with another shape's plan (round 4 kept key and value in two words); shapes beyond the fields skip the memo.
 inline TilePlan plan_tiles_search(int64_t m, int tiles_n, int cus);
 inline TilePlan plan_tiles(int64_t m, int tiles_n, int cus, int tile_m = 0) {
     const int forced = tile_m ? tile_m : fino_tune_get(FINO_TUNE_GEMM_TILE_M);
     if (forced >= 2 && forced <= 7) return TilePlan{0, forced};
     if (forced == 8 || m <= 0) return TilePlan{m, 8};
-    static PlanSlot memo[64];
-    // key: m (40 bits) | tiles_n (14 bits) | cus (10 bits); 0 never occurs (cus > 0)
-    const uint64_t key = ((uint64_t)m << 24) | ((uint64_t)(tiles_n & 0x3fff) << 10) | (uint64_t)(cus & 0x3ff);
-    PlanSlot& slot = memo[(key * 0x9E3779B97F4A7C15ull) >> 58];
-    if (m < (1ll << 40) && slot.key.load(std::memory_order_acquire) == key) {
-        const uint64_t v = slot.val.load(std::memory_order_relaxed);
-        if (slot.key.load(std::memory_order_acquire) == key) return TilePlan{(int64_t)(v >> 8), (int)(v & 0xff)};
+    static std::atomic<uint64_t> memo[64];
+    const bool memoable = m < (1ll << 24) && tiles_n > 0 && tiles_n < 512 && cus > 0 && cus < 512;
+    const uint64_t key = ((uint64_t)m << 18) | ((uint64_t)tiles_n << 9) | (uint64_t)cus;            // 42 bits
+    std::atomic<uint64_t>& slot = memo[(key * 0x9E3779B97F4A7C15ull) >> 58];
+    if (memoable) {
+        const uint64_t e = slot.load(std::memory_order_relaxed);
+        if ((e & 1) && (e >> 22) == key) {
+            const uint64_t r = (e >> 6) & 0xffff;                    // 0xffff: every row in 256-row tiles (rows1 = m)
+            return TilePlan{r == 0xffff ? m : (int64_t)r * 256, (int)((e >> 3) & 7) + 1};
+        }
     }
     const TilePlan tp = plan_tiles_search(m, tiles_n, cus);
-    if (m < (1ll << 40)) {
-        slot.key.store(0, std::memory_order_release);
-        slot.val.store(((uint64_t)tp.rows1 << 8) | (uint64_t)tp.mi2, std::memory_order_relaxed);
-        slot.key.store(key, std::memory_order_release);
-    }
+    if (memoable && (tp.rows1 == m || (tp.rows1 % 256 == 0 && tp.rows1 / 256 < 0xffff)) && tp.mi2 >= 2 && tp.mi2 <= 8)
+        slot.store((key << 22) | ((tp.rows1 == m ? 0xffffull : (uint64_t)(tp.rows1 / 256)) << 6) |
+                       ((uint64_t)(tp.mi2 - 1) << 3) | 1ull, std::memory_order_relaxed);
     return tp;
 }
 inline TilePlan plan_tiles_search(int64_t m, int tiles_n, int cus) {
@@ -790,6 +803,16 @@ int launch_gemm_rows(GemmParams p, int64_t r0, int64_t rows, int mi, int epi, hi
 template <typename T, bool GENERIC>
 int launch_gemm_e(const GemmParams& p, int epi, int tile_m, hipStream_t st) {
     const bool fits32 = ((p.m - 1) * p.lda + p.k) * 2 < (1ll << 31) && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
+    if (epi == FINO_EPI_F32 || epi == FINO_EPI_F32_RESIDUAL) {
+        // fp32 output (the split-bf16 products of the Wan VAE's mid-block attention): one launch of 256-row tiles on the
+        // ping-pong loop -- the row-offset arithmetic of the planned two-launch form counts T elements
+        if (GENERIC || !fits32) {
+            fino_set_error("fino_gemm: the fp32-output epilogues need K %% 64 == 0, 16-byte aligned operands and operands < 2 GiB");
+            return FINO_ERR_UNSUPPORTED;
+        }
+        return epi == FINO_EPI_F32 ? launch_gemm_pp<T, FINO_EPI_F32, false, 8>(p, st)
+                                   : launch_gemm_pp<T, FINO_EPI_F32_RESIDUAL, false, 8>(p, st);
+    }
     if (!GENERIC && use_pingpong() && fits32) {
         const TilePlan tp = plan_tiles(p.m, p.tiles_n, gemm_device_cus(), tile_m);
         if (tp.rows1 > 0)
@@ -886,9 +909,12 @@ extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias,
                FINO_ERR_ARG, "fino_gemm: leading dimensions must be multiples of 8 and cover the row");
     FINO_CHECK(fino_aligned16(a) && fino_aligned16(w) && fino_aligned16(c), FINO_ERR_ARG,
                "fino_gemm: A/W/C must be 16-byte aligned");
-    FINO_CHECK(epilogue >= FINO_EPI_NONE && epilogue <= FINO_EPI_GATED_RESIDUAL_STAGED, FINO_ERR_ARG,
+    FINO_CHECK(epilogue >= FINO_EPI_NONE && epilogue <= FINO_EPI_F32_RESIDUAL, FINO_ERR_ARG,
                "fino_gemm: epilogue %d", epilogue);
-    if (epilogue >= FINO_EPI_RESIDUAL)
+    if (epilogue == FINO_EPI_F32 || epilogue == FINO_EPI_F32_RESIDUAL)
+        FINO_CHECK(!c2 && tile_m == 0 && fino_aligned16(bias), FINO_ERR_ARG,
+                   "fino_gemm: the fp32-output epilogues take one output, the planned tiling and a 16-byte aligned fp32 bias");
+    if (epilogue >= FINO_EPI_RESIDUAL && epilogue != FINO_EPI_F32)
         FINO_CHECK(r && ldr % 8 == 0 && ldr >= n && fino_aligned16(r), FINO_ERR_ARG, "fino_gemm: residual operand");
     if (epilogue == FINO_EPI_GATED_RESIDUAL || epilogue == FINO_EPI_GATED_RESIDUAL_STAGED)
         FINO_CHECK(gate && fino_aligned16(gate) && mod_stride % 4 == 0, FINO_ERR_ARG, "fino_gemm: gate operand");
@@ -964,10 +990,34 @@ extern "C" int fino_gemm_blocked_a(const void* a, const void* w, const void* bia
     return FINO_OK;
 }
 
+// fino_conv3d and fino_conv3d_split (planes = 0 / 2 / 3): one body.  With planes > 0, c_in_pad is the width of ONE plane,
+// the A rows hold `planes` of them side by side and W one plane per product (3 for 2 planes, 6 for 3); bias, y and r are fp32.
+static int conv3d_impl(const void* x, const void* w, const void* bias, void* y, int t_in, int h_in, int w_in,
+                       int c_in_pad, int t_out, int h_out, int w_out, int c_out_pad, int kt, int kh, int kw, int st,
+                       int sh, int sw, int pt, int ph, int pw, int upsample2x, int epilogue, const void* r,
+                       const void* zero_page, int dtype, int planes, void* stream);
+
 extern "C" int fino_conv3d(const void* x, const void* w, const void* bias, void* y, int t_in, int h_in, int w_in,
                            int c_in_pad, int t_out, int h_out, int w_out, int c_out_pad, int kt, int kh, int kw, int st,
                            int sh, int sw, int pt, int ph, int pw, int upsample2x, int epilogue, const void* r,
                            const void* zero_page, int dtype, void* stream) {
+    return conv3d_impl(x, w, bias, y, t_in, h_in, w_in, c_in_pad, t_out, h_out, w_out, c_out_pad, kt, kh, kw, st, sh, sw, pt, ph,
+                       pw, upsample2x, epilogue, r, zero_page, dtype, 0, stream);
+}
+
+extern "C" int fino_conv3d_split(const void* x_planes, const void* w_products, const float* bias, float* y, int t_in, int h_in,
+                                 int w_in, int c_in_pad, int planes, int t_out, int h_out, int w_out, int c_out_pad, int kt,
+                                 int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int upsample2x, int epilogue,
+                                 const float* r, const void* zero_page, void* stream) {
+    FINO_CHECK(planes == 2 || planes == 3, FINO_ERR_ARG, "fino_conv3d_split: planes = %d (2: hi | lo, 3: hi | mid | lo)", planes);
+    return conv3d_impl(x_planes, w_products, bias, y, t_in, h_in, w_in, c_in_pad, t_out, h_out, w_out, c_out_pad, kt, kh, kw, st,
+                       sh, sw, pt, ph, pw, upsample2x, epilogue, r, zero_page, FINO_BF16, planes, stream);
+}
+
+static int conv3d_impl(const void* x, const void* w, const void* bias, void* y, int t_in, int h_in, int w_in,
+                       int c_in_pad, int t_out, int h_out, int w_out, int c_out_pad, int kt, int kh, int kw, int st,
+                       int sh, int sw, int pt, int ph, int pw, int upsample2x, int epilogue, const void* r,
+                       const void* zero_page, int dtype, int planes, void* stream) {
     FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_conv3d: dtype %d", dtype);
     FINO_CHECK(x && w && y && zero_page, FINO_ERR_ARG, "fino_conv3d: null pointer");
     FINO_CHECK(c_in_pad > 0 && c_in_pad % BK == 0, FINO_ERR_ARG,
@@ -981,24 +1031,38 @@ extern "C" int fino_conv3d(const void* x, const void* w, const void* bias, void*
     FINO_CHECK(fino_aligned16(x) && fino_aligned16(w) && fino_aligned16(y) && fino_aligned16(r) &&
                    fino_aligned16(zero_page),
                FINO_ERR_ARG, "fino_conv3d: 16-byte alignment required");
+    const int products = planes == 0 ? 1 : (planes == 2 ? 3 : 6);
+    const int64_t a_width = (int64_t)(planes == 0 ? 1 : planes) * c_in_pad;         // elements of one A row
     GemmParams p = {};
     p.a = (const uint16_t*)x; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.c = (uint16_t*)y;
     p.r = (const uint16_t*)r; p.gate = nullptr; p.sel = nullptr;
-    p.m = (int64_t)t_out * h_out * w_out; p.n = c_out_pad; p.k = (int64_t)kt * kh * kw * c_in_pad;
-    p.lda = c_in_pad; p.ldw = p.k; p.ldc = c_out_pad; p.ldr = c_out_pad; p.mod_stride = 0;
+    p.m = (int64_t)t_out * h_out * w_out; p.n = c_out_pad; p.k = (int64_t)kt * kh * kw * c_in_pad * products;
+    p.lda = a_width; p.ldw = p.k; p.ldc = c_out_pad; p.ldr = c_out_pad; p.mod_stride = 0;
+    p.a_cc = planes == 0 ? 0 : c_in_pad / BK; p.a_nplanes = planes;
     p.tiles_m = (int)((p.m + BM - 1) / BM); p.tiles_n = (int)((p.n + BN - 1) / BN);
     p.group_m = fino_tune_get(FINO_TUNE_GEMM_GROUP_M);
     p.to = t_out; p.ho = h_out; p.wo = w_out; p.ti = t_in; p.hi = h_in; p.wi = w_in;
     p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.sh = sh; p.sw = sw; p.pt = pt; p.ph = ph; p.pw = pw;
-    p.up = upsample2x; p.cin_chunks = c_in_pad / BK; p.zero_page = (const uint16_t*)zero_page;
+    p.up = upsample2x; p.cin_chunks = c_in_pad / BK * products; p.zero_page = (const uint16_t*)zero_page;
     hipStream_t s = (hipStream_t)stream;
     // ping-pong loop with per-tap gather offsets: 32-bit offsets relative to the first input frame a tile can touch,
     // output positions packed 8/12/12 bits
     const int64_t hw_out = (int64_t)h_out * w_out;
     const int64_t t_span = (BM - 1 + hw_out - 1) / hw_out + 1;                      // output frames a 256-row tile can straddle
-    const int64_t in_span_bytes = (t_span * st + kt) * (int64_t)h_in * w_in * c_in_pad * 2;
+    const int64_t in_span_bytes = (t_span * st + kt) * (int64_t)h_in * w_in * a_width * 2;
     const bool pp = use_pingpong() && fino_tune_get(FINO_TUNE_CONV_LOOP) != 1 && in_span_bytes < (1ll << 31) &&
                     h_out < 4096 && w_out < 4096 && t_span < 256 && c_out_pad % 32 == 0 && ((p.n - 1) * p.ldw + p.k) * 2 < (1ll << 31);
+    if (planes > 0) {
+        // the split products run on the ping-pong loop only (its K walk knows the plane map); what does not fit its 32-bit
+        // gather offsets -- one tile's input span of `planes` planes beyond 2 GiB -- is refused, not silently slow
+        if (!pp) {
+            fino_set_error("fino_conv3d_split: a 256-row tile's input span (%lld bytes) exceeds the 2 GiB the gather offsets cover, "
+                           "or c_out_pad %% 32 != 0 -- run the layer in chunks of fewer frames", (long long)in_span_bytes);
+            return FINO_ERR_UNSUPPORTED;
+        }
+        return epilogue == FINO_EPI_NONE ? launch_gemm_pp<BF16, FINO_EPI_F32, true>(p, s)
+                                         : launch_gemm_pp<BF16, FINO_EPI_F32_RESIDUAL, true>(p, s);
+    }
     if (pp) {
         if (dtype == FINO_BF16)
             return epilogue == FINO_EPI_NONE ? launch_gemm_pp<BF16, FINO_EPI_NONE, true>(p, s)

@@ -48,6 +48,12 @@ struct GemmParams {
     int to, ho, wo, ti, hi, wi;      // output / input extents
     int kt, kh, kw, st, sh, sw, pt, ph, pw, up, cin_chunks;
     const uint16_t* zero_page;       // >= 128 B of zeros: source of out-of-range taps (LDS-DMA cannot zero-fill)
+    // split-bf16 convolution (fino_conv3d_split: the Wan VAE computing like fp32, reference app.py:157): A holds a_nplanes
+    // bf16 planes of an fp32 activation side by side ([hi | lo] or [hi | mid | lo], a_cc 64-channel chunks each, lda =
+    // a_nplanes * 64 * a_cc), W one weight plane per PRODUCT of the truncated expansion -- (hi,hi) (hi,lo) (lo,hi), or
+    // (hi,hi) (hi,mid) (hi,lo) (mid,hi) (mid,mid) (lo,hi) -- and a tap's K walk visits the products in that order: the
+    // A plane of product s is {0,0,1}[s] / {0,0,0,1,1,2}[s].  a_cc = 0: plain convolution (cin_chunks chunks per tap).
+    int a_cc, a_nplanes;
     // MXFP8 output (QOUT epilogues of the fp8 kernel): e4m3 bytes [m, n] + scales in the fino_quantize_mxfp8 layout
     uint8_t* cq;
     uint8_t* cs;
@@ -164,9 +170,39 @@ __device__ __forceinline__ void gemm_load_bias(const GemmParams& p, int64_t n0, 
     }
 }
 
-template <typename T, int EPI, bool QOUT = false, int MI = 8>
-__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmParams& p, char* smem, int64_t m0,
-                                              int64_t n0, int tid, int lane, int wm, int wn) {
+// fp32 output (FINO_EPI_F32 / FINO_EPI_F32_RESIDUAL): C = acc + bias [+ R] with bias, R and C in fp32 (GemmParams::bias / r / c
+// hold float pointers, ldc / ldr count floats).  No LDS staging -- a 256-row fp32 tile is twice the LDS -- and none needed: a
+// lane owns 4 consecutive columns of 16 rows per (i, j), one 16-byte access each (a row's 64 bytes come from 4 lanes).  These
+// epilogues close the split-bf16 GEMMs, whose main loop is 3 or 6 times a bf16 one: the epilogue's share is a third / a sixth.
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue_f32(f32x4_t (&acc)[MI][4], const GemmParams& p, int64_t m0, int64_t n0, int lane,
+                                                  int wm, int wn) {
+    const float* bias = reinterpret_cast<const float*>(p.bias);
+    const float* r = reinterpret_cast<const float*>(p.r);
+    float* c = reinterpret_cast<float*>(p.c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t gn = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (gn >= p.n) continue;                                  // (N is a multiple of 4: a lane's 4 columns are in or out together)
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b4 = *reinterpret_cast<const float4*>(bias + gn);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int64_t gm = m0 + wm * (16 * MI) + i * 16 + (lane & 15);
+            if (gm >= p.m) continue;
+            float4 y = make_float4(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
+            if (EPI == FINO_EPI_F32_RESIDUAL) {
+                const float4 rv = *reinterpret_cast<const float4*>(r + gm * p.ldr + gn);
+                y.x += rv.x; y.y += rv.y; y.z += rv.z; y.w += rv.w;
+            }
+            *reinterpret_cast<float4*>(c + gm * p.ldc + gn) = y;
+        }
+    }
+}
+
+template <typename T, int EPI, bool QOUT, int MI>
+__device__ __forceinline__ void gemm_epilogue_t(f32x4_t (&acc)[MI][4], const GemmParams& p, char* smem, int64_t m0,
+                                                int64_t n0, int tid, int lane, int wm, int wn) {
     // ---- epilogue: y = T(acc + bias) [-> gelu] -> LDS tile -> whole-row global stores ----
     // lane holds n = wn*64 + j*16 + (lane>>4)*4 + e (e = 0..3), m = wm*16*MI + i*16 + (lane&15)
     constexpr bool kHasRes =
@@ -291,6 +327,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmP
         fino_gemm_dbg[(tid >> 6) * 8 + 7] = te2 - te1;
     }
 #endif
+}
+
+template <typename T, int EPI, bool QOUT = false, int MI = 8>
+__device__ __forceinline__ void gemm_epilogue(f32x4_t (&acc)[MI][4], const GemmParams& p, char* smem, int64_t m0,
+                                              int64_t n0, int tid, int lane, int wm, int wn) {
+    if constexpr (EPI == FINO_EPI_F32 || EPI == FINO_EPI_F32_RESIDUAL)
+        gemm_epilogue_f32<EPI, MI>(acc, p, m0, n0, lane, wm, wn);
+    else
+        gemm_epilogue_t<T, EPI, QOUT, MI>(acc, p, smem, m0, n0, tid, lane, wm, wn);
 }
 
 }  // namespace fino_gemm_ns

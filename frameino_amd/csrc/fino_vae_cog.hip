@@ -158,6 +158,36 @@ __global__ __launch_bounds__(256) void avg_pool_time2_kernel(const uint16_t* __r
     }
 }
 
+// diffusers' blend_v / blend_h of overlapping VAE tiles (AutoencoderKLCogVideoX.tiled_encode / tiled_decode; the same loops as
+// the in-tree architecture/autoencoder_kl_wan.py:1254-1268), in place on tile b from the last `extent` rows (axis 0) / columns
+// (axis 1) of its upper / left neighbour a, channels-last tiles of one frame count and -- along the other axis -- one extent:
+//     b[.., y, ..] = T( T(a[.., n_a - extent + y, ..] * (1 - y / extent)) + T(b[.., y, ..] * (y / extent)) )
+// with the rounding points of the reference's T-typed tensor arithmetic (tensor x Python float -> T, then the sum -> T).
+template <typename T>
+__global__ __launch_bounds__(256) void blend_tiles_kernel(const uint16_t* __restrict__ a, uint16_t* __restrict__ b, int t,
+                                                          int ha, int wa, int hb, int wb, int chunks, int extent, int axis) {
+    // rows of b touched: axis 0 -> y < extent (all x), axis 1 -> x < extent (all y)
+    const int nh = axis == 0 ? extent : hb, nw = axis == 0 ? wb : extent;
+    const int64_t total = (int64_t)t * nh * nw * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        int64_t r = i / chunks;
+        const int x = (int)(r % nw); r /= nw;
+        const int y = (int)(r % nh);
+        const int f = (int)(r / nh);
+        const int k = axis == 0 ? y : x;
+        const float wb_ = (float)((double)k / (double)extent), wa_ = (float)(1.0 - (double)k / (double)extent);
+        const int ya = axis == 0 ? ha - extent + y : y, xa = axis == 0 ? x : wa - extent + x;
+        float va[8], vb[8], o[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(a + ((((int64_t)f * ha + ya) * wa + xa) * chunks + c) * 8), va);
+        uint16_t* pb = b + ((((int64_t)f * hb + y) * wb + x) * chunks + c) * 8;
+        unpack8<T>(*reinterpret_cast<const uint4*>(pb), vb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = round_to<T>(va[j] * wa_) + round_to<T>(vb[j] * wb_);
+        *reinterpret_cast<uint4*>(pb) = pack8<T>(o);
+    }
+}
+
 inline unsigned grid_1d(int64_t total, int block = 256) {
     int64_t g = (total + block - 1) / block;
     return (unsigned)(g > 262144 ? 262144 : (g < 1 ? 1 : g));
@@ -222,6 +252,31 @@ extern "C" int fino_avg_pool_time2(const void* x, void* y, int t_in, int h, int 
         avg_pool_time2_kernel<BF16><<<grid_1d(t_out * fc), 256, 0, st>>>((const uint16_t*)x, (uint16_t*)y, t_in, fc);
     else
         avg_pool_time2_kernel<F16><<<grid_1d(t_out * fc), 256, 0, st>>>((const uint16_t*)x, (uint16_t*)y, t_in, fc);
+    FINO_LAUNCH_CHECK();
+    return FINO_OK;
+}
+
+extern "C" int fino_vae_blend_tiles(const void* a, void* b, int t, int h_a, int w_a, int h_b, int w_b, int c_pad, int extent,
+                                    int axis, int dtype, void* stream) {
+    FINO_CHECK(dtype == FINO_BF16 || dtype == FINO_F16, FINO_ERR_ARG, "fino_vae_blend_tiles: dtype %d", dtype);
+    FINO_CHECK(a && b && t > 0 && h_a > 0 && w_a > 0 && h_b > 0 && w_b > 0 && c_pad > 0 && c_pad % 8 == 0 &&
+                   (axis == 0 || axis == 1) && fino_aligned16(a) && fino_aligned16(b),
+               FINO_ERR_ARG, "fino_vae_blend_tiles: bad arguments");
+    // diffusers clamps the extent to both tiles (blend_extent = min(a.shape, b.shape, blend_extent)); the other axis must agree
+    const int lim = axis == 0 ? (h_a < h_b ? h_a : h_b) : (w_a < w_b ? w_a : w_b);
+    const int ext = extent < lim ? extent : lim;
+    FINO_CHECK(axis == 0 ? w_a == w_b : h_a == h_b, FINO_ERR_ARG,
+               "fino_vae_blend_tiles: the tiles must agree along the axis that is not blended (%d x %d against %d x %d)", h_a, w_a,
+               h_b, w_b);
+    if (ext <= 0) return FINO_OK;
+    const int64_t total = (int64_t)t * (axis == 0 ? ext : h_b) * (axis == 0 ? w_b : ext) * (c_pad / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FINO_BF16)
+        blend_tiles_kernel<BF16><<<grid_1d(total), 256, 0, st>>>((const uint16_t*)a, (uint16_t*)b, t, h_a, w_a, h_b, w_b,
+                                                                 c_pad / 8, ext, axis);
+    else
+        blend_tiles_kernel<F16><<<grid_1d(total), 256, 0, st>>>((const uint16_t*)a, (uint16_t*)b, t, h_a, w_a, h_b, w_b, c_pad / 8,
+                                                                ext, axis);
     FINO_LAUNCH_CHECK();
     return FINO_OK;
 }

@@ -18,11 +18,21 @@ profiles/r04_rccl_capture_probe.txt, one rank):
     all_to_all_single with async_op=True on the capturing stream               SIGSEGV inside hipStreamEndCapture
     all_to_all_single, blocking                                                 replays; the process group then hangs in teardown
 
-A segfault cannot be caught, so the rule is static: the split plan with the K|V all-gather (collectives on the step's own
-stream) captures -- tests/test_parallel_gpu.py replays it bit-equal through a real RCCL communicator; the interleaved plan
-(two side streams, two communicators) and the heads all-to-all stay eager until the runtime is fixed.  With more than one
-rank a capture has never run on real links here: it is taken only when asked for (`use_hip_graph = True`).  A gloo exchange
-staged through host memory (tests) and a user callback between steps cannot be captured either.
+Round 5 (profiles/r05_rccl_capture_probe.txt) -- what decides is the stream that is CURRENT when the collective is issued, not
+where the kernels around it run:
+
+    kernels on two side streams, no collective                                                  captured, replayed, bit-equal
+    kernels on two side streams, all_gather_into_tensor(async_op=True) issued with the
+      capturing stream current (it waits for the producer's event first), work.wait() on
+      the side stream -- one communicator or two                                                captured, replayed, bit-equal
+    the same with work.wait() on the capturing stream and the side stream forked again          captured, replayed, bit-equal
+
+A segfault cannot be caught, so the rule is static: the K|V all-gather captures when it is issued on the step's own stream --
+the split plan does that by construction, the interleaved plan (two side streams, two communicators) since round 5 through
+`TokenShard.issue_stream`; tests/test_parallel_gpu.py replays both bit-equal through real RCCL communicators.  The heads
+all-to-all stays eager until the runtime is fixed.  With more than one rank a capture has never run on real links here: it is
+taken only when asked for (`use_hip_graph = True`).  A gloo exchange staged through host memory (tests) and a user callback
+between steps cannot be captured either.
 
 `mode`: None = automatic (graph when capturable; a failed capture falls back to the eager loop with a warning -- the same
 HIP kernels either way), True = required (a failed capture raises), False = eager.
@@ -37,8 +47,10 @@ def groups_capturable(plan, explicit=False):
     `explicit`: the caller asked for the graph (`use_hip_graph = True`) -- needed with more than one rank."""
     if plan is None:
         return True
-    if plan.interleave or (plan.exchange == "heads" and plan.shard.active):
-        return False                       # side-stream / all-to-all captures segfault in hipStreamEndCapture
+    if plan.exchange == "heads" and plan.shard.active:
+        return False                       # an all-to-all inside a capture segfaults in hipStreamEndCapture / hangs in teardown
+    # (the interleaved plan's K|V all-gathers are issued on the step's own stream -- TokenShard.issue_stream -- while the
+    # branches' kernels run on two side streams: that pattern captures; round 5 probe)
     if plan.world > 1 and not explicit:
         return False                       # never run on real xGMI links here: opt-in
     import torch.distributed as dist
@@ -49,9 +61,18 @@ def groups_capturable(plan, explicit=False):
         return False
 
 
+def capture_error_mode(plan):
+    """`capture_error_mode` of torch.cuda.graph for a step of this plan.  With a process group alive, c10d's watchdog THREAD polls
+    the events of the eager collectives that ran just before the capture (hipEventQuery); under the default "global" mode any
+    such call from another thread while a capture is open fails, the watchdog takes that for a communicator error and aborts the
+    process (seen once in ~10 runs of the forced-shard rehearsal: SIGABRT in ProcessGroupNCCL::Watchdog::run).  "thread_local"
+    confines the check to the capturing thread, which makes no such call."""
+    return "thread_local" if plan is not None else "global"
+
+
 class StepGraph:
-    def __init__(self, step_fn, mode, capturable, total_steps):
-        self.step_fn, self.mode = step_fn, mode
+    def __init__(self, step_fn, mode, capturable, total_steps, error_mode="global"):
+        self.step_fn, self.mode, self.error_mode = step_fn, mode, error_mode
         # fewer than three steps: one eager + one capture pass and nothing left to replay
         self.enabled = mode is not False and bool(capturable) and (total_steps >= 3 or mode is True)
         if mode is True and not capturable:
@@ -66,7 +87,7 @@ class StepGraph:
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode=self.error_mode):
                         self.step_fn()
                 except RuntimeError as ex:
                     if self.mode is True:

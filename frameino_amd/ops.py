@@ -12,6 +12,7 @@ from . import _lib
 
 BF16, F16 = 0, 1
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_GATED_RESIDUAL, EPI_GATED_RESIDUAL_STAGED = 0, 1, 2, 3, 4
+EPI_F32, EPI_F32_RESIDUAL = 5, 6           # fp32 output of a split-bf16 product (gemm_f32)
 
 
 class KernelTimer:
@@ -24,6 +25,7 @@ class KernelTimer:
         self.names = set(names)
         self.events = {n: [] for n in self.names}
         self.flops = {}
+        self.bytes = {}
 
     def __enter__(self):
         KernelTimer.active = self
@@ -52,12 +54,39 @@ def _timed(name):
     return e
 
 
+def _timed_gemm(epilogue, flops, nbytes=0.0):
+    """a GEMM launch under KernelTimer: counted under "gemm_epi<epilogue>" (bench.py's roofline.secondary rows: one per epilogue
+    class of the block GEMMs) when that name is asked for, else under "gemm".  Returns a closure to call after the launch."""
+    kt = KernelTimer.active
+    if kt is None:
+        return None
+    name = f"gemm_epi{int(epilogue)}"
+    if name not in kt.names:
+        name = "gemm"
+        if name not in kt.names:
+            return None
+    ev = _timed(name)
+
+    def done():
+        ev.record()
+        kt.flops[name] = kt.flops.get(name, 0.0) + flops
+        kt.bytes[name] = kt.bytes.get(name, 0.0) + nbytes
+    return done
+
+
 def _dt(t):
     if t.dtype == torch.bfloat16:
         return BF16
     if t.dtype == torch.float16:
         return F16
     raise TypeError(f"frameino_amd: activations must be bf16 or fp16, got {t.dtype}")
+
+
+F32 = 2          # FINO_F32: fp32 STORAGE (the Wan VAE's rearrangement kernels in its fp32-faithful mode); never an MFMA operand type
+
+
+def _dt3(t):
+    return F32 if t.dtype == torch.float32 else _dt(t)
 
 
 def _stream():
@@ -231,6 +260,8 @@ def attention(q, k, v, heads, out=None, scale=None):
         kt_ = KernelTimer.active
         nm = "attn_self" if lk > 1024 else "attn_cross"
         kt_.flops[nm] = kt_.flops.get(nm, 0.0) + 4.0 * b * lq * lk * hd      # 4.Lq.Lk.(H.Dh) per batch element
+        # algorithmic bytes of the launch: Q read + O written (Lq rows), K and V read (Lk rows), 2 bytes per element
+        kt_.bytes[nm] = kt_.bytes.get(nm, 0.0) + 2.0 * b * hd * (2 * lq + 2 * lk)
     return out
 
 
@@ -429,7 +460,8 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     ms = gate.stride(0) if (gate is not None and gate.dim() == 2) else 0
     if bias is not None:
         assert bias.dtype == a.dtype and bias.is_contiguous()
-    ev = _timed("gemm")
+    # algorithmic bytes: A [M, K] and W [N, K] read, C [M, N] written (+ the residual read), 2 bytes per element
+    done = _timed_gemm(epilogue, 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n * (2 if residual is not None else 1)))
     if tile_m:
         _lib.check(_lib.lib().fino_gemm_split_n(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue,
                                                _p(r2), ldr, _p(gate), ms, _p(sel), _dt(a), None, 0, 0, tile_m, _stream()),
@@ -437,9 +469,8 @@ def gemm(a, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, sel=None,
     else:
         _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w), _p(bias), _p(o2), m, n, k, lda, w.stride(0), ldc, epilogue, _p(r2),
                                        ldr, _p(gate), ms, _p(sel), _dt(a), _stream()), "fino_gemm")
-    if ev is not None:
-        ev.record()
-        KernelTimer.active.flops["gemm"] = KernelTimer.active.flops.get("gemm", 0.0) + 2.0 * m * n * k
+    if done is not None:
+        done()
     return out
 
 
@@ -692,7 +723,7 @@ def rmsnorm_silu_cl(x, gamma, c_valid, silu=True, out=None):
 
 def softmax_rows_(s, n, scale):
     assert s.dim() == 2 and s.stride(1) == 1
-    _lib.check(_lib.lib().fino_softmax_rows(_p(s), s.shape[0], n, s.stride(0), float(scale), _dt(s), _stream()),
+    _lib.check(_lib.lib().fino_softmax_rows(_p(s), s.shape[0], n, s.stride(0), float(scale), _dt3(s), _stream()),
                "fino_softmax_rows")
     return s
 
@@ -702,7 +733,7 @@ def dup_up3d_add(main, x, c_in, c_out, factor_t, factor_s):
     out = torch.empty_like(main)
     assert main.shape == (1 + (t - 1) * factor_t, h * factor_s, w * factor_s, main.shape[3])
     _lib.check(_lib.lib().fino_dup_up3d_add(_p(main), _p(x), _p(out), t, h, w, c_in, cin_pad, c_out, main.shape[3],
-                                           factor_t, factor_s, _dt(x), _stream()), "fino_dup_up3d_add")
+                                           factor_t, factor_s, _dt3(x), _stream()), "fino_dup_up3d_add")
     return out
 
 
@@ -710,14 +741,14 @@ def avg_down3d_add(main, x, c_in, c_out, factor_t, factor_s):
     t, h, w, cin_pad = x.shape
     out = torch.empty_like(main)
     _lib.check(_lib.lib().fino_avg_down3d_add(_p(main), _p(x), _p(out), t, h, w, c_in, cin_pad, c_out, main.shape[3],
-                                             factor_t, factor_s, _dt(x), _stream()), "fino_avg_down3d_add")
+                                             factor_t, factor_s, _dt3(x), _stream()), "fino_avg_down3d_add")
     return out
 
 
 def vae_unpatchify_clamp(y, channels, patch):
     t, h, w, cpad = y.shape
     out = torch.empty((channels, t, h * patch, w * patch), dtype=torch.float32, device=y.device)
-    _lib.check(_lib.lib().fino_vae_unpatchify_clamp(_p(y), _p(out), t, h, w, cpad, channels, patch, _dt(y), _stream()),
+    _lib.check(_lib.lib().fino_vae_unpatchify_clamp(_p(y), _p(out), t, h, w, cpad, channels, patch, _dt3(y), _stream()),
                "fino_vae_unpatchify_clamp")
     return out
 
@@ -726,12 +757,124 @@ def vae_patchify(x, c_pad, patch, dtype):
     c, t, hp, wp = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous()
     y = torch.empty((t, hp // patch, wp // patch, c_pad), dtype=dtype, device=x.device)
-    _lib.check(_lib.lib().fino_vae_patchify(_p(x), _p(y), t, hp // patch, wp // patch, c_pad, c, patch, _dt(y),
+    _lib.check(_lib.lib().fino_vae_patchify(_p(x), _p(y), t, hp // patch, wp // patch, c_pad, c, patch, _dt3(y),
                                            _stream()), "fino_vae_patchify")
     return y
 
 
+# ---- the Wan VAE computing like fp32 on the bf16 matrix pipe: split-bf16 products (include/frameino_hip.h, FINO_VERSION 103) ----
+# an fp32 value = hi + mid + lo (three bf16 planes); a product keeps the terms >= 2^-16 relative
+SPLIT_PRODUCTS = {2: ((0, 0), (0, 1), (1, 0)),                                    # (A plane, W plane) per product, in K order
+                  3: ((0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0))}
+
+
+def _pack_planes(planes):
+    v = 0
+    for i, q in enumerate(planes):
+        v |= int(q) << (2 * i)
+    return v
+
+
+def split_bf16(x, layout, nplanes=3, out=None):
+    """x fp32 [..., C] (C % 8 == 0) -> bf16 [..., nseg * C] of split planes:
+      layout "planes": the planes side by side (the A operand of conv3d_split_cl), "A" / "W": one plane per product of
+      SPLIT_PRODUCTS[nplanes] -- the operands of gemm(..., EPI_F32) -- A side / W side."""
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+    rows, cols = x2.shape
+    prod = SPLIT_PRODUCTS[nplanes]
+    planes = tuple(range(nplanes)) if layout == "planes" else tuple(p[0 if layout == "A" else 1] for p in prod)
+    nseg = len(planes)
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (nseg * cols,), dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.numel() == rows * nseg * cols
+    _lib.check(_lib.lib().fino_split_bf16(_p(x2), _p(out), rows, cols, x2.stride(0), nseg * cols, nseg, _pack_planes(planes),
+                                         _stream()), "fino_split_bf16")
+    return out
+
+
+def rmsnorm_silu_cl_f32(x, gamma, c_valid, silu=True, split=None, nplanes=3):
+    """WanRMS_norm [+ SiLU] on fp32 channels-last activations, in fp32; split=None -> fp32 out, "planes" | "A" | "W" -> the split
+    planes of split_bf16 in the same pass"""
+    assert x.is_contiguous() and x.dtype == torch.float32 and gamma.dtype == torch.float32
+    cpad = x.shape[-1]
+    rows = x.numel() // cpad
+    if split is None:
+        planes, out = (), torch.empty_like(x)
+    else:
+        prod = SPLIT_PRODUCTS[nplanes]
+        planes = tuple(range(nplanes)) if split == "planes" else tuple(p[0 if split == "A" else 1] for p in prod)
+        out = torch.empty(tuple(x.shape[:-1]) + (len(planes) * cpad,), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().fino_rmsnorm_silu_cl_f32(_p(x), _p(out), rows, c_valid, cpad, _p(gamma), int(silu), len(planes),
+                                                  _pack_planes(planes), _stream()), "fino_rmsnorm_silu_cl_f32")
+    return out
+
+
+def conv3d_split_cl(xp, w6, bias, kernel, nplanes, stride=(1, 1, 1), pad=(0, 0, 0), out_thw=None, upsample2x=False,
+                    residual=None):
+    """conv3d_cl on split operands: xp bf16 [T, H, W, nplanes * Cin_pad] (split_bf16 layout "planes"), w6 bf16 [Cout_pad,
+    taps * products * Cin_pad] (W planes of the products per tap), bias fp32 [Cout_pad], residual fp32 -> fp32 [To, Ho, Wo, Cout_pad]"""
+    assert xp.dim() == 4 and xp.is_contiguous() and w6.is_contiguous() and xp.dtype == torch.bfloat16 and w6.dtype == torch.bfloat16
+    t, h, w, cw = xp.shape
+    cin = cw // nplanes
+    kt, kh, kw = kernel
+    cout = w6.shape[0]
+    nprod = len(SPLIT_PRODUCTS[nplanes])
+    assert cin * nplanes == cw and w6.shape[1] == kt * kh * kw * nprod * cin, (xp.shape, w6.shape, kernel)
+    assert bias is None or bias.dtype == torch.float32
+    if out_thw is None:
+        up = 2 if upsample2x else 1
+        out_thw = ((t + pad[0] - kt) // stride[0] + 1, (h * up + 2 * pad[1] - kh) // stride[1] + 1,
+                   (w * up + 2 * pad[2] - kw) // stride[2] + 1)
+    to, ho, wo = out_thw
+    out = torch.empty((to, ho, wo, cout), dtype=torch.float32, device=xp.device)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape == out.shape
+    ev = _timed("conv3d")
+    _lib.check(_lib.lib().fino_conv3d_split(_p(xp), _p(w6), _p(bias), _p(out), t, h, w, cin, nplanes, to, ho, wo, cout, kt, kh, kw,
+                                           stride[0], stride[1], stride[2], pad[0], pad[1], pad[2], int(upsample2x),
+                                           EPI_RESIDUAL if residual is not None else EPI_NONE, _p(residual),
+                                           _p(zero_page(xp.device)), _stream()), "fino_conv3d_split")
+    if ev is not None:
+        ev.record()
+        kt_ = KernelTimer.active
+        kt_.flops["conv3d"] = kt_.flops.get("conv3d", 0.0) + 2.0 * to * ho * wo * cout * w6.shape[1]
+    return out
+
+
+def gemm_f32(a_split, w_split, bias=None, residual=None, out=None):
+    """fp32 C = A.W^T + bias [+ R] from operands already expanded by split_bf16 ("A" / "W" layouts: one plane per product):
+    a_split [M, products * K], w_split [N, products * K] bf16; bias fp32 [N], residual / out fp32 [M, N]"""
+    a2, m, k, lda = _rows2d(a_split)
+    assert w_split.dim() == 2 and w_split.stride(1) == 1 and w_split.shape[1] == k and a_split.dtype == w_split.dtype == torch.bfloat16
+    n = w_split.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a_split.device)
+    assert out.dtype == torch.float32 and out.stride(-1) == 1
+    o2 = out if out.dim() == 2 else out.view(-1, out.shape[-1])
+    r2, ldr = None, 0
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        r2 = residual if residual.dim() == 2 else residual.view(-1, residual.shape[-1])
+        ldr = r2.stride(0)
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
+    _lib.check(_lib.lib().fino_gemm(_p(a2), _p(w_split), _p(bias), _p(o2), m, n, k, lda, w_split.stride(0), o2.stride(0),
+                                   EPI_F32_RESIDUAL if residual is not None else EPI_F32, _p(r2), ldr, None, 0, None, BF16,
+                                   _stream()), "fino_gemm")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ CogVideoX VAE
+def vae_blend_tiles_(a, b, extent, axis):
+    """diffusers' blend_v (axis 0) / blend_h (axis 1) in place on the channels-last tile b [T, Hb, Wb, Cpad] from its upper / left
+    neighbour a (fino_vae_blend_tiles)"""
+    assert a.dim() == 4 and b.dim() == 4 and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+    assert a.shape[0] == b.shape[0] and a.shape[3] == b.shape[3]
+    _lib.check(_lib.lib().fino_vae_blend_tiles(_p(a), _p(b), a.shape[0], a.shape[1], a.shape[2], b.shape[1], b.shape[2],
+                                              a.shape[3], int(extent), int(axis), _dt(a), _stream()), "fino_vae_blend_tiles")
+    return b
+
+
 _GN_WS = {}
 
 

@@ -70,6 +70,46 @@ class TokenShard:
     def fused_qkv_ok(self):
         return bool(self.fused_qkv)
 
+    # K|V exchange in HEAD GROUPS (round 5): the local K|V leave in this many all-gathers, one per run of heads, and the
+    # attention runs group by group as they arrive -- heads are independent in the self-attention, so group g is attended
+    # to while group g+1 is still on the wire: of the gather's time only the first group's share (1/groups) stands in
+    # front of the attention, the rest flies under it.  Costs one more small launch per layer-call (the K RMSNorm + RoPE
+    # kernel scatters k by head into [group][token][k_g | v_g] send blocks, v follows as a scattering copy instead of
+    # staying where the projection wrote it) and attention launches of heads / groups heads each (24 heads x 13 q-blocks of a
+    # 3080-row shard are 2 rounds of the CUs as one launch and as two).  1 = one gather.  tools/plan_sim.py with a modelled wire
+    # (FINO_PLAN_SIM_WIRE_GBPS) measures what it hides.
+    kv_head_groups = 2
+
+    def kv_groups(self, heads):
+        g = max(1, min(int(self.kv_head_groups), heads))
+        return g if (self.exchange == "kv" and not self.local_first()) else 1
+
+    def kv_group_layout(self, heads, dh, lpad, dtype, dev):
+        """send side of the head-grouped K|V gather as ONE flat buffer [group][lpad][k_g | v_g] (views[g]: the [lpad, 2 dg]
+        block all-gather number g sends; rows [n, lpad) are never written and stay zero) + the per-head tables of
+        ops.rmsnorm_rope_scatter: element offset of head h's k / v columns, and the row stride there."""
+        groups = self.kv_groups(heads)
+        key = ("kv_group_layout", heads, dh, lpad, dtype, str(dev), groups)
+        lay = self._buf.get(key)
+        if lay is None:
+            from types import SimpleNamespace
+            cuts = [heads * i // groups for i in range(groups + 1)]
+            ranges = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            flat = torch.zeros(lpad * 2 * heads * dh, dtype=dtype, device=dev)
+            views, off_k, off_v, ld, base = [], [0] * heads, [0] * heads, [0] * heads, 0
+            for h0, h1 in ranges:
+                dg = (h1 - h0) * dh
+                views.append(flat[base:base + lpad * 2 * dg].view(lpad, 2 * dg))
+                for h in range(h0, h1):
+                    off_k[h] = base + (h - h0) * dh
+                    off_v[h] = base + dg + (h - h0) * dh
+                    ld[h] = 2 * dg
+                base += lpad * 2 * dg
+            t64 = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)          # noqa: E731
+            lay = self._buf[key] = SimpleNamespace(flat=flat, views=views, ranges=ranges, off_k=t64(off_k), off_v=t64(off_v),
+                                                   ld=t64(ld))
+        return lay
+
     @property
     def active(self):
         return self.ways > 1 or self.force
@@ -101,6 +141,30 @@ class TokenShard:
     def out_local(self, lpad, width, dtype, dev):
         return self._get("out_loc", (lpad, width), dtype, dev)
 
+    # The stream every collective of this shard is ISSUED on, or None = the stream that is current at the call.  The
+    # interleaved plan runs its two branches on two side streams; a collective issued with a side stream current cannot be
+    # captured into a hipGraph on this image (SIGSEGV inside hipStreamEndCapture), one issued with the CAPTURING stream current
+    # can -- also when the kernels around it run on side streams (tools/debug/rccl_capture_probe.py, round 5:
+    # profiles/r05_rccl_capture_probe.txt).  So the pipeline names the step's own stream here: that stream waits for the
+    # branch's producer kernels (an event), c10d forks its communicator stream from it, and the BRANCH's stream waits for the
+    # collective where the forward calls work.wait().  Eager and captured runs enqueue exactly the same dependencies.
+    issue_stream = None
+
+    def _issue(self, fn, t, async_op):
+        """run the collective `fn()` (-> work handle) with `issue_stream` current; the calling stream waits for it at once unless
+        async_op.  -> work handle or None"""
+        iss = self.issue_stream
+        cur = torch.cuda.current_stream() if (iss is not None and t.is_cuda) else None
+        if cur is None or cur == iss:
+            return fn(async_op)
+        iss.wait_stream(cur)                     # what produced `t` is enqueued on the calling (branch) stream
+        with torch.cuda.stream(iss):
+            work = fn(True)
+        if not async_op:
+            work.wait()                          # current stream = the branch's again: it waits for the collective
+            return None
+        return work
+
     def _all_gather(self, key, t, async_op):
         out = self._get(key, (self.ways * t.shape[0],) + tuple(t.shape[1:]), t.dtype, t.device)
         if dist.get_backend(self.group) == "gloo":           # tests: CPU tensors, or device tensors staged via host
@@ -112,7 +176,7 @@ class TokenShard:
             parts = list(out.chunk(self.ways))
             dist.all_gather(parts, t.contiguous(), group=self.group)
             return out, None
-        work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=async_op)
+        work = self._issue(lambda a_: dist.all_gather_into_tensor(out, t, group=self.group, async_op=a_), t, async_op)
         return out, work
 
     def heads_exchange_ok(self, heads):
@@ -182,7 +246,7 @@ class TokenShard:
             dist.all_to_all_single(r, send.cpu().contiguous(), group=self.group)
             recv.copy_(r.to(send.device))
             return recv, None
-        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        work = self._issue(lambda a_: dist.all_to_all_single(recv, send, group=self.group, async_op=a_), send, async_op)
         return recv, (work if async_op else None)
 
     def a2a_buffer(self, key, shape, dtype, dev):

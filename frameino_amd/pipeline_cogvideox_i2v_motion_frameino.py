@@ -69,14 +69,14 @@ class CogVideoXPipelineOutput(SimpleNamespace):
 
 def _one_generator(generator, batch_size=1):
     """diffusers' randn_tensor rule for a list of generators: its length must equal the batch size, and a list of one
-    IS that generator (one video per call here) -- never silently dropped."""
+    IS that generator -- never silently dropped (batches: the callers hand every video its own generator)."""
     if isinstance(generator, (list, tuple)):
         if len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
                              f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
                              f"the generators.")
         if batch_size != 1:
-            raise NotImplementedError("one video per call")
+            raise ValueError("a list of generators is consumed one per video: index it before drawing a single row")
         return generator[0]
     return generator
 
@@ -235,7 +235,22 @@ class CogVideoXImageToVideoPipeline:
         tr = self.transformer
         dev, dt = latents.device, tr.dtype
         if latents.shape[0] != 1:
-            raise NotImplementedError("one video per call")
+            # A batch (a list of prompts, batched `prompt_embeds` / `latents`) runs video by video: the loop state -- the static
+            # model-input buffer, the sampler history, the captured graph -- is one video's.  The videos of a batched loop never
+            # meet (per-sample attention, per-sample guidance), so every row equals the single call on that row's noise, prompt
+            # and conditions; conditions given with batch 1 (the reference's traj / ID latents are batch 1, :803-826) are shared.
+            nb_ = latents.shape[0]
+
+            def row(t, i):
+                return t if t is None or t.shape[0] == 1 else t[i:i + 1]
+            outs = []
+            for i in range(nb_):
+                gi = generator[i] if isinstance(generator, (list, tuple)) else generator
+                outs.append(self.denoise(latents[i:i + 1], row(image_latents, i), row(traj_latents, i), row(id_latent, i),
+                                         row(prompt_embeds, i), row(negative_prompt_embeds, i), guidance_scale,
+                                         num_inference_steps, use_dynamic_cfg, image_rotary_emb, attention_kwargs,
+                                         callback_on_step_end, gi))
+            return torch.cat(outs, dim=0)
         generator = _one_generator(generator)
         cfg_on = guidance_scale > 1.0 and negative_prompt_embeds is not None
         self.scheduler.set_timesteps(num_inference_steps, device=dev)
@@ -317,6 +332,21 @@ class CogVideoXImageToVideoPipeline:
                 ".config.invert_scale_latents, .dtype): that model is third-party and not part of the reference tree. "
                 "`denoise()` works on latents alone.")
 
+    @staticmethod
+    def _noise_rows(shape, generator, dtype, device):
+        """diffusers' randn_tensor: one generator draws the whole batch in one call, a list of generators one row each (its
+        length must be the batch size); drawn on the generator's device, then moved"""
+        if isinstance(generator, (list, tuple)) and shape[0] > 1:
+            if len(generator) != shape[0]:
+                raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                                 f"effective batch size of {shape[0]}. Make sure the batch size matches the length of "
+                                 f"the generators.")
+            return torch.cat([torch.randn((1,) + tuple(shape[1:]), generator=g_, device=g_.device, dtype=dtype).to(device)
+                              for g_ in generator], dim=0)
+        g1 = _one_generator(generator, shape[0])
+        gdev = g1.device if g1 is not None else device
+        return torch.randn(tuple(shape), generator=g1, device=gdev, dtype=dtype).to(device)
+
     def prepare_latents(self, image, batch_size=1, num_channels_latents=16, num_frames=13, height=60, width=90,
                         dtype=None, device=None, generator=None, latents=None):
         """reference :350-423 (patch_size_t None).  image [B, C, H, W] in [-1, 1]."""
@@ -338,10 +368,7 @@ class CogVideoXImageToVideoPipeline:
         pad = torch.zeros((batch_size, nlf - 1, num_channels_latents, lh, lw), device=device, dtype=dtype)
         image_latents = torch.cat([image_latents, pad], dim=1)
         if latents is None:
-            g1 = _one_generator(generator, batch_size)
-            gdev = g1.device if g1 is not None else device
-            latents = torch.randn((batch_size, nlf, num_channels_latents, lh, lw), generator=g1, device=gdev,
-                                  dtype=dtype).to(device)
+            latents = self._noise_rows((batch_size, nlf, num_channels_latents, lh, lw), generator, dtype, device)
         else:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma, image_latents
@@ -359,9 +386,10 @@ class CogVideoXImageToVideoPipeline:
                  generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type="pil",
                  return_dict=True, attention_kwargs=None, callback_on_step_end=None,
                  callback_on_step_end_tensor_inputs=["latents"], max_sequence_length=226):
-        """reference :604-957, one video per call: `prompt=` / `negative_prompt=` strings (what app.py:719 and
+        """reference :604-957: `prompt=` / `negative_prompt=` strings (what app.py:719 and
         test_code/run_cogvideox_FrameIn_mass_evaluation.py:206-213 pass) or pre-computed `prompt_embeds` /
-        `negative_prompt_embeds` [1, 226, 4096].  As in the reference (:744, :766-768) guidance needs a negative branch:
+        `negative_prompt_embeds` [B, 226, 4096]; a list of B prompts / B embedding rows gives B videos (run one by one; the
+        reference's own loop only survives B = 1).  `num_videos_per_prompt` is accepted and, as in the reference (:723), ignored.  As in the reference (:744, :766-768) guidance needs a negative branch:
         with `guidance_scale > 1` and no `negative_prompt_embeds` the empty negative prompt is encoded."""
         self._need_vae()
         if timesteps is not None or eta != 0.0:
@@ -373,8 +401,15 @@ class CogVideoXImageToVideoPipeline:
         width = width or c.sample_width * self.vae_scale_factor_spatial
         self.check_inputs(image, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, latents,
                           prompt_embeds, negative_prompt_embeds)
-        if isinstance(prompt, list) and len(prompt) != 1:
-            raise NotImplementedError("one video per call")
+        # The reference overwrites `num_videos_per_prompt` with 1 (:723) and its loop breaks on more than one prompt (the
+        # trajectory / identity latents are batch 1, :803-826 against torch.cat at :872-880); here a list of B prompts (or
+        # B rows of `prompt_embeds`) makes B videos, run video by video in `denoise` (the Wan mirror does the same).
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None:
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
         dev = self._execution_device
         dt = self.transformer.dtype
         prompt_embeds, negative_prompt_embeds = self.encode_prompt(
@@ -388,11 +423,26 @@ class CogVideoXImageToVideoPipeline:
         else:
             import numpy as np
             import PIL.Image
-            arr = np.asarray(image.resize((width, height), resample=PIL.Image.LANCZOS)).astype("float32") / 255.0
-            img = 2.0 * torch.from_numpy(arr.transpose(2, 0, 1).copy())[None] - 1.0
+            pil = image if isinstance(image, list) else [image]
+            arrs = [np.asarray(im.resize((width, height), resample=PIL.Image.LANCZOS)).astype("float32") / 255.0 for im in pil]
+            img = 2.0 * torch.from_numpy(np.stack(arrs).transpose(0, 3, 1, 2).copy()) - 1.0
         img = img.to(dev, dtype=dt)
+        if img.shape[0] not in (1, batch_size):
+            raise ValueError(f"`image` holds {img.shape[0]} images for {batch_size} prompts: pass one image, or one per prompt")
         n_lat = c.out_channels          # 16 for CogVideoX-5B (hard-coded at :797)
-        latents, image_latents = self.prepare_latents(img, 1, n_lat, num_frames, height, width, dt, dev, generator, latents)
+        if img.shape[0] == 1 and batch_size > 1:
+            # ONE first frame for B prompts: its latent is one posterior sample, shared by the B videos like the trajectory and
+            # identity latents below; the noise is drawn as the batch's rows (diffusers' randn_tensor rule for generator lists)
+            g0 = generator[0] if isinstance(generator, (list, tuple)) else generator
+            _, image_latents = self.prepare_latents(img, 1, n_lat, num_frames, height, width, dt, dev, g0,
+                                                    torch.zeros(1, device=dev))
+            nlf_ = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+            shape = (batch_size, nlf_, n_lat, height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+            latents = self._noise_rows(shape, generator, dt, dev) if latents is None else latents.to(dev)
+            latents = latents * self.scheduler.init_noise_sigma
+        else:
+            latents, image_latents = self.prepare_latents(img, batch_size, n_lat, num_frames, height, width, dt, dev, generator,
+                                                          latents)
         latents = latents / self.scheduler.init_noise_sigma          # denoise() applies it (:421)
         vdt = getattr(self.vae, "dtype", dt)
         traj = traj_tensor.to(dev, dtype=vdt)[None].permute(0, 2, 1, 3, 4)                        # :809-811
@@ -413,8 +463,8 @@ class CogVideoXImageToVideoPipeline:
         if output_type == "latent":
             video = out
         else:
-            frames = self.decode_latents(out)                                                      # [1, C, F, H, W]
-            v = (frames.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)                      # [1, F, C, H, W]
+            frames = torch.cat([self.decode_latents(out[i:i + 1]) for i in range(out.shape[0])])   # [B, C, F, H, W]
+            v = (frames.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)                      # [B, F, C, H, W]
             if output_type == "pt":
                 video = v
             elif output_type == "np":

@@ -314,6 +314,10 @@ class WanImageToVideoPipeline:
                 self._streams = (torch.cuda.Stream(), torch.cuda.Stream()) if x.is_cuda else (None, None)
             main = torch.cuda.current_stream() if x.is_cuda else None
             gens, outs = [], [None, None]
+            for shard in plan.shards:
+                # the branches' kernels run on the two side streams, their collectives are issued on the step's own stream
+                # (TokenShard.issue_stream: the call pattern a hipGraph capture of this step survives)
+                shard.issue_stream = main
             for name, emb, shard in (("cond", st.pe, plan.shards[0]), ("uncond", st.ne, plan.shards[1])):
                 gens.append((name, tr.forward_steps(hidden_states=x, timestep=None, encoder_hidden_states=emb,
                                                      return_dict=False, attention_kwargs=st.attention_kwargs,
@@ -439,12 +443,12 @@ class WanImageToVideoPipeline:
         ts_dev = timesteps.to(dev).float()
         self._num_timesteps = len(timesteps)
 
-        from .graph_step import StepGraph, groups_capturable
+        from .graph_step import StepGraph, capture_error_mode, groups_capturable
         stepper = StepGraph(lambda: self._step(st), self.use_hip_graph,
                             callback_on_step_end is None and st.lat.is_cuda
                             and (self.use_hip_graph is True or tr_default_procs(self.transformer))
                             and groups_capturable(getattr(self, "parallel", None), self.use_hip_graph is True),
-                            len(timesteps))
+                            len(timesteps), capture_error_mode(getattr(self, "parallel", None)))
         for i in range(len(timesteps)):
             if self._interrupt:
                 continue

@@ -650,6 +650,32 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                         if work is not None:
                             work.wait()
                         a3[:, :, h0 * dh:h1 * dh].copy_(orv[:, :n].permute(1, 0, 2))
+            elif (hasattr(sh, "kv_groups") and sh.kv_groups(heads) > 1 and hasattr(o, "rmsnorm_rope_scatter")
+                  and hasattr(sh, "kv_group_layout")):
+                # K|V all-gather in HEAD GROUPS (TokenShard.kv_head_groups): the attention of group g runs while group g+1 is
+                # still on the wire.  k (norm_k + RoPE) is scattered by head into [group][token][k_g | v_g] send blocks, v
+                # follows as a scattering copy; per group one all-gather and one attention launch over that group's heads.
+                kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
+                lay = sh.kv_group_layout(heads, dh, lpad, dt, dev)
+                if sh.fused_qkv_ok() and not self._fp8:
+                    o.gemm(nrm, e.wqkv, e.bqkv, out=q2, out2=kv_loc[:n], split=d, **tk)
+                else:
+                    self._lin(li, "kv", nrm, e.wqkv[d:], e.bqkv[d:], out=kv_loc[:n], **tk)
+                o.rmsnorm_rope_scatter(kv_loc[:n, :d], blk.attn1.norm_k.weight, blk.attn1.norm_k.eps, cos, sin, dh, lay.flat,
+                                       lay.off_k, lay.ld)
+                o.rmsnorm_rope_scatter(kv_loc[:n, d:], None, 0.0, None, None, dh, lay.flat, lay.off_v, lay.ld)
+                flying = [sh._all_gather(f"kv_all_g{gi}", v_, True) for gi, v_ in enumerate(lay.views)]
+                if not (sh.fused_qkv_ok() and not self._fp8):
+                    self._lin(li, "q", nrm, e.wqkv[:d], e.bqkv[:d], out=q2, **tk)
+                o.rmsnorm_rope_(q2, blk.attn1.norm_q.weight, blk.attn1.norm_q.eps, cos, sin, dh, **qfold)
+                q3, a3 = q2.view(1, n, d), att.view(1, n, d)
+                for (h0, h1), (kv_all, work) in zip(lay.ranges, flying):
+                    if work is not None:
+                        work.wait()
+                    dg = (h1 - h0) * dh
+                    kv3 = kv_all.view(1, -1, 2 * dg)[:, :L]
+                    o.attention(q3[:, :, h0 * dh:h1 * dh], kv3[:, :, :dg], kv3[:, :, dg:], h1 - h0,
+                                out=a3[:, :, h0 * dh:h1 * dh], **afold)
             else:
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
                 if sh.fused_qkv_ok() and not self._fp8:

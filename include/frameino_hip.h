@@ -24,9 +24,14 @@ extern "C" {
 /* 101: fino_gemm_split_n / fino_gemm_blocked_a take a per-call tile_m; FINO_TUNE_GEMM_TILE_M is an A/B knob only. */
 /* 102: fino_attn_fwd_fp8 takes p_mode (how a softmax weight becomes an e4m3 byte: FINO_FP8_P_EXP2 | FINO_FP8_P_RAMP);
  * fino_attn_fwd_tail / fino_attn_tail_supported, fino_attn_probs / fino_attn_probs_supported added. */
-#define FINO_VERSION 102
+/* 103 (round 5): the Wan VAE can compute like the fp32 the reference app runs it in (app.py:157) -- fino_conv3d_split,
+ * fino_split_bf16, fino_rmsnorm_silu_cl_f32, FINO_EPI_F32 / FINO_EPI_F32_RESIDUAL of fino_gemm, dtype FINO_F32 for the VAE's
+ * rearrangement kernels; fino_vae_blend_tiles (CogVideoX VAE tiling). */
+#define FINO_VERSION 103
 
-enum { FINO_BF16 = 0, FINO_F16 = 1 };
+/* FINO_F32: fp32 STORAGE of activations -- accepted only where a function says so (the Wan VAE's rearrangement kernels);
+ * MFMA operands are always bf16 / fp16. */
+enum { FINO_BF16 = 0, FINO_F16 = 1, FINO_F32 = 2 };
 enum {
     FINO_OK = 0,
     FINO_ERR_ARG = -1,     /* bad shape / alignment / dtype */
@@ -243,9 +248,13 @@ int fino_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, int b
  * gate rows as in fino_adaln_modulate. C may alias R.  Replaces nn.Linear at transformer_wan.py:60-62, :117,
  * diffusers FeedForward (:347), patch_embedding (:486) and proj_out (:537) after patchify.
  *   FINO_EPI_GATED_RESIDUAL_STAGED  C = T(R + T(y * gate[r][n]))    (cogvideox_transformer_3d.py:146-147, :158-159:
- *                                   the CogVideoX block does the gate multiply and the add in T) */
+ *                                   the CogVideoX block does the gate multiply and the add in T)
+ *   FINO_EPI_F32, FINO_EPI_F32_RESIDUAL  C = acc + bias [+ R] WITHOUT the rounding to T: bias, R and C are fp32 (ldc / ldr
+ *                                   count floats, N a multiple of 4; M and K as usual).  The closing step of a split-bf16
+ *                                   product -- operands expanded by fino_split_bf16 -- with which the Wan VAE computes like
+ *                                   the fp32 the reference app runs it in (app.py:157; fino_conv3d_split below). */
 enum { FINO_EPI_NONE = 0, FINO_EPI_GELU_TANH = 1, FINO_EPI_RESIDUAL = 2, FINO_EPI_GATED_RESIDUAL = 3,
-       FINO_EPI_GATED_RESIDUAL_STAGED = 4 };
+       FINO_EPI_GATED_RESIDUAL_STAGED = 4, FINO_EPI_F32 = 5, FINO_EPI_F32_RESIDUAL = 6 };
 int fino_gemm(const void* a, const void* w, const void* bias, void* c, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldw, int64_t ldc, int epilogue, const void* r, int64_t ldr, const float* gate,
               int64_t mod_stride, const int32_t* sel, int dtype, void* stream);
@@ -367,6 +376,37 @@ int fino_vae_unpatchify_clamp(const void* y, float* out, int t, int h, int w, in
 /* encoder head: patchify (:912-932): x fp32 [channels, T, H*p, W*p] -> y [T,H,W,c_pad]. */
 int fino_vae_patchify(const float* x, void* y, int t, int h, int w, int c_pad, int channels, int patch, int dtype,
                       void* stream);
+/* fino_softmax_rows, fino_dup_up3d_add, fino_avg_down3d_add, fino_vae_unpatchify_clamp and fino_vae_patchify also take
+ * dtype = FINO_F32: the activations are fp32 [T, H, W, c_pad] (same index arithmetic, no rounding to 16 bits).
+ *
+ * ---- the same VAE computing like fp32 (reference app.py:157 loads AutoencoderKLWan in fp32 and decodes in fp32,
+ * architecture/autoencoder_kl_wan.py:1198-1227) on the bf16 matrix pipe: SPLIT-BF16 PRODUCTS.  An fp32 value is the sum of
+ * three bf16 planes, hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (3 x 8 significant bits, every difference exact
+ * in fp32); a product of two such sums truncated to the terms >= 2^-16 relative -- (hi,hi) (hi,mid) (hi,lo) (mid,hi) (mid,mid)
+ * (lo,hi) -- is accumulated exactly in the MFMA's fp32 accumulator.  Six bf16 MFMAs per product term: 1/6 of the bf16 rate,
+ * against 1/16 for the fp32-input MFMA (v_mfma_f32_32x32x2_f32 runs at the vector rate).  Two planes ((hi,hi) (hi,lo)
+ * (lo,hi), 2^-16 relative) cost 1/3.
+ *
+ * fino_split_bf16: out[row][s * cols + c] = plane p_s of x[row][c] for the nseg <= 6 segments s, p_s = (planes_packed >>
+ *   2 s) & 3 in {0: hi, 1: mid, 2: lo}; x fp32 [rows, cols] (row stride ldx), out bf16 (row stride ldo >= nseg * cols).  The
+ *   layouts in use: the A operand of fino_conv3d_split = the planes side by side (nseg = planes, p = 0, 1[, 2]); the operands of a
+ *   plain fino_gemm with FINO_EPI_F32 = one plane per product, A: (0,0,0,1,1,2) / (0,0,1), W: (0,1,2,0,1,0) / (0,1,0).
+ * fino_rmsnorm_silu_cl_f32: fino_rmsnorm_silu_cl on fp32 activations, computed in fp32 in the reference's order (x / max(||x||,
+ *   1e-12) * sqrt(C) * gamma, SiLU by an IEEE division); y = fp32 [rows, c_pad] (nseg = 0) or the split planes of
+ *   fino_split_bf16 (bf16 [rows, nseg * c_pad]) in the same pass.
+ * fino_conv3d_split: fino_conv3d on split operands.  x_planes bf16 [T, H, W, planes * c_in_pad] (planes = 2 | 3 side by side),
+ *   w_products bf16 [c_out_pad][tap][product][c_in_pad] with the W plane of product s = (0,1,2,0,1,0)[s] / (0,1,0)[s] of the fp32
+ *   weight; bias, y and r fp32; the main loop's K walk visits a tap's products in that order and reads A plane (0,0,0,1,1,2)[s]
+ *   / (0,0,1)[s].  epilogue FINO_EPI_NONE | FINO_EPI_RESIDUAL (y += r).  Returns FINO_ERR_UNSUPPORTED when one 256-row
+ *   tile's input span exceeds 2 GiB (run the layer on fewer frames at a time). */
+int fino_split_bf16(const float* x, void* out, int64_t rows, int cols, int64_t ldx, int64_t ldo, int nseg,
+                    unsigned planes_packed, void* stream);
+int fino_rmsnorm_silu_cl_f32(const float* x, void* y, int64_t rows, int c_valid, int c_pad, const float* gamma, int silu,
+                             int nseg, unsigned planes_packed, void* stream);
+int fino_conv3d_split(const void* x_planes, const void* w_products, const float* bias, float* y, int t_in, int h_in, int w_in,
+                      int c_in_pad, int planes, int t_out, int h_out, int w_out, int c_out_pad, int kt, int kh, int kw, int st,
+                      int sh, int sw, int pt, int ph, int pw, int upsample2x, int epilogue, const float* r,
+                      const void* zero_page, void* stream);
 
 /* ---- MXFP8 linear layers (BASELINE config 5: "fp8 MFMA path"; no reference counterpart) -------------
  * OCP e4m3 elements with one e8m0 scale per 32 consecutive K-elements (MX), fp32 accumulate
@@ -413,13 +453,19 @@ int fino_traj_blur_quantize(const float* canvas, float* scratch, float* out, con
  *   y = T(T(y * scale[z]) + shift[z]) through F.interpolate's nearest index map (first frame of an odd-length batch
  *   mapped on its own); silu != 0 appends T(silu(y)).  workspace: fino_groupnorm_workspace_bytes(c_pad) bytes.
  * fino_avg_pool_time2: CogVideoXDownsample3D's temporal compression: frame pairs averaged, the first frame of an
- *   odd-length batch kept -> [t_in/2 (+1), H, W, Cpad]. */
+ *   odd-length batch kept -> [t_in/2 (+1), H, W, Cpad].
+ * fino_vae_blend_tiles: diffusers' blend_v (axis 0) / blend_h (axis 1) of AutoencoderKLCogVideoX.tiled_encode / tiled_decode
+ *   (`vae.enable_tiling()`, reference test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96; the loops are those of the
+ *   in-tree architecture/autoencoder_kl_wan.py:1254-1268), in place on tile b [t, h_b, w_b, c_pad] from its upper / left
+ *   neighbour a [t, h_a, w_a, c_pad]:  b[y] = T(T(a[n_a - e + y] * (1 - y / e)) + T(b[y] * (y / e))), e = min(extent, n_a, n_b). */
 int64_t fino_groupnorm_workspace_bytes(int c_pad);
 int fino_groupnorm_cl(const void* x, void* y, int t, int h, int w, int channels, int c_pad, int groups,
                       const float* gamma, const float* beta, float eps, const void* mod_scale, const void* mod_shift,
                       int tz, int hz, int wz, int silu, void* workspace, int64_t workspace_bytes, int dtype,
                       void* stream);
 int fino_avg_pool_time2(const void* x, void* y, int t_in, int h, int w, int c_pad, int dtype, void* stream);
+int fino_vae_blend_tiles(const void* a, void* b, int t, int h_a, int w_a, int h_b, int w_b, int c_pad, int extent, int axis,
+                         int dtype, void* stream);
 
 /* Canvas / identity-reference builders of app.py (:270-350 build_canvas, :634-695 ID padding), on the device.
  * fino_resize_area_pad_u8: pixel-area resampling (cv2.INTER_AREA's area relation; OpenCV is third-party and absent

@@ -347,6 +347,49 @@ def test_cog_full_call_plumbing_with_a_stand_in_vae(golden):
         CogVideoXImageToVideoPipeline(transformer=m, scheduler=CogVideoXDDIMScheduler())(image=image)
 
 
+def test_cog_call_batches_run_video_by_video(golden):
+    """B rows of `prompt_embeds` / `latents` (what a list of B prompts becomes; reference :744-750 computes that batch size, its
+    loop then breaks on the batch-1 trajectory / identity latents at :872-880): the mirror runs the batch video by video -- every
+    row equals the single call on that row's noise and prompt, with one shared first frame and with one first frame per prompt."""
+    from frameino_amd.pipeline_cogvideox_i2v_motion_frameino import CogVideoXImageToVideoPipeline
+    from frameino_amd.schedulers import CogVideoXDDIMScheduler
+    pipe0, a, _ = _cog_pipe(golden)
+    vae = _FakeCogVAE(c_lat=16).to(DEV)
+    pipe = CogVideoXImageToVideoPipeline(transformer=pipe0.transformer, scheduler=CogVideoXDDIMScheduler(), vae=vae)
+    g = torch.Generator().manual_seed(12)
+    H = W = 64
+    frames = 9
+    image = torch.rand(2, 3, H, W, generator=g) * 2 - 1
+    traj = torch.rand(frames, 3, H, W, generator=g) * 2 - 1
+    ident = torch.rand(3, H, W, generator=g) * 2 - 1
+    lat0 = torch.randn(2, 3, 16, 8, 8, generator=g)
+    pe = torch.cat([a["prompt_embeds"], a["prompt_embeds"].flip(1)]).to(DEV).bfloat16()
+    ne = torch.cat([a["negative_embeds"], a["negative_embeds"]]).to(DEV).bfloat16()
+    kw = dict(traj_tensor=traj.to(DEV), ID_tensor=ident.to(DEV), height=H, width=W, num_frames=frames, num_inference_steps=3,
+              guidance_scale=6.0, add_ID_reference_augment_noise=False, output_type="latent")
+    for shared_image in (True, False):
+        im = image[:1] if shared_image else image
+        both = pipe(image=im.to(DEV), latents=lat0.to(DEV), prompt_embeds=pe, negative_prompt_embeds=ne, **kw).frames
+        assert both.shape[0] == 2
+        for i in range(2):
+            one = pipe(image=(im[:1] if shared_image else im[i:i + 1]).to(DEV), latents=lat0[i:i + 1].to(DEV),
+                       prompt_embeds=pe[i:i + 1], negative_prompt_embeds=ne[i:i + 1], **kw).frames
+            assert torch.equal(both[i:i + 1], one), (shared_image, i)
+    assert not torch.equal(both[0], both[1])
+    # noise drawn inside the call: a list of generators = one row each; `num_videos_per_prompt` is ignored as in the reference (:723)
+    gens = [torch.Generator().manual_seed(5), torch.Generator().manual_seed(6)]
+    drawn = pipe(image=image[:1].to(DEV), prompt_embeds=pe, negative_prompt_embeds=ne, generator=gens, num_videos_per_prompt=3,
+                 **kw).frames
+    row1 = pipe(image=image[:1].to(DEV), prompt_embeds=pe[1:], negative_prompt_embeds=ne[1:],
+                generator=torch.Generator().manual_seed(6), **kw).frames
+    assert drawn.shape[0] == 2 and torch.equal(drawn[1:], row1)
+    vid = pipe(image=image[:1].to(DEV), latents=lat0.to(DEV), prompt_embeds=pe, negative_prompt_embeds=ne,
+               **dict(kw, output_type="pil")).frames
+    assert len(vid) == 2 and len(vid[0]) == frames
+    with pytest.raises(ValueError):
+        pipe(image=image[:1].to(DEV), prompt_embeds=pe, negative_prompt_embeds=ne, generator=gens[:1] * 3, **kw)
+
+
 def test_baseline_config1_shape_full_width_two_layers_vs_oracle():
     """BASELINE config 1's shape class: the STAGE-1 CogVideoX-5B model (`use_FrameIn=False`) on 13 frames
     256x256 -> hidden_states [2, 4, 48, 32, 32], text [2, 226, 4096], L = 226 + 1024, resized learned PE -- at the real

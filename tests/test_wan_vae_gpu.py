@@ -190,3 +190,140 @@ def test_full_size_decode_vs_oracle_fp32_on_device():
     record("wan_vae_decode_full_size_5_latent_frames_704x1280", "rel_rms (all pixels / unclamped pixels: "
            f"{r_in:.4f})", r, 2.5e-2)
     assert p > 38.0 and r < 2.5e-2, (p, r)
+
+
+# ------------------------------------------------------------------------------------------------ fp32-compute mode (round 5)
+@pytest.mark.parametrize("planes,bound", [(3, 2e-6), (2, 6e-5)])
+@pytest.mark.parametrize("name,ci,co,k,stride,pad,up,thw", [
+    ("causal3x3x3", 48, 72, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, (5, 6, 7)),
+    ("1x1x1", 100, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (3, 5, 4)),
+    ("up2x+conv2d", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, (3, 5, 6)),
+    ("down conv2d s2", 40, 40, (1, 3, 3), (1, 2, 2), (0, 0, 0), False, (3, 8, 10)),
+    ("down time s2", 64, 64, (3, 1, 1), (2, 1, 1), (0, 0, 0), False, (9, 4, 5)),
+    ("wide K", 512, 256, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, (3, 9, 10)),
+])
+def test_split_bf16_conv_vs_torch_fp64(name, ci, co, k, stride, pad, up, thw, planes, bound):
+    """fino_conv3d_split: fp32 activations and weights as bf16 planes, the cross terms >= 2^-16 relative accumulated on the matrix
+    pipe -- against the same convolution in fp64 on UNROUNDED fp32 operands.  Three planes: the error of an fp32 convolution
+    (torch's own fp32 conv measures the same); two planes: ~2^-16."""
+    from frameino_amd import ops
+    from frameino_amd.autoencoder_kl_wan import cpad
+    g = torch.Generator().manual_seed(1)
+    t, h, w = thw
+    x = torch.randn(1, ci, t, h, w, generator=g)
+    wt = torch.randn(co, ci, *k, generator=g) / math.sqrt(ci * k[0] * k[1] * k[2])
+    b = torch.randn(co, generator=g) * 0.1
+    xin = x.double()
+    if up:
+        xin = F.interpolate(xin[0].permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact").permute(1, 0, 2, 3)[None]
+    if name == "down conv2d s2":
+        ref = F.conv3d(F.pad(xin, (0, 1, 0, 1)), wt.double(), b.double(), stride=stride)
+    else:
+        ref = F.conv3d(F.pad(xin, (pad[2], pad[2], pad[1], pad[1], pad[0], 0)), wt.double(), b.double(), stride=stride)
+    xcl = torch.zeros(t, h, w, cpad(ci))
+    xcl[..., :ci] = x[0].permute(1, 2, 3, 0)
+    w2 = _pack(wt, cpad(ci), cpad(co))                                       # [Cout_pad, taps * Cin_pad] fp32
+    taps = k[0] * k[1] * k[2]
+    w6 = ops.split_bf16(w2.reshape(cpad(co) * taps, cpad(ci)).to(DEV).contiguous(), "W", planes).reshape(cpad(co), -1)
+    b2 = torch.zeros(cpad(co))
+    b2[:co] = b
+    xp = ops.split_bf16(xcl.to(DEV), "planes", planes)
+    assert xp.shape == (t, h, w, planes * cpad(ci)) and xp.dtype == torch.bfloat16
+    # the planes add up to the fp32 value (three planes: exactly, up to the last bit of a 24-bit significand)
+    back = xp.float().view(t, h, w, planes, cpad(ci)).sum(3).cpu()
+    assert (back - xcl).abs().max().item() <= (2.0 ** -22 if planes == 3 else 2.0 ** -15) * xcl.abs().max().item()
+    out_thw = tuple(ref.shape[2:])
+    y = ops.conv3d_split_cl(xp, w6, b2.to(DEV), k, planes, stride, pad, out_thw, up)
+    assert y.dtype == torch.float32
+    got = y[..., :co].permute(3, 0, 1, 2).double().cpu()[None]
+    e = rel_rms(got, ref)
+    e32 = rel_rms(F.conv3d(F.pad(xin.float(), (0, 1, 0, 1)) if name == "down conv2d s2" else
+                           F.pad(xin.float(), (pad[2], pad[2], pad[1], pad[1], pad[0], 0)), wt, b, stride=stride).double(), ref)
+    print(f"{name} planes={planes}: split-bf16 conv rel-RMS {e:.2e} vs fp64 (torch fp32 conv on the CPU: {e32:.2e})")
+    assert got.shape == ref.shape and e < bound, (name, planes, e)
+    if cpad(co) > co:
+        assert y[..., co:].abs().max().item() == 0
+    r = torch.randn(y.shape, device=DEV)
+    y2 = ops.conv3d_split_cl(xp, w6, b2.to(DEV), k, planes, stride, pad, out_thw, up, residual=r)
+    assert torch.equal(y2, y + r)                                            # one fp32 add in the epilogue
+
+
+def test_split_bf16_plain_gemm_fp32_output():
+    """fino_gemm with FINO_EPI_F32 / FINO_EPI_F32_RESIDUAL on operands expanded one plane per product (the mid-block attention's
+    matrix products in the fp32-compute mode): ragged M, N = 8 and N = 3520-ish, against fp64."""
+    from frameino_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for m, n, kdim in ((300, 1024, 1024), (3520, 3520, 1024), (77, 8, 64)):
+        a = torch.randn(m, kdim, generator=g).to(DEV)
+        w = (torch.randn(n, kdim, generator=g) / math.sqrt(kdim)).to(DEV)
+        b = torch.randn(n, generator=g).to(DEV)
+        r = torch.randn(m, n, generator=g).to(DEV)
+        ref = a.double() @ w.double().t() + b.double()
+        for planes, bound in ((3, 2e-6), (2, 6e-5)):
+            got = ops.gemm_f32(ops.split_bf16(a, "A", planes), ops.split_bf16(w, "W", planes), b)
+            assert got.dtype == torch.float32 and rel_rms(got.double(), ref) < bound, (m, n, planes, rel_rms(got.double(), ref))
+            got2 = ops.gemm_f32(ops.split_bf16(a, "A", planes), ops.split_bf16(w, "W", planes), b, residual=r)
+            assert torch.equal(got2, got + r)
+
+
+def test_fp32_compute_mode_tiny_vae_vs_reference_golden(golden):
+    """`set_compute_dtype(torch.float32)` on the tiny VAE against the reference's own fp32 streaming run (the golden fixture):
+    decode 1 / 2 / 3 latent frames, encode 1 / 5 / 9 frames -- at fp32 accuracy, where the bf16 mode is held to 35 dB / 3e-2."""
+    from tests.parity import record
+    vae, a = _vae(golden, "wan_vae_tiny")
+    vae.set_compute_dtype(torch.float32)
+    assert vae.compute_dtype == torch.float32
+    worst_d = worst_e = 0.0
+    for nl in (1, 2, 3):
+        out = vae.decode(a[f"dec_in_{nl}"].to(DEV), return_dict=False)[0]
+        ref = a[f"dec_out_{nl}"]
+        assert out.shape == ref.shape and out.dtype == torch.float32
+        worst_d = max(worst_d, (out.cpu() - ref).abs().max().item())
+    for nf in (1, 5, 9):
+        post = vae.encode(a[f"enc_in_{nf}"].to(DEV)).latent_dist
+        ref = a[f"enc_out_{nf}"]
+        assert post.parameters.shape == ref.shape
+        worst_e = max(worst_e, rel_rms(post.parameters, ref))
+    record("wan_vae_tiny_fp32_compute[decode]", "max-abs vs the reference's fp32 streaming decode (video in [-1, 1])", worst_d, 1e-5)
+    record("wan_vae_tiny_fp32_compute[encode]", "rel_rms of the moments vs the reference's fp32 streaming encode", worst_e, 1e-5)
+    assert worst_d < 1e-5 and worst_e < 1e-5, (worst_d, worst_e)
+    # ... and the time-chunked tail stays bit-identical in this mode too
+    vae.decode_chunk_frames = 0
+    z = a["dec_in_3"].to(DEV)
+    whole = vae.decode(z, return_dict=False)[0]
+    vae.decode_chunk_frames = 2
+    assert torch.equal(whole, vae.decode(z, return_dict=False)[0])
+    vae.set_compute_dtype(torch.bfloat16)
+    assert vae.compute_dtype == torch.bfloat16 and psnr(vae.decode(z, return_dict=False)[0], a["dec_out_3"]) > 35.0
+
+
+@pytest.mark.parametrize("planes,min_psnr,max_rel", [(3, 80.0, 1e-4), (2, 70.0, 4e-4)])
+def test_full_size_decode_fp32_compute_vs_oracle_fp32_on_device(planes, min_psnr, max_rel):
+    """the reference app decodes in fp32 (app.py:157).  5 latent frames at 704x1280, the real Wan2.2 VAE widths,
+    seeded random weights: `set_compute_dtype(torch.float32)` against oracle/wan_vae.py executed in fp32 on the device (whose own
+    convolutions are an fp32 library's: two fp32 computations of the same network, so the bound is what THEY differ by)."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    from oracle import wan_vae as V
+    from tests.parity import record
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=7, device=DEV)
+    vae.set_compute_dtype(torch.float32, planes=planes)
+    sd = {k: v.float() for k, v in vae._sd.items()}
+    z = torch.randn(1, 48, 5, 44, 80, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    import time
+    with torch.no_grad():
+        out = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        ref = V.wan_vae_decode(sd, dict(WAN22_VAE_CFG), z)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape == (1, 3, 17, 704, 1280) and torch.isfinite(out).all()
+    p, r = psnr(out, ref), rel_rms(out, ref)
+    print(f"fp32-compute decode, {planes} planes: PSNR {p:.1f} dB, rel-RMS {r:.2e}, {dt_s:.2f} s for 17 frames")
+    record(f"wan_vae_decode_fp32_compute_{planes}planes_5_latent_frames_704x1280", "PSNR dB vs oracle fp32 on device (higher is better)",
+           p, min_psnr, lower_is_better=False)
+    record(f"wan_vae_decode_fp32_compute_{planes}planes_5_latent_frames_704x1280", f"rel_rms ({dt_s:.2f} s for 17 frames)", r, max_rel)
+    assert p > min_psnr and r < max_rel, (p, r)

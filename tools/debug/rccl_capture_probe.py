@@ -2,6 +2,7 @@
 """Which RCCL call patterns survive hipGraph capture on this image (torch 2.10 + RCCL 2.26, one rank)?  One pattern per
 child process; faulthandler prints the Python stack of a crash.
     python tools/debug/rccl_capture_probe.py            # all patterns
+    python tools/debug/rccl_capture_probe.py only <pattern> ...   # those patterns
     python tools/debug/rccl_capture_probe.py child <pattern>"""
 import faulthandler
 import os
@@ -9,7 +10,10 @@ import subprocess
 import sys
 
 PATTERNS = ["allgather_main", "allgather_side", "allgather_two_comms_two_sides", "alltoall_main", "alltoall_side",
-            "allgather_main_sync", "alltoall_main_sync"]
+            "allgather_main_sync", "alltoall_main_sync",
+            # round 5: kernels on two side streams, every collective ISSUED with the capturing stream current
+            "sides_compute_only", "allgather_main_issue_side_wait", "allgather_main_issue_main_wait",
+            "allgather_main_issue_side_wait_two_comms"]
 
 
 def child(pattern):
@@ -74,6 +78,51 @@ def child(pattern):
             main.wait_stream(s1)
             main.wait_stream(s2)
             return r1 + r2
+        if pattern == "sides_compute_only":
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                r1 = x * 2
+            with torch.cuda.stream(s2):
+                r2 = x * 3
+            main.wait_stream(s1)
+            main.wait_stream(s2)
+            return r1 + r2
+        if pattern in ("allgather_main_issue_side_wait", "allgather_main_issue_main_wait",
+                       "allgather_main_issue_side_wait_two_comms"):
+            # the interleaved plan re-expressed: the branches' kernels run on s1 / s2, the capturing stream carries only
+            # event waits and the collectives (c10d forks its communicator stream from the CAPTURING stream, the pattern
+            # that captures); a branch's stream then waits for its own collective
+            gb_ = gb if pattern.endswith("two_comms") else ga
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                a1 = x * 2                      # "S_A": produces what the collective sends
+            with torch.cuda.stream(s2):
+                a2 = x * 3
+            main.wait_stream(s1)
+            w1 = dist.all_gather_into_tensor(y1, a1, group=ga, async_op=True)
+            main.wait_stream(s2)
+            w2 = dist.all_gather_into_tensor(y2, a2, group=gb_, async_op=True)
+            if pattern == "allgather_main_issue_main_wait":
+                w1.wait()
+                s1.wait_stream(main)
+                with torch.cuda.stream(s1):
+                    r1 = y1 + a1
+                w2.wait()
+                s2.wait_stream(main)
+                with torch.cuda.stream(s2):
+                    r2 = y2 + a2
+            else:
+                with torch.cuda.stream(s1):
+                    w1.wait()
+                    r1 = y1 + a1
+                with torch.cuda.stream(s2):
+                    w2.wait()
+                    r2 = y2 + a2
+            main.wait_stream(s1)
+            main.wait_stream(s2)
+            return r1 + r2
         raise ValueError(pattern)
 
     ref = body()
@@ -96,7 +145,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(sys.argv[2])
         sys.exit(0)
-    for pat in PATTERNS:
+    pats = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "only" else PATTERNS
+    for pat in pats:
         print(f"===== {pat}", flush=True)
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "child", pat], timeout=80, capture_output=True,

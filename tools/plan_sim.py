@@ -2,7 +2,8 @@
 """Compute-side cost of the multi-GPU plans on ONE GPU: the per-rank work of an N-GPU run with the collectives replaced
 by local copies (a fake TokenShard), full Wan2.2-5B size.  split(N): one CFG branch, 1/(N/2) of the tokens;
 interleave(N): both branches, 1/N of the tokens each, advanced alternately on two streams.  Add the K|V all-gather
-time of the node by hand -- this measures what the GPU has to do, not the wire."""
+time of the node by hand -- this measures what the GPU has to do, not the wire; or model the wire's
+DURATION with FINO_PLAN_SIM_WIRE_GBPS (FakeShard) to see which plans hide it."""
 import os
 import sys
 import time
@@ -15,18 +16,68 @@ from bench import build_model  # noqa: E402
 from frameino_amd.parallel import TokenShard  # noqa: E402
 
 
+class _WireWork:
+    """stands for c10d's work handle: wait() makes the CURRENT stream wait for the modelled wire"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class FakeShard(TokenShard):
-    """rank 0 of `ways`; the all-gather copies the local block into its slot (the other slots keep old data)."""
+    """rank 0 of `ways`; the all-gather copies the local block into its slot (the other slots keep old data).
+
+    FINO_PLAN_SIM_WIRE_GBPS=<GB/s into one rank, all links together> (round 5): the exchange then also TAKES TIME -- a spin kernel
+    of bytes_received / rate on a stream of its own (one per communicator, as c10d keeps one), after which the copy runs; the
+    forward's work.wait() waits for it.  One GPU cannot show what xGMI delivers; this shows which plans HIDE an exchange of a given
+    duration behind the other branch's kernels and which stand and wait for it (1 WG spinning: it takes no CU from the GEMMs)."""
+
+    wire_gbps = float(os.environ.get("FINO_PLAN_SIM_WIRE_GBPS", "0") or 0)
+    if os.environ.get("FINO_PLAN_SIM_KV_GROUPS"):          # A/B: head groups of the K|V all-gather (TokenShard.kv_head_groups)
+        kv_head_groups = int(os.environ["FINO_PLAN_SIM_KV_GROUPS"])
+    _spin_per_us = None
+
+    def _wire(self, nbytes, cur_tensor, copy_fn, async_op):
+        if not self.wire_gbps:
+            copy_fn()
+            return None
+        if FakeShard._spin_per_us is None:                 # calibrate torch.cuda._sleep's unit once
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1000000)
+            e0.record(); torch.cuda._sleep(20000000); e1.record()
+            torch.cuda.synchronize()
+            FakeShard._spin_per_us = 20000000 / (e0.elapsed_time(e1) * 1e3)
+        if getattr(self, "_wire_stream", None) is None:
+            self._wire_stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        iss = self.issue_stream                       # as TokenShard._issue: the step's own stream issues, the branch's stream waits
+        if iss is not None and iss != cur:            # (a stream forked from a SIDE stream inside a capture segfaults in
+            iss.wait_stream(cur)                      # hipStreamEndCapture on this image -- the same runtime limit as c10d's)
+            cur = iss
+        self._wire_stream.wait_stream(cur)
+        with torch.cuda.stream(self._wire_stream):
+            torch.cuda._sleep(int(nbytes / (self.wire_gbps * 1e3) * FakeShard._spin_per_us))      # bytes / (GB/s) = ns -> us
+            copy_fn()
+            ev = torch.cuda.Event()
+            ev.record()
+        work = _WireWork(ev)
+        if not async_op:
+            work.wait()
+            return None
+        return work
 
     def _all_gather(self, key, t, async_op):
         out = self._get(key, (self.ways * t.shape[0],) + tuple(t.shape[1:]), t.dtype, t.device)
-        out[:t.shape[0]].copy_(t)
-        return out, None
+        work = self._wire((self.ways - 1) * t.numel() * t.element_size(), t, lambda: out[:t.shape[0]].copy_(t), async_op)
+        return out, work
 
     def all_to_all(self, key, send, async_op=False):   # heads exchange: every slice "arrives" as a copy of what was sent
         recv = self._get(key, tuple(send.shape), send.dtype, send.device)
-        recv.copy_(send)
-        return recv, None
+        work = self._wire((self.ways - 1) * send[0].numel() * send.element_size(), send, lambda: recv.copy_(send), async_op)
+        return recv, work
 
 
 def main():
@@ -46,8 +97,16 @@ def main():
     idl = torch.randn(1, C, 1, lh, lw, generator=g).to(dev)
     mask = torch.ones(1, 1, fg, lh, lw, device=dev)
     mask[:, :, 0] = 0
-    pe = torch.randn(1, 512, cfg["text_dim"], generator=g).to(dev).bfloat16()
-    ne = torch.randn(1, 512, cfg["text_dim"], generator=g).to(dev).bfloat16()
+    pe = torch.randn(1, 512, cfg["text_dim"], generator=g)
+    ne = torch.randn(1, 512, cfg["text_dim"], generator=g)
+    if not os.environ.get("FINO_PLAN_SIM_UNPADDED"):
+        # round 5: the prompts of bench.py's headline workload -- 64 / 8 tokens zero-padded to 512 rows, as the reference pads
+        # every prompt (pipeline_wan_i2v_motion_FrameINO.py:235-238) -- so that a simulated rank runs the text branch the bench
+        # step runs (padding run folded, out-projection re-associated).  Rounds 2-4 simulated un-padded 512-token prompts
+        # (FINO_PLAN_SIM_UNPADDED=1): their N = 1 line is ~2 % above the bench's for that reason.
+        pe[:, 64:] = 0
+        ne[:, 8:] = 0
+    pe, ne = pe.to(dev).bfloat16(), ne.to(dev).bfloat16()
     pipe.scheduler.set_timesteps(8, device=dev)
     st = pipe.make_state(lat, cond, traj, idl, mask, pe, ne, 5.0)
     st.t_rows[1:2] = 700.0
