@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 linears (reduced precision, opt-in)")
     ap.add_argument("--fp8-attention", action="store_true", help="fp8 (e4m3) attention operands (reduced precision, opt-in)")
     ap.add_argument("--smoke", action="store_true", help="tiny random model + tiny VAE, 64x96, 9 frames")
+    ap.add_argument("--no-tiling", action="store_true", help="random-weight run: leave the VAE's tiling off (the evaluation "
+                                                              "script switches it on)")
     ap.add_argument("--repeat", type=int, default=1, help="generate the clip this many times (the first call is cold)")
     ap.add_argument("--out", default=None, help="write the cropped uint8 frames [F, h, w, 3] as .npy")
     a = ap.parse_args()
@@ -98,6 +100,11 @@ def main():
             vae_kw = dict(block_out_channels=(32, 64, 64, 128), layers_per_block=1, norm_num_groups=8)
         transformer = random_cog_model(cfg, dev)
         vae = AutoencoderKLCogVideoX(**vae_kw).random_init_(seed=2, device=dev)
+        if not a.no_tiling:
+            # as the evaluation script does (test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96): at 480 x 720 the tiles
+            # (240 x 360, overlapping) are active in every encode and in the decode
+            vae.enable_slicing()
+            vae.enable_tiling()
         text_dim = cfg["text_embed_dim"]
         pipe = CogVideoXImageToVideoPipeline(vae=vae, transformer=transformer, scheduler=sched)
     if a.mxfp8:

@@ -99,12 +99,20 @@ class AutoencoderKLCogVideoX(FromPretrainedMixin):
 
     def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 512), latent_channels=16,
                  layers_per_block=3, norm_eps=1e-6, norm_num_groups=32, temporal_compression_ratio=4,
-                 scaling_factor=0.7, invert_scale_latents=False, **unused):
+                 scaling_factor=0.7, invert_scale_latents=False, sample_height=480, sample_width=720, **unused):
         self.config = _Config(in_channels=in_channels, out_channels=out_channels,
                               block_out_channels=tuple(block_out_channels), latent_channels=latent_channels,
                               layers_per_block=layers_per_block, norm_eps=norm_eps, norm_num_groups=norm_num_groups,
                               temporal_compression_ratio=temporal_compression_ratio, scaling_factor=scaling_factor,
-                              invert_scale_latents=invert_scale_latents)
+                              invert_scale_latents=invert_scale_latents, sample_height=sample_height,
+                              sample_width=sample_width)
+        self.use_slicing = self.use_tiling = False
+        # diffusers' tiling bookkeeping (AutoencoderKLCogVideoX.__init__): minimum tile = half the sample size of the config
+        self.tile_sample_min_height = sample_height // 2
+        self.tile_sample_min_width = sample_width // 2
+        self.tile_overlap_factor_height = 1 / 6
+        self.tile_overlap_factor_width = 1 / 5
+        self._tile_latent()
         for c in block_out_channels:
             if cpad(c) & (cpad(c) - 1):
                 raise ValueError("block_out_channels must pad to powers of two (GroupNorm kernel layout)")
@@ -132,11 +140,26 @@ class AutoencoderKLCogVideoX(FromPretrainedMixin):
     def disable_slicing(self):
         self.use_slicing = False
 
-    def enable_tiling(self, *tile_args, **tile_kwargs):
-        """diffusers' tiling blends overlapping spatial tiles (a memory saver that changes the result); this mirror already
-        walks the video in diffusers' own frame batches (8 sample / 2 latent frames with conv caches: 12 GiB at
-        49 f 480x720), so the switch is accepted and the result stays the untiled one."""
+    def _tile_latent(self):
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        self.tile_latent_min_height = int(self.tile_sample_min_height / down)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / down)
+
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_overlap_factor_height=None,
+                      tile_overlap_factor_width=None):
+        """diffusers' `enable_tiling` (what the canonical caller switches on: reference
+        test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96): frames larger than a tile -- half the config's sample size,
+        240 x 360 -- are encoded / decoded as OVERLAPPING spatial tiles, each walked in the frame batches with its own conv
+        caches, and blended over the overlap (`tiled_encode` / `tiled_decode`; overlap factors 1/6 and 1/5).  The result
+        differs from the un-tiled one (GroupNorm statistics are per tile, the overlap is a linear cross-fade), and at the
+        default 480 x 720 tiling is ACTIVE -- so a drop-in must reproduce it: round 5 implements it on the HIP convolutions
+        (fino_vae_blend_tiles) against the oracle's restatement (oracle/cog_vae.py; third-party: parity unpinned)."""
         self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
+        self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
+        self._tile_latent()
 
     def disable_tiling(self):
         self.use_tiling = False
@@ -306,11 +329,48 @@ class AutoencoderKLCogVideoX(FromPretrainedMixin):
         y[..., :c] = x[0].permute(1, 2, 3, 0).to(self._dtype)
         return y
 
+    def _tiles(self, xs, tile_h, tile_w, stride_h, stride_w, batch, run):
+        """rows of tiles as tiled_encode / tiled_decode build them: tile (i, j) = frames walked in `batch`-frame batches (own conv
+        caches) over xs[:, i : i + tile_h, j : j + tile_w]; channels-last [T', h', w', Cpad] each"""
+        rows = []
+        for i in range(0, xs.shape[1], stride_h):
+            row = []
+            for j in range(0, xs.shape[2], stride_w):
+                caches, outs = {}, []
+                for s, e in frame_batches(xs.shape[0], batch):
+                    y, caches = run(xs[s:e, i:i + tile_h, j:j + tile_w].contiguous(), caches)
+                    outs.append(y)
+                row.append(torch.cat(outs, dim=0))
+            rows.append(row)
+        return rows
+
+    @staticmethod
+    def _blend(rows, extent_h, extent_w, limit_h, limit_w):
+        """every tile blended IN PLACE with its (already blended) upper and left neighbour, cropped to the stride, concatenated"""
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0 and extent_h > 0:
+                    ops.vae_blend_tiles_(rows[i - 1][j], tile, extent_h, 0)
+                if j > 0 and extent_w > 0:
+                    ops.vae_blend_tiles_(row[j - 1], tile, extent_w, 1)
+                result_row.append(tile[:, :limit_h, :limit_w])
+            result_rows.append(torch.cat(result_row, dim=2))
+        return torch.cat(result_rows, dim=1)
+
     @torch.no_grad()
     def _encode(self, x):
         self._pk or self._pack()
         cfg = self.config
         xs = self._to_cl(x, cfg.in_channels)
+        if self.use_tiling and (xs.shape[2] > self.tile_sample_min_width or xs.shape[1] > self.tile_sample_min_height):
+            th, tw = self.tile_sample_min_height, self.tile_sample_min_width
+            fh, fw = self.tile_overlap_factor_height, self.tile_overlap_factor_width
+            eh, ew = int(self.tile_latent_min_height * fh), int(self.tile_latent_min_width * fw)
+            rows = self._tiles(xs, th, tw, int(th * (1 - fh)), int(tw * (1 - fw)), self.num_sample_frames_batch_size, self._encoder)
+            m = self._blend(rows, eh, ew, self.tile_latent_min_height - eh, self.tile_latent_min_width - ew)
+            return m[..., :2 * cfg.latent_channels].permute(3, 0, 1, 2)[None].contiguous()
         caches, outs = {}, []
         for s, e in frame_batches(xs.shape[0], self.num_sample_frames_batch_size):
             y, caches = self._encoder(xs[s:e].contiguous(), caches)
@@ -328,6 +388,13 @@ class AutoencoderKLCogVideoX(FromPretrainedMixin):
         self._pk or self._pack()
         cfg = self.config
         zs = self._to_cl(z, cfg.latent_channels)
+        if self.use_tiling and (zs.shape[2] > self.tile_latent_min_width or zs.shape[1] > self.tile_latent_min_height):
+            th, tw = self.tile_latent_min_height, self.tile_latent_min_width
+            fh, fw = self.tile_overlap_factor_height, self.tile_overlap_factor_width
+            eh, ew = int(self.tile_sample_min_height * fh), int(self.tile_sample_min_width * fw)
+            rows = self._tiles(zs, th, tw, int(th * (1 - fh)), int(tw * (1 - fw)), self.num_latent_frames_batch_size, self._decoder)
+            v = self._blend(rows, eh, ew, self.tile_sample_min_height - eh, self.tile_sample_min_width - ew)
+            return v[..., :cfg.out_channels].permute(3, 0, 1, 2)[None].contiguous()
         caches, outs = {}, []
         for s, e in frame_batches(zs.shape[0], self.num_latent_frames_batch_size):
             y, caches = self._decoder(zs[s:e].contiguous(), caches)

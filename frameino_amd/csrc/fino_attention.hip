@@ -12,11 +12,12 @@
 //   * K/V tiles of 64 keys are register-staged (buffer/global_load_dwordx4, then ds_write_b128) into a double-buffered,
 //     XOR-swizzled LDS image that is conflict-free for both the row reads (K) and the transposed reads (V).
 //   * Main loops: attn_pp_kernel -- PING-PONG: the two waves of a SIMD alternate a softmax phase and a 32-MFMA matrix
-//     phase, one phase apart, two barriers per tile -- and attn_fwd_kernel, the earlier one-barrier loop in which every
-//     wave interleaves S(t+1) MFMAs with the exp of S(t) (FINO_ATTN_PP=0, kept for A/B).  Round 4, head_dim 128:
+//     phase, one phase apart, two barriers per tile (the earlier one-barrier loop in which every wave interleaved S(t+1)
+//     MFMAs with the exp of S(t) left the library in round 5: git history).  Round 4, head_dim 128:
 //     attn_ppd_kernel (the default for long key sequences: the ping-pong loop with K/V by LDS-DMA into four-slot rings,
 //     LDS reads issued between the MFMAs) and attn_ppw_kernel (short key sequences: one workgroup per CU walks a run of
-//     q-blocks without draining).  attn_fr_kernel (round 3): 4 waves, two workgroups per CU.  All give the same bits.
+//     q-blocks without draining).  attn_fr_kernel (round 3): 4 waves, two workgroups per CU -- short key sequences with
+//     fewer than two q-blocks per CU (token shards).  All give the same bits.  INTEGRATION.md has the dispatch table.
 //   * Tail split: the key tiles of an XCD's last, partial round of blocks are dealt to all its CUs (fino_attn_fwd_ws).
 //   * q/k/v are read in place from the fused-QKV GEMM output ([L, 3*H*Dh], strides passed in), o is written
 //     token-major [L, H*Dh]: no transposes anywhere.
@@ -43,316 +44,6 @@ namespace {
 
 // VAR only names the launch site (0: long-KV self-attention, 1: short-KV text cross-attention) so that profilers
 // report the two call classes as separate kernel symbols; the code is identical.
-template <typename T, int D, int VAR>
-__global__ __launch_bounds__(kWaves * 64, 2) void attn_fwd_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kTileBytes = kKV * D * 2;
-    constexpr int kChunksPerRow = D / 8;
-    constexpr int kLoadsPerThread = (kKV * kChunksPerRow) / (kWaves * 64);  // 2 (D=128) or 1 (D=64)
-    constexpr int kKS = D / 16;                                             // k-steps of QK^T
-    constexpr int kDT = D / 32;                                             // d-tiles of O^T
-    typedef typename T::vec8 vec8;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int r = lane & 31;
-    const int h = lane >> 5;
-
-    // ---- XCD-aware block -> (head-batch, q-block) ----
-    const int id = blockIdx.x;
-    const int xcd = id & 7;
-    const int slot = id >> 3;
-    // whole blocks first; then the XCD's last `rem_x` blocks as one stream of rem_x*nt key tiles cut into `nwg` equal
-    // ranges (tail split): a range covers pieces of at most two blocks (per < nt).
-    const int ntall = (p.lk + kKV - 1) / kKV;
-    int npieces = 1, first_b = 0;
-    int64_t g0 = 0, g1 = 0;
-    if (slot >= p.full_x) {
-        g0 = (int64_t)(slot - p.full_x) * p.per;
-        g1 = g0 + p.per < (int64_t)p.rem_x * ntall ? g0 + p.per : (int64_t)p.rem_x * ntall;
-        first_b = (int)(g0 / ntall);
-        npieces = (int)((g1 - 1) / ntall) - first_b + 1;
-    }
-  for (int piece = 0; piece < npieces; ++piece) {
-    if (piece > 0) __syncthreads();                 // every wave is done reading the previous piece's LDS tiles
-    int bx = slot, part = -1, t_begin = 0, t_end = ntall;
-    if (slot >= p.full_x) {
-        const int tb = first_b + piece;
-        const int64_t b0 = (int64_t)tb * ntall;
-        t_begin = g0 > b0 ? (int)(g0 - b0) : 0;
-        t_end = g1 - b0 < ntall ? (int)(g1 - b0) : ntall;
-        bx = p.full_x + tb;
-        if (t_begin != 0 || t_end != ntall) part = ((xcd * p.nwg) + (slot - p.full_x)) * 2 + piece;
-    }
-    int hb, qb;
-    if (!attn_map_block(p, xcd, bx, hb, qb)) continue;
-    if (p.all_partial) part = hb * p.nqb + qb;
-    const int bi = hb / p.heads;
-    const int head = hb - bi * p.heads;
-
-    const uint16_t* qp = p.q + bi * p.q_bs + head * p.q_hs;
-    const uint16_t* kp = p.k + bi * p.k_bs + head * p.k_hs + (int64_t)t_begin * kKV * p.k_rs;
-    const uint16_t* vp = p.v + bi * p.v_bs + head * p.v_hs + (int64_t)t_begin * kKV * p.v_rs;
-    uint16_t* op = p.o + bi * p.o_bs + head * p.o_hs;
-    // keys of this workgroup's range, re-based to 0 (a multiple of kKV precedes it, so tail masks are unchanged)
-    const int lk = (t_end * kKV < p.lk ? t_end * kKV : p.lk) - t_begin * kKV;
-
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
-    const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
-    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
-    vec8 qf[kKS];
-#pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) {
-        uint4 u = *reinterpret_cast<const uint4*>(qp + (int64_t)qrow_c * p.q_rs + 16 * ks + 8 * h);
-        if (qrow >= p.lq) u = make_uint4(0, 0, 0, 0);      // rows past Lq are never stored: zero operands draw the least power
-        qf[ks] = __builtin_bit_cast(vec8, u);
-    }
-
-    // ---- staging roles ----
-    int st_row[kLoadsPerThread], st_ch[kLoadsPerThread];
-#pragma unroll
-    for (int i = 0; i < kLoadsPerThread; ++i) {
-        const int cid = tid + i * (kWaves * 64);
-        st_row[i] = cid / kChunksPerRow;
-        st_ch[i] = cid % kChunksPerRow;
-    }
-    // NOTE: plain macros over named arrays (lambdas capturing the staging arrays sent them to scratch).
-    u32x4_t kreg[kLoadsPerThread], vreg[kLoadsPerThread];
-    int st_off[kLoadsPerThread];
-#pragma unroll
-    for (int i = 0; i < kLoadsPerThread; ++i) st_off[i] = lds_off<D>(st_row[i], st_ch[i]);
-#define STAGE_LOAD(T_)                                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
-        int row_ = (T_) * kKV + st_row[i_];                                                           \
-        row_ = row_ < lk ? row_ : lk - 1;                                                         \
-        kreg[i_] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)row_ * p.k_rs + st_ch[i_] * 8);      \
-        vreg[i_] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)row_ * p.v_rs + st_ch[i_] * 8);      \
-    }
-#define STAGE_WRITE(BUF_)                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < kLoadsPerThread; ++i_) {                                  \
-        *reinterpret_cast<u32x4_t*>(smem + (BUF_) * kTileBytes + st_off[i_]) = kreg[i_];                \
-        *reinterpret_cast<u32x4_t*>(smem + (2 + (BUF_)) * kTileBytes + st_off[i_]) = vreg[i_];          \
-    }
-
-    // ---- per-lane LDS read addressing ----
-    // K row read (A operand): row = r (+32), chunk = 2*ks + h
-    // V transposed read: 16-lane group g16 = lane>>4; inside it lane 4q+p supplies row q, columns 4p..4p+3.
-    const int tq = (lane & 15) >> 2;
-    const int tp = lane & 3;
-    const int g1 = (lane >> 4) & 1;
-
-    f32x16_t o[kDT];
-#pragma unroll
-    for (int i = 0; i < kDT; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
-    float m_run = -INFINITY;   // running max of scale_log2 * s (log2 domain); only moved by a rescale
-    float l_run = 0.f;
-    const float c2 = p.scale_log2;
-
-    // S^T = K.Q^T for one 64-key tile held in LDS buffer `KB_` -> two 32x32 accumulators
-#define QK_TILE(KB_, S0_, S1_)                                                                              \
-    {                                                                                                       \
-        const char* kb_ = smem + (KB_) * kTileBytes;                                                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) { S0_[j_] = 0.f; S1_[j_] = 0.f; }                 \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < kKS; ++ks_) {                                             \
-            const uint4 a0_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(r, 2 * ks_ + h));            \
-            const uint4 a1_ = *reinterpret_cast<const uint4*>(kb_ + lds_off<D>(32 + r, 2 * ks_ + h));       \
-            S0_ = T::mfma32(__builtin_bit_cast(vec8, a0_), qf[ks_], S0_);                                   \
-            S1_ = T::mfma32(__builtin_bit_cast(vec8, a1_), qf[ks_], S1_);                                   \
-        }                                                                                                   \
-    }
-
-    // Software pipeline (K runs one tile ahead of V): iteration t issues S(t+1) = K(t+1).Q^T on the matrix pipe
-    // while the VALU does the softmax of S(t); then O += V(t)^T.P(t).  LDS: K[2] ring + V[2] ring; K(t+2) and
-    // V(t+1) travel global -> registers during the iteration and are written to LDS at its end; 1 barrier / tile.
-    const int nt = (lk + kKV - 1) / kKV;
-    STAGE_LOAD(0)
-    STAGE_WRITE(0)
-    if (nt > 1) {
-        // K(1) only
-#pragma unroll
-        for (int i = 0; i < kLoadsPerThread; ++i) {
-            int row = kKV + st_row[i];
-            row = row < lk ? row : lk - 1;
-            kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)row * p.k_rs + st_ch[i] * 8);
-            *reinterpret_cast<u32x4_t*>(smem + 1 * kTileBytes + st_off[i]) = kreg[i];
-        }
-    }
-    __syncthreads();
-
-    f32x16_t sc0, sc1;   // S(t)
-    QK_TILE(0, sc0, sc1)
-
-    // row max of a tile (query on the lane; partner half-wave holds the other 32 keys) -> MX_
-#define ROW_MAX(S0_, S1_, MX_)                                                                               \
-    {                                                                                                        \
-        float mx_ = fmaxf(fmaxf(S0_[0], S0_[1]), S0_[2]);                                                    \
-        _Pragma("unroll") for (int j = 3; j < 15; j += 2) mx_ = fmaxf(fmaxf(mx_, S0_[j]), S0_[j + 1]);       \
-        mx_ = fmaxf(fmaxf(mx_, S0_[15]), S1_[0]);                                                            \
-        _Pragma("unroll") for (int j = 1; j < 15; j += 2) mx_ = fmaxf(fmaxf(mx_, S1_[j]), S1_[j + 1]);       \
-        mx_ = fmaxf(mx_, S1_[15]);                                                                           \
-        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_), __float_as_uint(mx_), false, false); \
-        MX_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                       \
-    }
-    // deferred rescale (T13): move the running max only when it grew by more than rescale_thr<T>() (log2 units).  O, l
-    // and m move together and only BETWEEN tiles (all of the previous tile's P.V is in O, no P of the next exists).
-    // Rows beyond lk in a ragged last tile are clamped copies of key lk-1, so the max over the padded tile is the
-    // max over the valid keys.
-#define MAYBE_RESCALE(MX_)                                                                                   \
-    {                                                                                                        \
-        const float m_cand_ = fmaxf(m_run, (MX_) * c2);                                                      \
-        if (__any((m_cand_ - m_run) > rescale_thr<T>())) {                                                        \
-            const float alpha_ = __builtin_amdgcn_exp2f(m_run - m_cand_);                                    \
-            m_run = m_cand_;                                                                                 \
-            l_run *= alpha_;                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < kDT; ++i)                                                  \
-                _Pragma("unroll") for (int j = 0; j < 16; ++j) o[i][j] *= alpha_;                            \
-        }                                                                                                    \
-    }
-    {
-        float mx0;
-        ROW_MAX(sc0, sc1, mx0)
-        MAYBE_RESCALE(mx0)
-    }
-
-    // One tile of the pipeline.  HAS_NEXT_: S(t+1) is issued (every tile but the last); LAST_: ragged-tail mask.
-#define TILE_BODY(HAS_NEXT_, LAST_)                                                                          \
-    {                                                                                                        \
-        const int cur = t & 1;                                                                               \
-        ASTAMP(ts0)                                                                                          \
-        /* global -> registers: K(t+2), V(t+1) (clamped rows; dead data is never written to LDS) */          \
-        if (HAS_NEXT_) {                                                                            \
-            _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i) {                                    \
-                int rk = (t + 2) * kKV + st_row[i];                                                          \
-                int rv = (t + 1) * kKV + st_row[i];                                                          \
-                rk = rk < lk ? rk : lk - 1;                                                              \
-                rv = rv < lk ? rv : lk - 1;                                                              \
-                kreg[i] = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)rk * p.k_rs + st_ch[i] * 8);      \
-                vreg[i] = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)rv * p.v_rs + st_ch[i] * 8);      \
-            }                                                                                                \
-        }                                                                                                    \
-        /* matrix pipe: S(t+1) = K(t+1).Q^T   ||   VALU: P(t) = exp2(c.S(t) - m), row sums */                \
-        f32x16_t sn0, sn1;                                                                                   \
-        if (HAS_NEXT_) QK_TILE(cur ^ 1, sn0, sn1)                                                            \
-        float psum0 = 0.f, psum1 = 0.f;                                                                      \
-        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                     \
-            sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);                                            \
-            sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);                                            \
-        }                                                                                                    \
-        if (LAST_ && (lk & (kKV - 1))) { /* key = (j&3) + 8*(j>>2) + 4*h (+32) */                          \
-            const int kbase = t * kKV + 4 * h;                                                               \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                 \
-                const int key = kbase + (j & 3) + 8 * (j >> 2);                                              \
-                if (key >= lk) sc0[j] = 0.f;                                                               \
-                if (key + 32 >= lk) sc1[j] = 0.f;                                                          \
-            }                                                                                                \
-        }                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                     \
-            psum0 += sc0[j];                                                                                 \
-            psum1 += sc1[j];                                                                                 \
-        }                                                                                                    \
-        l_run += psum0 + psum1;                                                                              \
-        ASTAMP(ts1)                                                                                          \
-        /* matrix pipe: O^T += V(t)^T . P(t)^T   ||   VALU: bf16 packing, row max of S(t+1) */               \
-        const char* vb = smem + (2 + cur) * kTileBytes;                                                      \
-        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                   \
-            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                               \
-                vec8 pb;                                                                                     \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                              \
-                    const float pv = kt == 0 ? sc0[8 * s2 + j] : sc1[8 * s2 + j];                            \
-                    pb[j] = (typename T::scalar)pv;                                                          \
-                }                                                                                            \
-                const int key0 = kt * 32 + 16 * s2 + 4 * h + tq;                                             \
-                _Pragma("unroll") for (int dt = 0; dt < kDT; ++dt) {                                         \
-                    const int ch = dt * 4 + 2 * g1 + (tp >> 1);                                              \
-                    const int a_lo = lds_off<D>(key0, ch) + 8 * (tp & 1);                                    \
-                    const int a_hi = lds_off<D>(key0 + 8, ch) + 8 * (tp & 1);                                \
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_lo)); \
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FINO_LDS s16x4_t*)(vb + a_hi)); \
-                    const s16x8_t va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);              \
-                    o[dt] = T::mfma32(__builtin_bit_cast(vec8, va), pb, o[dt]);                              \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-        if (HAS_NEXT_) {                                                                                     \
-            float mxn;                                                                                       \
-            ROW_MAX(sn0, sn1, mxn)                                                                           \
-            ASTAMP(ts2)                                                                                      \
-            /* registers -> LDS: K(t+2) into the K slot S(t) came from, V(t+1) into the other V slot */      \
-            if (t + 2 < nt) {                                                                       \
-                _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                  \
-                    *reinterpret_cast<u32x4_t*>(smem + cur * kTileBytes + st_off[i]) = kreg[i];              \
-            }                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < kLoadsPerThread; ++i)                                      \
-                *reinterpret_cast<u32x4_t*>(smem + (2 + (cur ^ 1)) * kTileBytes + st_off[i]) = vreg[i];      \
-            sc0 = sn0;                                                                                       \
-            sc1 = sn1;                                                                                       \
-            MAYBE_RESCALE(mxn)                                                                               \
-            ASTAMP(ts3)                                                                                      \
-            __syncthreads();                                                                                 \
-            ASTAMP(ts4)                                                                                      \
-            ASTAMP_ACC                                                                                       \
-        }                                                                                                    \
-    }
-
-    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-#ifdef FINO_ATTN_STAMP
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
-#define ASTAMP_ACC { sa0 += ts1 - ts0; sa1 += ts2 - ts1; sa2 += ts3 - ts2; sa3 += ts4 - ts3; }
-#else
-#define ASTAMP_ACC
-#endif
-    int t = 0;
-    for (; t < nt - 1; ++t) TILE_BODY(true, false)
-    TILE_BODY(false, true)
-#ifdef FINO_ATTN_STAMP
-    if (blockIdx.x == 40 && lane == 0 && VAR == 0) {
-        fino_attn_dbg[wave * 8 + 0] = sa0; fino_attn_dbg[wave * 8 + 1] = sa1; fino_attn_dbg[wave * 8 + 2] = sa2;
-        fino_attn_dbg[wave * 8 + 3] = sa3; fino_attn_dbg[wave * 8 + 4] = (unsigned long long)(nt - 1);
-    }
-#endif
-#undef TILE_BODY
-#undef ROW_MAX
-#undef MAYBE_RESCALE
-#undef QK_TILE
-
-    // ---------------- epilogue: normalise, store O[q][d] ----------------
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    if (part >= 0) {
-        // partial: raw accumulators in thread order (coalesced), m and l per thread; attn_combine_kernel finishes
-        float* w = p.ws + (int64_t)part * partial_floats<D>();
-#pragma unroll
-        for (int dt = 0; dt < kDT; ++dt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) w[(dt * 16 + j) * (kWaves * 64) + tid] = o[dt][j];
-        w[kDT * 16 * (kWaves * 64) + tid] = m_run;
-        w[kDT * 16 * (kWaves * 64) + kWaves * 64 + tid] = l_run;
-        continue;
-    }
-    const float inv = 1.0f / l_run;
-    if (qrow < p.lq) {
-        uint16_t* orow = op + (int64_t)qrow * p.o_rs;
-#pragma unroll
-        for (int dt = 0; dt < kDT; ++dt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dt * 32 + 8 * g + 4 * h;
-                uint32_t w0 = (uint32_t)T::from_f32(o[dt][4 * g + 0] * inv) |
-                              ((uint32_t)T::from_f32(o[dt][4 * g + 1] * inv) << 16);
-                uint32_t w1 = (uint32_t)T::from_f32(o[dt][4 * g + 2] * inv) |
-                              ((uint32_t)T::from_f32(o[dt][4 * g + 3] * inv) << 16);
-                *reinterpret_cast<uint2*>(orow + d0) = make_uint2(w0, w1);
-            }
-        }
-    }
-  }   // piece
-}
-
 template <typename T, int D, int VAR>
 __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -467,7 +158,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_pp_kernel(const AttnParam
         *reinterpret_cast<u32x4_t*>(smem + (2 + ((W_) & 1)) * kTileBytes + st_off[i_]) = vreg[i_];         \
     }
 
-    // ---- per-lane LDS read addressing (as attn_fwd_kernel) ----
+    // ---- per-lane LDS read addressing ----
     const int tq = (lane & 15) >> 2;
     const int tp = lane & 3;
     const int g1 = (lane >> 4) & 1;
@@ -2100,10 +1791,6 @@ int launch_attn_ppw(AttnParams p, hipStream_t st) {
 template <typename T, int D, int VAR>
 int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     constexpr int smem = 4 * kKV * D * 2;
-    static const bool pingpong = [] {
-        const char* ev = getenv("FINO_ATTN_PP");          // A/B knob: 0 selects the one-barrier loop
-        return !(ev && ev[0] == '0') && kWaves == 8;
-    }();
     // the free-running kernel (two workgroups of 4 waves per CU): FINO_TUNE_ATTN_KERNEL = 3, and by default for the short key
     // sequences of the text cross-attention at head_dim 128 (whole blocks only: never for fino_attn_partial)
     {
@@ -2120,11 +1807,11 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
                              span(p.v_bs, p.v_hs, p.v_rs, p.lk) < (1ll << 31) && span(p.o_bs, p.o_hs, p.o_rs, p.lq) < (1ll << 31);
             if (can && (tk == 6 || (tk == 0 && VAR == 1 && blocks >= 2 * device_cus()))) return launch_attn_ppw<T>(p, st);
         }
-        if (!p.all_partial && (tk == 3 || ((tk == 0 || tk == 5 || tk == 7) && VAR == 1 && D == 128))) return launch_attn_fr<T, D>(p, st);
+        // the free-running kernel exists for head_dim 128 only (at head_dim 64 it lost to the 4-wave kernel and left in round 5)
+        if constexpr (D == 128)
+            if (!p.all_partial && (tk == 3 || ((tk == 0 || tk == 5 || tk == 7) && VAR == 1))) return launch_attn_fr<T, D>(p, st);
     }
-    static FinoPerDeviceOnce once_a, once_b;
-    if (int rc = fino_max_smem_once(once_a, reinterpret_cast<const void*>(&attn_fwd_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
-        return rc;
+    static FinoPerDeviceOnce once_b;
     if (int rc = fino_max_smem_once(once_b, reinterpret_cast<const void*>(&attn_pp_kernel<T, D, VAR>), smem, "fino_attn_fwd"))
         return rc;
     attn_virtual_heads(p.batch, p.heads, p.nqb, p.vsplit, p.nqb_v);
@@ -2153,7 +1840,7 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
     const bool w4 = fino_attn_w4_supports(D, p.scale_log2) &&
                     (tune_k == 2 || (tune_k == 0 && D == 64 && p.scale_log2 == 1.0f && p.lk >= 2048));
     // 5: the round-3 policy (register-staged).  head_dim 64: the LDS-DMA-staged kernel by tune 4 (the policy there: below)
-    const bool ppd = pingpong && (tune_k == 4 || (D == 128 && (tune_k == 0 || tune_k == 7) && VAR == 0));
+    const bool ppd = tune_k == 4 || (D == 128 && (tune_k == 0 || tune_k == 7) && VAR == 0);
     if (w4) {
         if (int rc = fino_attn_launch_w4(p, T::kId, D, st)) return rc;
     } else if (ppd) {
@@ -2162,10 +1849,8 @@ int launch_attn_v(AttnParams p, int64_t ws_bytes, hipStream_t st) {
         if (int rc = fino_max_smem_once(once_d, reinterpret_cast<const void*>(&attn_ppd_kernel<T, D, VAR>), smem_d, "fino_attn_fwd"))
             return rc;
         attn_ppd_kernel<T, D, VAR><<<grid, kWaves * 64, smem_d, st>>>(p);
-    } else if (pingpong)
+    } else
         attn_pp_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
-    else
-        attn_fwd_kernel<T, D, VAR><<<grid, kWaves * 64, smem, st>>>(p);
     FINO_LAUNCH_CHECK();
     if (sp.rem_x > 0) {
         attn_combine_kernel<T, D><<<dim3((unsigned)(8 * sp.rem_x), (unsigned)(D / 32)), kWaves * 64, 0, st>>>(p);

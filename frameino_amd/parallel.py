@@ -281,6 +281,9 @@ class ParallelPlan:
                 sh.head_groups = 1
                 sh.fused_qkv = True
                 sh.gemm_tile_m = 8
+                # two kernel streams already put one branch's attention under the other's gather: head groups add 2.3 ms of
+                # launches per step there and hide nothing more (tools/plan_sim.py with a modelled wire, profiles/r05_plan_sim*)
+                sh.kv_head_groups = 1
         self._buf = None
 
     def with_exchange(self, exchange):

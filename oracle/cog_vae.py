@@ -24,6 +24,11 @@ UNPINNED** (no golden vector can exist offline).  What is restated:
     batch, conv caches carried across batches).  GroupNorm statistics are therefore per frame batch: results depend
     on the batching, which is reproduced here.
 
+  * TILING (`enable_tiling()`; round 5): `tiled_encode` / `tiled_decode` -- overlapping spatial tiles of half the config's
+    sample size, overlap factors 1/6 and 1/5, every tile with its own frame batches and conv caches, `blend_v` / `blend_h`
+    (the same loops as the in-tree Wan VAE's, architecture/autoencoder_kl_wan.py:1254-1268) -- restated from the library's
+    documented behaviour like everything else here: parity UNPINNED.
+
 State-dict keys are diffusers' parameter names (`encoder.down_blocks.0.resnets.0.conv1.conv.weight`, ...)."""
 import torch
 import torch.nn.functional as F
@@ -175,6 +180,100 @@ def decode(sd, cfg, z, latent_batch=2):
         y, caches = decoder(sd, cfg, z[:, :, s:e], caches)
         outs.append(y)
     return torch.cat(outs, dim=2)
+
+
+# ------------------------------------------------------------------------------------------------ tiling (enable_tiling)
+def tiling_params(cfg, tile_sample_min_height=None, tile_sample_min_width=None, tile_overlap_factor_height=None,
+                  tile_overlap_factor_width=None):
+    """diffusers' `AutoencoderKLCogVideoX.__init__` / `enable_tiling` bookkeeping: the minimum tile is HALF the sample size the
+    config names (480 x 720 -> 240 x 360), its latent size that divided by 2^(blocks - 1); overlap factors 1/6 (height) and 1/5
+    (width).  The canonical CogVideoX caller switches it on (reference test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96)."""
+    sh = tile_sample_min_height or cfg.get("sample_height", 480) // 2
+    sw = tile_sample_min_width or cfg.get("sample_width", 720) // 2
+    down = 2 ** (len(cfg["block_out_channels"]) - 1)
+    return dict(sample_h=sh, sample_w=sw, latent_h=int(sh / down), latent_w=int(sw / down),
+                of_h=tile_overlap_factor_height or 1 / 6, of_w=tile_overlap_factor_width or 1 / 5)
+
+
+def blend_v(a, b, blend_extent):
+    """the loop of diffusers' blend_v (identical to the in-tree architecture/autoencoder_kl_wan.py:1254-1260), in place on b"""
+    blend_extent = min(a.shape[3], b.shape[3], blend_extent)
+    for y in range(blend_extent):
+        b[:, :, :, y, :] = a[:, :, :, -blend_extent + y, :] * (1 - y / blend_extent) + b[:, :, :, y, :] * (y / blend_extent)
+    return b
+
+
+def blend_h(a, b, blend_extent):
+    """... and blend_h (:1262-1268)"""
+    blend_extent = min(a.shape[4], b.shape[4], blend_extent)
+    for x in range(blend_extent):
+        b[:, :, :, :, x] = a[:, :, :, :, -blend_extent + x] * (1 - x / blend_extent) + b[:, :, :, :, x] * (x / blend_extent)
+    return b
+
+
+def _blend_rows(rows, blend_h_extent, blend_w_extent, limit_h, limit_w):
+    """the second half of tiled_encode / tiled_decode: every tile blended IN PLACE with its upper and left neighbour (which have
+    been blended already: row-major order), cropped to the stride, concatenated"""
+    result_rows = []
+    for i, row in enumerate(rows):
+        result_row = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = blend_v(rows[i - 1][j], tile, blend_h_extent)
+            if j > 0:
+                tile = blend_h(row[j - 1], tile, blend_w_extent)
+            result_row.append(tile[:, :, :, :limit_h, :limit_w])
+        result_rows.append(torch.cat(result_row, dim=4))
+    return torch.cat(result_rows, dim=3)
+
+
+def tiled_encode_moments(sd, cfg, x, tp=None, sample_batch=8):
+    """AutoencoderKLCogVideoX.tiled_encode: overlapping spatial tiles, each walked in the frame batches of `_encode` with its own
+    conv caches, blended over the overlap.  (`_encode` takes this path when tiling is on and the frame is larger than a tile.)"""
+    tp = tp or tiling_params(cfg)
+    height, width = x.shape[3], x.shape[4]
+    overlap_h, overlap_w = int(tp["sample_h"] * (1 - tp["of_h"])), int(tp["sample_w"] * (1 - tp["of_w"]))
+    blend_eh, blend_ew = int(tp["latent_h"] * tp["of_h"]), int(tp["latent_w"] * tp["of_w"])
+    limit_h, limit_w = tp["latent_h"] - blend_eh, tp["latent_w"] - blend_ew
+    rows = []
+    for i in range(0, height, overlap_h):
+        row = []
+        for j in range(0, width, overlap_w):
+            caches, outs = {}, []
+            for s, e in frame_batches(x.shape[2], sample_batch):
+                y, caches = encoder(sd, cfg, x[:, :, s:e, i:i + tp["sample_h"], j:j + tp["sample_w"]], caches)
+                outs.append(y)
+            row.append(torch.cat(outs, dim=2))
+        rows.append(row)
+    return _blend_rows(rows, blend_eh, blend_ew, limit_h, limit_w)
+
+
+def tiled_decode(sd, cfg, z, tp=None, latent_batch=2):
+    """AutoencoderKLCogVideoX.tiled_decode"""
+    tp = tp or tiling_params(cfg)
+    height, width = z.shape[3], z.shape[4]
+    overlap_h, overlap_w = int(tp["latent_h"] * (1 - tp["of_h"])), int(tp["latent_w"] * (1 - tp["of_w"]))
+    blend_eh, blend_ew = int(tp["sample_h"] * tp["of_h"]), int(tp["sample_w"] * tp["of_w"])
+    limit_h, limit_w = tp["sample_h"] - blend_eh, tp["sample_w"] - blend_ew
+    rows = []
+    for i in range(0, height, overlap_h):
+        row = []
+        for j in range(0, width, overlap_w):
+            caches, outs = {}, []
+            for s, e in frame_batches(z.shape[2], latent_batch):
+                y, caches = decoder(sd, cfg, z[:, :, s:e, i:i + tp["latent_h"], j:j + tp["latent_w"]], caches)
+                outs.append(y)
+            row.append(torch.cat(outs, dim=2))
+        rows.append(row)
+    return _blend_rows(rows, blend_eh, blend_ew, limit_h, limit_w)
+
+
+def uses_tiling_encode(x, tp):
+    return x.shape[4] > tp["sample_w"] or x.shape[3] > tp["sample_h"]
+
+
+def uses_tiling_decode(z, tp):
+    return z.shape[4] > tp["latent_w"] or z.shape[3] > tp["latent_h"]
 
 
 # ------------------------------------------------------------------------------------------------ shapes / random weights

@@ -64,6 +64,64 @@ def test_decode_vs_oracle(latent_frames):
     assert r < 4e-2 and p > 35.0, (r, p)
 
 
+def test_blend_tiles_kernel_vs_the_reference_loops():
+    """fino_vae_blend_tiles against the blend_v / blend_h loops (oracle/cog_vae.py = the in-tree
+    architecture/autoencoder_kl_wan.py:1254-1268) run on bf16 tensors: same rounding points -> bit-equal; extent clamped to both
+    tiles like `min(a.shape, b.shape, blend_extent)`."""
+    from frameino_amd import ops
+    from oracle import cog_vae as V
+    g = torch.Generator().manual_seed(4)
+    for (ha, wa, hb, wb, extent, axis) in ((6, 5, 6, 5, 2, 0), (6, 5, 2, 5, 4, 0), (6, 5, 6, 3, 3, 1), (6, 5, 6, 5, 1, 1),
+                                           (30, 45, 10, 45, 5, 0)):
+        a = torch.randn(3, ha, wa, 64, generator=g).bfloat16().to(DEV)
+        b = torch.randn(3, hb, wb, 64, generator=g).bfloat16().to(DEV)
+        # the oracle's loops take [B, C, T, H, W]
+        a5, b5 = a.permute(3, 0, 1, 2)[None].clone(), b.permute(3, 0, 1, 2)[None].clone()
+        ref = (V.blend_v if axis == 0 else V.blend_h)(a5, b5, extent)[0].permute(1, 2, 3, 0)
+        got = ops.vae_blend_tiles_(a, b.clone(), extent, axis)
+        assert torch.equal(got, ref.contiguous()), (ha, wa, hb, wb, extent, axis)
+
+
+@pytest.mark.parametrize("frames,hw", [(9, (96, 120)), (17, (96, 80)), (1, (48, 120))])
+def test_tiled_encode_and_decode_vs_oracle_tiling(frames, hw):
+    """`enable_tiling()` (reference test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96): overlapping tiles, every tile its own
+    frame batches and conv caches, blend_v / blend_h over the overlap -- HIP vs the oracle's restatement of diffusers'
+    tiled_encode / tiled_decode on the tiny VAE with small tiles (48 x 40 sample / 6 x 5 latent: 3 x 4 tiles at 96 x 120 incl. ragged
+    edge tiles).  Third-party algorithm: parity UNPINNED.  Tiled and un-tiled results differ (that is why the switch matters)."""
+    from oracle import cog_vae as V
+    vae, sd = _vae(3)
+    vae.enable_tiling(tile_sample_min_height=48, tile_sample_min_width=40)
+    tp = V.tiling_params(TINY, 48, 40)
+    assert (vae.tile_latent_min_height, vae.tile_latent_min_width) == (tp["latent_h"], tp["latent_w"]) == (6, 5)
+    g = torch.Generator().manual_seed(frames)
+    h, w = hw
+    x = torch.rand(1, 3, frames, h, w, generator=g) * 2 - 1
+    assert V.uses_tiling_encode(x, tp)
+    ref = V.tiled_encode_moments(sd, TINY, x, tp)
+    plain = V.encode_moments(sd, TINY, x)
+    out = vae.encode(x.to(DEV)).latent_dist.parameters
+    assert out.shape == ref.shape == plain.shape
+    r, r_plain = rel_rms(out, ref), rel_rms(plain, ref)
+    print(f"tiled encode {frames} f {h}x{w}: rel-RMS vs oracle tiling {r:.4f} (un-tiled oracle vs tiled oracle: {r_plain:.3f})")
+    assert r < 3e-2 and r_plain > 3 * r, (r, r_plain)
+    nl = 1 + (frames - 1) // 4
+    z = torch.randn(1, 4, nl, h // 8, w // 8, generator=g)
+    refd = V.tiled_decode(sd, TINY, z, tp)
+    plaind = V.decode(sd, TINY, z)
+    outd = vae.decode(z.to(DEV)).sample
+    assert outd.shape == refd.shape == (1, 3, frames, h, w)
+    rd, rd_plain = rel_rms(outd, refd), rel_rms(plaind, refd)
+    p = _psnr(outd, refd, peak=float(refd.abs().max()) * 2)
+    print(f"tiled decode -> {frames} f: rel-RMS {rd:.4f}, PSNR {p:.1f} dB (un-tiled vs tiled oracle: {rd_plain:.3f})")
+    assert rd < 4e-2 and p > 35.0 and rd_plain > 3 * rd, (rd, p, rd_plain)
+    # frames no larger than a tile take the un-tiled path, like `_encode` / `_decode`
+    xs = torch.rand(1, 3, 1, 48, 40, generator=g) * 2 - 1
+    assert not V.uses_tiling_encode(xs, tp)
+    assert rel_rms(vae.encode(xs.to(DEV)).latent_dist.parameters, V.encode_moments(sd, TINY, xs)) < 3e-2
+    vae.disable_tiling()
+    assert rel_rms(vae.encode(x.to(DEV)).latent_dist.parameters, plain) < 3e-2
+
+
 def test_groupnorm_kernel_vs_torch():
     """fino_groupnorm_cl vs F.group_norm (+ the SpatialNorm modulation through F.interpolate's nearest map, + SiLU),
     odd batch (first frame mapped on its own) and even batch."""

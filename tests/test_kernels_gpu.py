@@ -610,7 +610,7 @@ def test_rmsnorm_rope_scatter_equals_inplace_kernel_plus_permute_copy(ways, grou
 
 
 @pytest.mark.parametrize("b,heads,lq,lk,dh", [(2, 24, 1000, 512, 128), (1, 3, 300, 77, 128), (2, 2, 129, 1024, 128),
-                                              (1, 4, 513, 640, 64), (1, 24, 3080, 12320, 128)])
+                                              (1, 24, 3080, 12320, 128)])      # (head_dim 128 only since round 5)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_free_running_attention_kernel_equals_the_ping_pong_kernel(b, heads, lq, lk, dh, dtype):
     """attn_fr_kernel (4 waves, two workgroups per CU, LDS-DMA staging; FINO_TUNE_ATTN_KERNEL = 3, the default for the text

@@ -273,20 +273,25 @@ def test_fp32_compute_mode_tiny_vae_vs_reference_golden(golden):
     vae, a = _vae(golden, "wan_vae_tiny")
     vae.set_compute_dtype(torch.float32)
     assert vae.compute_dtype == torch.float32
-    worst_d = worst_e = 0.0
+    worst_d = worst_e = worst_dr = 0.0
     for nl in (1, 2, 3):
         out = vae.decode(a[f"dec_in_{nl}"].to(DEV), return_dict=False)[0]
         ref = a[f"dec_out_{nl}"]
         assert out.shape == ref.shape and out.dtype == torch.float32
         worst_d = max(worst_d, (out.cpu() - ref).abs().max().item())
+        worst_dr = max(worst_dr, rel_rms(out, ref))
     for nf in (1, 5, 9):
         post = vae.encode(a[f"enc_in_{nf}"].to(DEV)).latent_dist
         ref = a[f"enc_out_{nf}"]
         assert post.parameters.shape == ref.shape
         worst_e = max(worst_e, rel_rms(post.parameters, ref))
-    record("wan_vae_tiny_fp32_compute[decode]", "max-abs vs the reference's fp32 streaming decode (video in [-1, 1])", worst_d, 1e-5)
+    # (2e-5 max-abs is the bar the fp32 ORACLE is held to against the same fixture, tests/test_oracle_golden.py: two fp32
+    # evaluations of one network in different summation orders)
+    record("wan_vae_tiny_fp32_compute[decode]", f"max-abs vs the reference's fp32 streaming decode (video in [-1, 1]; rel_rms "
+           f"{worst_dr:.2e})", worst_d, 2e-5)
+    record("wan_vae_tiny_fp32_compute[decode rel_rms]", "rel_rms vs the reference's fp32 streaming decode", worst_dr, 1e-5)
     record("wan_vae_tiny_fp32_compute[encode]", "rel_rms of the moments vs the reference's fp32 streaming encode", worst_e, 1e-5)
-    assert worst_d < 1e-5 and worst_e < 1e-5, (worst_d, worst_e)
+    assert worst_d < 2e-5 and worst_dr < 1e-5 and worst_e < 1e-5, (worst_d, worst_dr, worst_e)
     # ... and the time-chunked tail stays bit-identical in this mode too
     vae.decode_chunk_frames = 0
     z = a["dec_in_3"].to(DEV)

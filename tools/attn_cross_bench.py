@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Text cross-attention at the bench shape (B = 2, Lq = 12320, Lk = 512, 24 heads x 128): median us per launch and TFLOP/s.
-FINO_ATTN_PP=0 selects the one-barrier loop (read once at library load: one process per setting)."""
+(the one-barrier loop FINO_ATTN_PP=0 used to select left the library in round 5)."""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,4 +20,4 @@ for _ in range(7):
     for _ in range(10): f()
     e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e) / 10 * 1e3)
 us = statistics.median(ts)
-print(f"cross-attention Lq {lq} x Lk {lk}, B {b}: {us:7.1f} us  {4.0 * b * lq * lk * d / us / 1e6:6.0f} TFLOP/s  (FINO_ATTN_PP={os.environ.get('FINO_ATTN_PP', '1')})")
+print(f"cross-attention Lq {lq} x Lk {lk}, B {b}: {us:7.1f} us  {4.0 * b * lq * lk * d / us / 1e6:6.0f} TFLOP/s")

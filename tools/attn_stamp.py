@@ -22,7 +22,4 @@ for wv in range(8):
     if KERNEL == 4:
         print(f"wave {wv}: per tile cycles: softmax {v[0]/nt:6.0f} (to its last arithmetic {v[6]/nt:5.0f})  barrier {v[1]/nt:6.0f}  matrix {v[2]/nt:6.0f} = S {v[5]/nt:5.0f} + P.V {(v[2]-v[5])/nt:5.0f}  barrier {v[3]/nt:6.0f}  total {sum(v[:4])/nt:6.0f}")
         continue
-    if os.environ.get("FINO_ATTN_PP", "1") != "0":
-        print(f"wave {wv}: per tile cycles: softmax {v[0]/nt:6.0f}  barrier {v[1]/nt:6.0f}  matrix {v[2]/nt:6.0f}  barrier {v[3]/nt:6.0f}  total {sum(v[:4])/nt:6.0f} | softmax = staging {v[5]/nt:5.0f} + max/rescale {v[6]/nt:5.0f} + exp {v[7]/nt:5.0f} + sum/pack {(v[0]-v[5]-v[6]-v[7])/nt:5.0f}")
-        continue
-    print(f"wave {wv}: per tile cycles: QK(t+1)||exp {v[0]/nt:6.0f}  PV||cvt,max {v[1]/nt:6.0f}  ds_write+rescale {v[2]/nt:6.0f}  barrier {v[3]/nt:6.0f}  total {sum(v[:4])/nt:6.0f}")
+    print(f"wave {wv}: per tile cycles: softmax {v[0]/nt:6.0f}  barrier {v[1]/nt:6.0f}  matrix {v[2]/nt:6.0f}  barrier {v[3]/nt:6.0f}  total {sum(v[:4])/nt:6.0f} | softmax = staging {v[5]/nt:5.0f} + max/rescale {v[6]/nt:5.0f} + exp {v[7]/nt:5.0f} + sum/pack {(v[0]-v[5]-v[6]-v[7])/nt:5.0f}")

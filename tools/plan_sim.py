@@ -169,6 +169,7 @@ def main():
             for sh in pipe.parallel.shards:
                 sh.head_groups = 1
                 sh.fused_qkv = not os.environ.get("FINO_PLAN_SIM_NO_FUSED_QKV")      # as ParallelPlan sets it
+                sh.kv_head_groups = int(os.environ.get("FINO_PLAN_SIM_KV_GROUPS", "1"))
             model.parallel = pipe.parallel.shards[0]
         else:
             pipe.parallel = SimpleNamespace(interleave=False, cfg_ways=2, cfg_idx=0, token_ways=ways,
@@ -192,6 +193,7 @@ def main():
         set_tiling(True)
         for sh in pipe.parallel.shards:
             sh.fused_qkv = True                 # as ParallelPlan sets it for the interleaved plan
+            sh.kv_head_groups = int(os.environ.get("FINO_PLAN_SIM_KV_GROUPS", "1"))
         model.parallel = pipe.parallel.shards[0]
         print(f"interleave N={ways}: 2 branches x token{ways}: {timed():.1f} ms/step of GPU work per rank (host enqueue {host_ms[0]:.1f} ms){graph_txt[0]}")
     # the same plans with the heads exchange (all-to-all instead of the K|V all-gather; attention over H/ways heads x all tokens)
