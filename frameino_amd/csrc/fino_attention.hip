@@ -646,9 +646,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 
     u32x4_t ka[3][2];
     s16x4_t vlo[2][kDT], vhi[2][kDT];
-#ifdef PD_X_NOREAD       /* timing experiment (wrong results): the matrix phase without its LDS reads */
-#define PD_KISSUE(KS_, B_) { asm volatile("" : "=v"(ka[B_][0]), "=v"(ka[B_][1])); __builtin_amdgcn_sched_barrier(0); }
-#else
 #define PD_KISSUE(KS_, B_)                                                                                   \
     {                                                                                                        \
         const uint32_t a_ = ka0 ^ ((KS_) << 5);                                                              \
@@ -656,31 +653,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
                      : "=&v"(ka[B_][0]), "=&v"(ka[B_][1]) : "v"(a_), "n"(32 * D * 2));                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
-#endif
 #define PD_KWAIT(N_, B_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(ka[B_][0]), "+v"(ka[B_][1]));
     // one MFMA, then the reads its 32 cycles shadow -- an in-order wave issues nothing while its MFMA waits for the
     // pipe, so reads queued behind a run of MFMAs start late and the next run waits for them
-    // timing experiments (wrong results): PD_X_AOP 1 = the A operand of every MFMA is one fixed register set (reads kept: what
-    // the operands' bit flips cost), 2 = it rotates through the Q / P registers (with PD_X_NOREAD: what the reads cost)
-#if defined(PD_X_AOP) && PD_X_AOP == 1
-#define PD_A_S(KS_, B_, H_) qf[0]
-#define PD_A_V(STEP_, B_, DT_) qf[0]
-#elif defined(PD_X_AOP) && PD_X_AOP == 2
-#define PD_A_S(KS_, B_, H_) qf[((KS_) + 1 + 3 * (H_)) % kKS]
-#define PD_A_V(STEP_, B_, DT_) pb[((STEP_) + (DT_) + 1) % 4]
-#else
 #define PD_A_S(KS_, B_, H_) __builtin_bit_cast(vec8, ka[B_][H_])
 #define PD_A_V(STEP_, B_, DT_) __builtin_bit_cast(vec8, __builtin_shufflevector(vlo[B_][DT_], vhi[B_][DT_], 0, 1, 2, 3, 4, 5, 6, 7))
-#endif
 #define PD_MF0(KS_, B_, FIRST_)                                                                              \
     sc0 = T::mfma32(PD_A_S(KS_, B_, 0), qf[KS_], (FIRST_) ? zero16 : sc0);                                   \
     __builtin_amdgcn_sched_barrier(0);
 #define PD_MF1(KS_, B_, FIRST_)                                                                              \
     sc1 = T::mfma32(PD_A_S(KS_, B_, 1), qf[KS_], (FIRST_) ? zero16 : sc1);                                   \
     __builtin_amdgcn_sched_barrier(0);
-#ifdef PD_X_NOREAD
-#define PD_VPAIR(STEP_, B_, DT_) { asm volatile("" : "=v"(vlo[B_][DT_]), "=v"(vhi[B_][DT_])); __builtin_amdgcn_sched_barrier(0); }
-#else
 #define PD_VPAIR(STEP_, B_, DT_)                                                                             \
     {                                                                                                        \
         const uint32_t l_ = vl0 ^ ((DT_) << 6), h_ = vh0 ^ ((DT_) << 6);                                     \
@@ -688,7 +671,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
                      : "=&v"(vlo[B_][DT_]), "=&v"(vhi[B_][DT_]) : "v"(l_), "v"(h_), "n"((STEP_) * 16 * D * 2)); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
-#endif
 #define PD_VW(N_, B_, DT_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(vlo[B_][DT_]), "+v"(vhi[B_][DT_]));
 #define PD_MFV(STEP_, B_, DT_)                                                                               \
     {                                                                                                        \
@@ -718,10 +700,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         ASTAMP(ts0)
         // ================= softmax phase =================
         const int w = t + grp;
-#ifndef PD_X_NODMA       /* timing experiment (wrong results): no K / V staging at all after the prologue */
         PD_DMA_K(w + 3)
         PD_DMA_V(w + 2)
-#endif
 #if PD_MAX_SOFTMAX
         {
             MASK_RAGGED(t)
@@ -743,13 +723,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-#ifdef PD_X_NOEXP        /* timing experiment (wrong results): the softmax phase without its 32 exp2 */
-            sc0[j] = sc0[j] * c2 - m_run;
-            sc1[j] = sc1[j] * c2 - m_run;
-#else
             sc0[j] = __builtin_amdgcn_exp2f(sc0[j] * c2 - m_run);
             sc1[j] = __builtin_amdgcn_exp2f(sc1[j] * c2 - m_run);
-#endif
         }
         {
             float psum0 = 0.f, psum1 = 0.f;
@@ -1251,11 +1226,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnPara
         // Per phase, in issue order: 4 DMAs [+ 8 Q loads in a block's first phase] [+ 8 stores behind its last matrix phase].
         if (cp.lt == nt - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (cp.lt == 0 && cp.blk == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#ifdef PW_X_NOSTORE      /* timing experiment (wrong results): no output stores */
-        else if (cp.lt == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-#else
         else if (cp.lt == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-#endif
         else if (cp.lt == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1304,11 +1275,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppw_kernel(const AttnPara
             for (int k8 = 0; k8 < 8; ++k8) {
                 const int qrow = qrow0 + 4 * k8;
                 const uint32_t off = qrow < p.lq ? (uint32_t)((int64_t)qrow * p.o_rs * 2) + ocol : 0x80000000u;
-#ifdef PW_X_NOSTORE
-                asm volatile("" :: "v"(rows[k8]), "v"(off));
-#else
                 __builtin_amdgcn_raw_buffer_store_b128(rows[k8], o_rsrc, off, o_boff, 0);
-#endif
             }
 #pragma unroll
             for (int i = 0; i < kDT; ++i)

@@ -252,15 +252,7 @@ __device__ __forceinline__ void load_q_fp8(const AttnParams& p, const uint16_t* 
     }
 }
 
-#ifdef F8_X_STAMP   // s_memtime stamps around the segments of both phases (tools/attn_fp8_stamp.py; experiment build only)
-__device__ unsigned long long fino_attn_f8_dbg[64];
-extern "C" int fino_attn_f8_debug_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fino_attn_f8_dbg), sizeof(unsigned long long) * 64);
-}
-#define F8STAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
 #define F8STAMP(V_)
-#endif
 
 // max of the 16 registers of an S accumulator, ordered BEHIND the MFMA that produced `behind` (an input the asm never reads:
 // the data dependence is what keeps the compiler from hoisting the statement above that MFMA).  Plain fmaxf on MFMA results
@@ -451,14 +443,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
     float ex_next = 0.f;                      // max over the tile of (s - m_run): what may exceed 8
     if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one phase behind group 0 from here on
 
-#if defined(F8_X_NOBAR)
-#define F8_BARRIER() asm volatile("" ::: "memory")
-#else
 #define F8_BARRIER() __builtin_amdgcn_s_barrier()
-#endif
-#ifdef F8_X_STAMP
-    unsigned long long ts0 = 0, tsa = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa[6] = {0, 0, 0, 0, 0, 0};
-#endif
     for (int t = 0; t < nt; ++t) {
         F8STAMP(ts0)
         // ================= softmax phase =================
@@ -499,33 +484,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
             }
         }
         i32x8_t pf;
-#if defined(F8_X_NOEXP)                       // timing experiments (wrong results; fino_common.h ties them to FINO_EXPERIMENT)
-#define F8_EXP(X_) (X_)
-#define F8_P4(A_, B_, C_, D_) pack4_fp8(A_, B_, C_, D_)
-#else
 #define F8_EXP(X_) __builtin_amdgcn_exp2f(X_)
 #define F8_P4(A_, B_, C_, D_) p_bytes4<PX>(A_, B_, C_, D_)
-#endif
-#if defined(F8_X_NOPACK)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float e0 = F8_EXP(s0[4 * i]) + F8_EXP(s0[4 * i + 1]), e1 = F8_EXP(s0[4 * i + 2]) + F8_EXP(s0[4 * i + 3]);
-            float e2 = F8_EXP(s1[4 * i]) + F8_EXP(s1[4 * i + 1]), e3 = F8_EXP(s1[4 * i + 2]) + F8_EXP(s1[4 * i + 3]);
-            asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3));
-            pf[i] = 0x38383838; pf[4 + i] = 0x38383838;
-        }
-#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             pf[i] = (int)F8_P4(s0[4 * i], s0[4 * i + 1], s0[4 * i + 2], s0[4 * i + 3]);
             pf[4 + i] = (int)F8_P4(s1[4 * i], s1[4 * i + 1], s1[4 * i + 2], s1[4 * i + 3]);
         }
-#endif
 #undef F8_EXP
 #undef F8_P4
-#if !defined(F8_X_NOSTAGE)
         F8_DMA(t + 4)
-#endif
         {   // the softmax belongs to THIS phase: pin its results here (pure arithmetic otherwise sinks past the barrier)
             asm volatile("" : "+v"(pf));
         }
@@ -550,41 +518,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         {
             uint4 mn_u = make_uint4(g == 0 ? px_mneg_word<T, PX>(m_run) : 0u, 0u, 0u, 0u);
             const vec8 onesv = __builtin_bit_cast(vec8, ones_u), mnegv = __builtin_bit_cast(vec8, mn_u);
-#if defined(F8_X_NOOPENER)
-            asm volatile("" :: "v"(mnegv), "v"(onesv));
-            const f32x16_t c0 = zero16;
-#else
             const f32x16_t c0 = T::mfma32(onesv, mnegv, zero16);
-#endif
-#if !defined(F8_X_NOQK)
             F8_QK(c0, c0, s0, s1)
-#else
-            s0 = c0; s1 = c0;
-#endif
         }
 #define F8_PV(DT_)                                                                                           \
         {                                                                                                    \
             const i32x8_t vv_ = __builtin_shufflevector(vf0[DT_], vf1[DT_], 0, 1, 2, 3, 4, 5, 6, 7);         \
             o[DT_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv_, pf, o[DT_], 0, 0, 0, vsr[DT_], 0, kPs); \
         }
-#if defined(F8_X_NOPV)
-        asm volatile("" :: "v"(vf0[0]), "v"(vf1[0]), "v"(vf0[1]), "v"(vf1[1]), "v"(vsr[0]), "v"(vsr[1]), "v"(pf));
-        F8_MASK(t + 1, s0, s1)
-        float mxa = max16_behind(s0, s1[0]);
-        const float mxb = max16_behind(s1, mxa);
-#elif defined(F8_X_NOMAX)
-        F8_PV(0)
-        F8_PV(1)
-        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
-        float mxa = s0[0], mxb = s1[0];
-#else
         F8_PV(0)
         F8_MASK(t + 1, s0, s1)
         float mxa = max16_behind(s0, o[0][0]);          // behind P.V (d-tile 0): S0 was written back two MFMAs ago
         F8_PV(1)
         const float mxb = max16_behind(s1, o[1][0]);    // behind P.V (d-tile 1)
         lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
-#endif
         mxa = vmax2(mxa, mxb);
         F8_SWAPMAX(mxa, ex_next)
 #undef F8_PV
@@ -594,17 +541,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_fp8_kernel(const Fp8AttnP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         F8_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
-#ifdef F8_X_STAMP
-        F8STAMP(ts4)
-        sa[0] += tsa - ts0; sa[1] += ts1 - tsa; sa[2] += ts2 - ts1; sa[3] += ts3 - ts2; sa[4] += ts4 - ts3;
-#endif
     }
-#ifdef F8_X_STAMP
-    if (blockIdx.x == 40 && lane == 0) {
-        for (int i = 0; i < 5; ++i) fino_attn_f8_dbg[wave * 8 + i] = sa[i];
-        fino_attn_f8_dbg[wave * 8 + 5] = (unsigned long long)nt;
-    }
-#endif
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef F8_DMA
 #undef F8_PREFETCH_K
@@ -792,42 +729,13 @@ __global__ __launch_bounds__(kFrWaves * 64, 3) void attn_fp8_fr_kernel(const Fp8
             const i32x8_t vv_ = __builtin_shufflevector(vf0[DT_], vf1[DT_], 0, 1, 2, 3, 4, 5, 6, 7);         \
             o[DT_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vv_, pf, o[DT_], 0, 0, 0, vsr[DT_], 0, kPs); \
         }
-    // drop-one timing switches (WRONG results; -DFINO_EXPERIMENT only: tools/debug/attn_fp8_fr_dropone.sh)
-#if defined(FR_X_NODMA)
-#define FRX_DMA(U_)
-#else
 #define FRX_DMA(U_) FR_DMA(U_)
-#endif
-#if defined(FR_X_NOREAD)
-#define FRX_KREAD(SL_) if (t == 0) FR_KREAD(SL_)
-#else
 #define FRX_KREAD(SL_) FR_KREAD(SL_)
-#endif
-#if defined(FR_X_NOCVT)
-#define FRX_P4(A_, B_, C_, D_) (__float_as_uint(A_) & 0x38383838u)
-#else
 #define FRX_P4(A_, B_, C_, D_) p_bytes4<PX>(A_, B_, C_, D_)
-#endif
-#if defined(FR_X_NOMAX)
-#define FRX_MAX(S_, B_) (S_)[0]
-#else
 #define FRX_MAX(S_, B_) max16_behind(S_, B_)
-#endif
-#if defined(FR_X_NOLACC)
-#define FRX_LACC() asm volatile("" : "+v"(lacc) : "v"(pf));
-#else
 #define FRX_LACC() lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pf, lacc, 0, 0, 0, kOne, 0, kPs);
-#endif
-#if defined(FR_X_NOFOLD)
-#define FRX_FOLD(A_, B_) zero16; asm volatile("" :: "v"(A_), "v"(B_))
-#else
 #define FRX_FOLD(A_, B_) T::mfma32(A_, B_, zero16)
-#endif
-#if defined(FR_X_NOBAR)
-#define FRX_BARRIER() asm volatile("" ::: "memory")
-#else
 #define FRX_BARRIER() __builtin_amdgcn_s_barrier()
-#endif
 #define FR_TILE(T_, SI0_, SI1_, SO0_, SO1_)                                                                  \
     {                                                                                                        \
         const int t = (T_);                                                                                  \

@@ -310,13 +310,6 @@ void attn_w4_kernel(const AttnParams p) {
             psum0 += sa[0][kh][j];
         }
 
-#if defined(W4_X_PACKPERM)
-    uint32_t perm_sel = 0x07060302u;
-    asm volatile("" : "+v"(perm_sel));
-#elif defined(W4_X_PACKCONST)
-    float pk_c0 = 0.25f, pk_c1 = 0.5f;
-    asm volatile("" : "+v"(pk_c0), "+v"(pk_c1));
-#endif
     u32x4_t pb[2][4];              // P(t) packed bf16: pb[sub-block][2 * key half + (j >> 3)]
 
     // The fragment reads of the tile loop are inline asm with hand-counted lgkmcnt waits.  As compiler-visible loads
@@ -325,11 +318,7 @@ void attn_w4_kernel(const AttnParams p) {
     // of its own prefetch in every tile.  LDS returns data in order, so "lgkmcnt(n)" = all but the last n reads landed.
 #define W4_LD128(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_));
 #define W4_LDTR(DST_, ADDR_, OFF_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_));
-#ifdef W4_X_NOLGKM         /* timing experiment: no waits for LDS fragment reads (wrong results) */
-#define W4_WAIT_LGKM(N_)
-#else
 #define W4_WAIT_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory");
-#endif
     // loop-invariant fragment addresses: ring slots and the +32-row / +16-key-row steps are instruction offsets
     uint32_t ka_addr[kKS], vl_addr[kDT], vh_addr[kDT];
 #pragma unroll
@@ -368,24 +357,6 @@ void attn_w4_kernel(const AttnParams p) {
     }
 #define W4_EL(S_, QS_, E_) S_[QS_][(E_) >> 4][(E_) & 15]
     // pack elements (E_, E_ + 1) of sub-block QS_ (E_ even) into P's B-operand registers
-#ifdef W4_X_NOPACK         /* timing experiment: P is never packed (wrong results) */
-#define W4_PACK2(S_, QS_, E_)
-#elif defined(W4_X_PACKPERM)   /* timing experiment: P truncated to bf16 by one v_perm_b32 per pair */
-#define W4_PACK2(S_, QS_, E_)                                                                                  \
-    {                                                                                                          \
-        uint32_t w_;                                                                                           \
-        asm volatile("v_perm_b32 %0, %2, %1, %3" : "=v"(w_)                                                    \
-                     : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]), "v"(perm_sel)); \
-        pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
-    }
-#elif defined(W4_X_PACKCONST)  /* timing experiment: the packs read two loop-invariant registers (wrong results) */
-#define W4_PACK2(S_, QS_, E_)                                                                                  \
-    {                                                                                                          \
-        uint32_t w_;                                                                                           \
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w_) : "v"(pk_c0), "v"(pk_c1));                      \
-        pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
-    }
-#else
 #define W4_PACK2(S_, QS_, E_)                                                                                  \
     {                                                                                                          \
         uint32_t w_;                                                                                           \
@@ -397,7 +368,6 @@ void attn_w4_kernel(const AttnParams p) {
                          : "v"(S_[QS_][(E_) >> 4][(E_) & 15]), "v"(S_[QS_][(E_) >> 4][((E_) & 15) + 1]));      \
         pb[QS_][(E_) >> 3][((E_) & 7) >> 1] = w_;                                                              \
     }
-#endif
     // V^T fragment pair n (= kDT * key step + d-tile) of the V slot at byte VS_ -> ring entry n & 3 (two 64-bit halves)
 #define W4_LOADV(N_, VS_)                                                                                      \
     {                                                                                                          \
@@ -408,9 +378,6 @@ void attn_w4_kernel(const AttnParams p) {
     // exp2 of elements [LO_, LO_ + N_) of a sub-block and the row-sum adds of the elements BEFORE each of them (PREV_ =
     // element LO_ - 1, or zero), as ONE asm statement (between two statements the hazard recogniser pads with s_nop).
     // LO_, N_ are constant expressions (the slices are spelled out by literal index below).
-#ifdef W4_X_NOEXP          /* timing experiment: no exp2 / row-sum adds at all (wrong results) */
-#define W4_EXPADD(S_, QS_, LO_, N_, PREV_, SUM_)
-#else
 #define W4_EXPADD(S_, QS_, LO_, N_, PREV_, SUM_)                                                               \
     {                                                                                                          \
         if constexpr (kMS) {                    /* row sums on the matrix pipe: exp2 only */                    \
@@ -428,7 +395,6 @@ void attn_w4_kernel(const AttnParams p) {
                          : "+v"(W4_EL(S_, QS_, LO_)), "+v"(W4_EL(S_, QS_, (LO_) + 1)), "+v"(W4_EL(S_, QS_, (LO_) + 2)), \
                            "+v"(SUM_) : "v"(PREV_));                                                           \
     }
-#endif
     // element E_ - 1 as the PREV_ operand above (zero before element 0)
 #define W4_PREV(S_, QS_, E_) ((E_) >= 1 ? W4_EL(S_, QS_, (E_) >= 1 ? (E_) - 1 : 0) : zero_f)
     const float zero_f = 0.f;
@@ -439,21 +405,9 @@ void attn_w4_kernel(const AttnParams p) {
     //      sub-block 1 one slice after its second exp2), dealt by w4_lo; the 2 kNPW LDS-DMA pieces one per k-step ----
     // packs of phase-1 slice (lo_, n_, plo_ in scope): k-th element of this slice -> its sub-block-0 pair; k-th element of
     // the PREVIOUS slice, if odd -> the sub-block-1 pair it completes
-#ifdef W4_X_NOBAR          /* timing experiments (wrong results): no per-tile barrier / no K, V prefetch in the loop / no row maxima */
-#define W4_TILE_BARRIER
-#else
 #define W4_TILE_BARRIER __builtin_amdgcn_s_barrier();
-#endif
-#ifdef W4_X_NODMA
-    constexpr bool kDoDma = false;
-#else
     constexpr bool kDoDma = true;
-#endif
-#ifdef W4_X_NOMAX
-    constexpr bool kNoMax = true;
-#else
     constexpr bool kNoMax = false;
-#endif
 #define W4_P1_PACK(SC_, K_)                                                                                    \
     if constexpr ((K_) < n_ && lo_ + (K_) < 16) { W4_PACK2(SC_, 0, 2 * (lo_ + (K_))) }                         \
     if constexpr (s_ >= 1 && plo_ + (K_) < lo_ && ((plo_ + (K_)) & 1)) { W4_PACK2(SC_, 1, plo_ + (K_) - 1) }

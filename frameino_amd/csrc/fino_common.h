@@ -7,17 +7,6 @@
 
 #include "../../include/frameino_hip.h"
 
-// Timing-experiment switches that produce WRONG RESULTS (kept because DESIGN.md section 4.1 cites their measurements):
-// they compile only together with -DFINO_EXPERIMENT, which makes fino_version() negative (fino_api.cpp) so that
-// frameino_amd._lib.load() refuses the library unless FINO_ALLOW_EXPERIMENT=1.
-//   make variant NAME=nopack VFLAGS="-DFINO_EXPERIMENT -DW4_X_NOPACK"
-#if (defined(W4_X_NOLGKM) || defined(W4_X_NOPACK) || defined(W4_X_PACKPERM) || defined(W4_X_PACKCONST) || \
-     defined(W4_X_NOEXP) || defined(W4_X_NOBAR) || defined(W4_X_NODMA) || defined(W4_X_NOMAX) ||           \
-     defined(FINO_GEMM_DESYNC_EXP) || defined(F8_X_NOEXP) || defined(F8_X_NOPACK) || defined(F8_X_NOMAX) ||   \
-     defined(F8_X_NOSTAGE) || defined(F8_X_NOPV) || defined(F8_X_NOBAR) || defined(F8_X_NOQK) || defined(F8_X_NOOPENER) || defined(F8_X_STAMP) || defined(FR_X_NOMAX) || defined(FR_X_NOLACC) || defined(FR_X_NOCVT) || defined(FR_X_NOFOLD) || defined(FR_X_NOBAR) || defined(FR_X_NOREAD) || defined(FR_X_NODMA) || defined(PD_X_NOREAD) || defined(PD_X_NOEXP) || defined(PD_X_NODMA) || defined(PD_X_AOP) || defined(PW_X_NOSTORE) || defined(GP_X_NODMA) || defined(GP_X_NOREAD) || defined(GP_X_NOSTORE)) && \
-    !defined(FINO_EXPERIMENT)
-#error "wrong-result timing experiments (W4_X_*, F8_X_*, FR_X_*, PD_X_*, PW_X_*, GP_X_*, FINO_GEMM_DESYNC_EXP) need -DFINO_EXPERIMENT: see fino_common.h"
-#endif
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));

@@ -477,9 +477,6 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
         const char* sb = smem + cur * kStageBytes;
         PSTAMP(t0)
         // ---------------- LOAD(t): all fragments of my (16 MI)x64 (A) and 64x64 (W) operand blocks ----------------
-#if defined(GP_X_NOREAD)  /* timing experiment (wrong results): no LDS fragment reads; GP_X_NOREAD=2: the operands rotate instead */
-        if (t == 0)
-#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int pch = (pch0 ^ (kk << 2)) << 4;
@@ -488,26 +485,7 @@ __device__ __forceinline__ void pp_mainloop(const GemmParams& p, char* smem, con
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(sb + a_base + i * 2048 + pch);
         }
-#if defined(GP_X_NOREAD) && GP_X_NOREAD == 2
-        if (t > 0) {        // every fragment register changes its bits each K-tile, as fresh LDS data would (4 + MI moves per kk)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const u32x4_t w0 = wf[kk][0];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) wf[kk][j] = wf[kk][j + 1];
-                wf[kk][3] = w0;
-                const u32x4_t a0 = af[kk][0];
-#pragma unroll
-                for (int i = 0; i < MI - 1; ++i) af[kk][i] = af[kk][i + 1];
-                af[kk][MI - 1] = a0;
-            }
-        }
-#endif
-#ifdef GP_X_NODMA         /* timing experiment (wrong results): no operand staging after the prologue */
-        if (false) {
-#else
         if (t >= 1 && t + 1 < nk) {                  // tile t+1 into the stage tile t-1 has left
-#endif
 #pragma unroll
             for (int q = 0; q < NA0; ++q) PP_DMA_A(cur ^ 1, t + 1, q)
             if (wm == 0) {
@@ -613,11 +591,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     const int64_t m0 = (int64_t)tm * (32 * MI), n0 = (int64_t)tn * BN;
     f32x4_t acc[MI][4];
     int nk = (int)(p.k / BK);
-#ifdef FINO_GEMM_DESYNC_EXP
-    // TIMING EXPERIMENT ONLY (wrong results): the first round's tiles stop after 1/8 .. 8/8 of K, so that the CUs leave
-    // lock step and the epilogue bursts of later rounds are spread in time
-    if (blockIdx.x < 256) nk = nk * (int)((blockIdx.x >> 3) % 8 + 1) / 8;
-#endif
 #ifdef FINO_GEMM_STAMP
     unsigned long long ts0, ts1;
     STAMP(ts0)

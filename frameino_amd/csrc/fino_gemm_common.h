@@ -277,9 +277,6 @@ __device__ __forceinline__ void gemm_epilogue_t(f32x4_t (&acc)[MI][4], const Gem
         const int ch = idx & 31;
         const int64_t gm = m0 + row, gn = n0 + ch * 8;
         if (gm >= p.m || gn >= p.n) continue;
-#ifdef GP_X_NOSTORE      /* timing experiment (wrong results): the epilogue without its global stores */
-        if (p.m > 0) continue;
-#endif
         uint4 yv = *reinterpret_cast<const uint4*>(smem + row * kCsStride + ch * 16);
         if (kHasRes) {
             float y[8], rv[8], o[8];

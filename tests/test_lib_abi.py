@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.fino_version() == 102 == _lib.ABI_VERSION
+    assert lib.fino_version() == 103 == _lib.ABI_VERSION
     # bad dtype -> FINO_ERR_ARG before anything touches a device
     rc = lib.fino_gemm(1, 1, 0, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 0, 0, 7, 0)
     assert rc == -1 and b"dtype" in lib.fino_last_error()
@@ -114,3 +114,23 @@ def test_an_experiment_build_is_refused_as_the_product_library(tmp_path, monkeyp
     guard = common[common.index("#if (defined("):common.index("#error")]
     assert used and all(f"defined({u})" in guard for u in used), sorted(used)
     assert "return -FINO_VERSION" in open(os.path.join(csrc, "fino_api.cpp")).read()
+
+
+def test_product_sources_carry_no_experiment_switch_and_the_patch_applies(tmp_path):
+    """the wrong-result timing switches (PD_X_* / PW_X_* / F8_X_* / FR_X_* / GP_X_* / W4_X_* ...) are not in
+    frameino_amd/csrc any more -- they live in tools/debug/experiments.patch, which must keep applying to the product sources
+    (tools/debug/mkvar.sh --experiments builds the variant libraries from the patched scratch copy)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "debug", "strip_experiments.py")
+    p = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    dst = str(tmp_path / "csrc_exp")
+    p = subprocess.run([sys.executable, tool, "--apply", dst], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    patched = open(os.path.join(dst, "fino_attention.hip")).read()
+    assert "PD_X_NODMA" in patched and "PD_X_NODMA" not in open(os.path.join(root, "frameino_amd", "csrc", "fino_attention.hip")).read()
+    for f in os.listdir(os.path.join(root, "frameino_amd", "csrc")):
+        if f.endswith((".hip", ".h", ".cpp")):
+            assert "wrong results" not in open(os.path.join(root, "frameino_amd", "csrc", f)).read().lower(), f

@@ -7,15 +7,10 @@ VARS="STAMP NOEXP NOPACK NOMAX NOSTAGE NOPV NOBAR NOOPENER"
 RIM=${RIM:-0}   # F8_READS_IN_MATRIX of the variant builds
 if [ "$1" = build ]; then
   make -s
+  cd ../..
+  # the F8_X_* switches live in tools/debug/experiments.patch: mkvar.sh --experiments builds from a patched scratch copy of csrc/
   for v in $VARS; do
-    mkdir -p build/f8x
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DFINO_EXPERIMENT -DF8_X_$v -DF8_READS_IN_MATRIX=$RIM -x hip \
-          -c fino_attention_fp8.hip -o build/f8x/$v.o &
-  done
-  wait
-  for v in $VARS; do
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libframeino_f8x_$v.so build/f8x/$v.o \
-          $(ls build/*.o | grep -v fino_attention_fp8)
+    tools/debug/mkvar.sh --experiments f8x_$v fino_attention_fp8.hip "-DFINO_EXPERIMENT -DF8_X_$v -DF8_READS_IN_MATRIX=$RIM"
   done
 else
   cd ../..

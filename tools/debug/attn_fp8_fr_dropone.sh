@@ -7,8 +7,8 @@ VARS="NOMAX NOLACC NOCVT NOFOLD NOBAR NOREAD NODMA"
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   make -s -C frameino_amd/csrc
-  for v in $VARS; do tools/debug/mkvar.sh frx_$v fino_attention_fp8.hip "-DFINO_EXPERIMENT -DFR_X_$v" & done
-  wait
+  # (sequential: --experiments re-creates the patched scratch copy of csrc/ for every build)
+  for v in $VARS; do tools/debug/mkvar.sh --experiments frx_$v fino_attention_fp8.hip "-DFINO_EXPERIMENT -DFR_X_$v"; done
 else
   echo "product:"; FINO_FP8_ONLY=1 python3 tools/attn_fp8_bench.py | grep TFLOP
   for v in $VARS; do

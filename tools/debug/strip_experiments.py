@@ -38,7 +38,7 @@ def _cond_value(expr):
     """value of a preprocessor expression when every experiment macro is undefined, or None if it mentions anything else"""
     e = re.sub(r"/\*.*?\*/", " ", expr)
     e = re.sub(r"//.*$", " ", e)
-    e = e.replace("\\\n", " ")
+    e = e.replace("\\\n", " ").replace("\n", " ")
     names = [m for m in IDENT.findall(e) if m != "defined"]
     if not names or not all(EXP_EVAL.fullmatch(n) for n in names):
         return None
