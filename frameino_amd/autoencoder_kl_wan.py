@@ -142,6 +142,7 @@ class AutoencoderKLWan(FromPretrainedMixin):
         self._dtype = torch.bfloat16           # MFMA operand dtype of the convolutions (bf16 | fp16)
         self._io_dtype = None                  # what `.dtype` reports when fp32 was asked for (reference app.py:157)
         self._planes = 0                       # 0: convolutions in `_dtype`; 2 | 3: fp32-compute mode on split-bf16 products
+        self._span_limit = 1 << 31             # bytes a split convolution's gather offsets cover (tests lower it: strip path)
         self._device = torch.device("cpu")
         self.use_slicing = self.use_tiling = False
         self.tile_sample_min_height = self.tile_sample_min_width = 256            # reference :1070-1075 (recorded only)
@@ -365,6 +366,26 @@ class AutoencoderKLWan(FromPretrainedMixin):
         e = self._pk[name]
         if self._planes:
             xp = x.t if isinstance(x, _Planes) else ops.split_bf16(x, "planes", self._planes)
+            t, h, w, cw = xp.shape
+            kt, kh, kw = e.k
+            # The convolution kernel gathers with 32-bit byte offsets from the first input frame a 256-row tile can touch:
+            # (2 stride_t + k_t) frames of `planes` planes must stay under 2 GiB.  ONE layer of the 704 x 1280 decode is over
+            # (up_blocks.3.resnets.0.conv1: 512 channels x 3 planes at 352 x 640 = 692 MB per frame): such a stride-1 "same"
+            # convolution runs as horizontal strips with one halo row each side -- every output row sees the same taps.
+            lim = self._span_limit
+            span = (((255 + h * w - 1) // (h * w) + 1) * stride[0] + kt) * h * w * cw * 2        # (fino_conv3d_split's own formula)
+            if span >= lim and tuple(stride) == (1, 1, 1) and not up and out_thw is None and pad[1] == kh // 2 \
+                    and pad[2] == kw // 2 and h >= 8:
+                n = min(h // 4, -(-span // (lim - lim // 16)))
+                rows = -(-h // n)
+                outs = []
+                for r0 in range(0, h, rows):
+                    r1 = min(h, r0 + rows)
+                    a0, a1 = max(0, r0 - pad[1]), min(h, r1 + (kh - 1 - pad[1]))
+                    rs = None if residual is None else residual[:, a0:a1].contiguous()
+                    ys = ops.conv3d_split_cl(xp[:, a0:a1].contiguous(), e.w, e.b, e.k, self._planes, stride, pad, None, False, rs)
+                    outs.append(ys[:, r0 - a0:r0 - a0 + (r1 - r0)])
+                return torch.cat(outs, dim=1)
             return ops.conv3d_split_cl(xp, e.w, e.b, e.k, self._planes, stride, pad, out_thw, up, residual)
         return ops.conv3d_cl(x, e.w, e.b, e.k, stride, pad, out_thw, up, residual)
 

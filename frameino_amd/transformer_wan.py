@@ -428,7 +428,12 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             self.ops.rmsnorm_rope_(kv[:, :d], blk.attn2.norm_k.weight, blk.attn2.norm_k.eps)
             kvs.append(kv)
         val = SimpleNamespace(txt=txt, kv=kvs, lt=kept.shape[1], tail=None if tail is None else (tail[1], tail[2]), w2=None)
-        if tail is not None and self.reassociate_text_out and not self._fp8 and not self._fp8_pending \
+        # P.(V W_o^T) pays only while its K = heads x keys stays well under D (K = 1728 / 384 at 64 / 8 prompt tokens against
+        # 3072): from ~77 kept keys on (24 heads) it costs the FLOPs it saves, plus the rrms / probabilities passes, a GEMM per
+        # sample and 30 cached [D, heads x kp] matrices per sample (0.32 GB for a 64-token prompt, per cache context).  Longer prompts take the
+        # folded attention + the ordinary out-projection.
+        worth = tail is not None and self.config.num_attention_heads * (-(-max(tail[1]) // 8) * 8) <= 0.6 * d
+        if worth and self.reassociate_text_out and not self._fp8 and not self._fp8_pending \
                 and hasattr(self.ops, "attention_probs") \
                 and self.ops.attention_probs_supported(1, self.config.num_attention_heads, lq, kept.shape[1],
                                                        d // self.config.num_attention_heads):

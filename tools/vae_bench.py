@@ -15,11 +15,16 @@ ap.add_argument("--h", type=int, default=44)
 ap.add_argument("--w", type=int, default=80)
 ap.add_argument("--encode", action="store_true")
 ap.add_argument("--cog", action="store_true", help="CogVideoX VAE (49 f 480x720: latent 13 x 60 x 90) instead of the Wan one")
+ap.add_argument("--fp32", type=int, default=0, metavar="PLANES",
+                help="Wan VAE in the fp32-compute mode (set_compute_dtype(torch.float32, planes=2|3): split-bf16 products)")
+ap.add_argument("--tiling", action="store_true", help="--cog: diffusers' tiled encode / decode (enable_tiling())")
 a = ap.parse_args()
 dev = torch.device("cuda")
 if a.cog:
     from frameino_amd.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
     vae = AutoencoderKLCogVideoX().random_init_(seed=0, device=dev)
+    if a.tiling:
+        vae.enable_tiling()
     h, w = (60, 90) if (a.h, a.w) == (44, 80) else (a.h, a.w)
     z = torch.randn(1, 16, a.frames, h, w, device=dev)
     for it in range(2):
@@ -40,6 +45,8 @@ if a.cog:
         print(f"cog encode {tuple(vid.shape)} -> {tuple(m.shape)}: {time.time() - t0:.3f} s", flush=True)
     sys.exit(0)
 vae = AutoencoderKLWan(**WAN22_VAE).random_init_(seed=0, device=dev)
+if a.fp32:
+    vae.set_compute_dtype(torch.float32, planes=a.fp32)
 z = torch.randn(1, 48, a.frames, a.h, a.w, device=dev)
 for it in range(2):
     torch.cuda.synchronize(); t0 = time.time()
