@@ -572,11 +572,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
     // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16*ks + 8h .. +7] ----
     const int qrow = qb * kQBlock + wave * kQRowsPerWave + r;
     const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
-    // A wave whose 32 rows all lie past Lq (the last q-block of a sequence: 32 valid rows of 256 at L = 12320, 8 at a 3080-row
-    // token shard) keeps its share of the K / V staging and every barrier, and SKIPS its softmax and matrix phases: nothing of
-    // it is ever stored.  Round 5 (profiles/r05_energy_probes.txt): those blocks cost a full block's time and energy -- L =
-    // 12320 ran 1.8 % longer and drew 3.4 % more joules per valid FLOP than L = 12288.
-    const bool live_w = __builtin_amdgcn_readfirstlane((int)(qb * kQBlock + wv * kQRowsPerWave < p.lq)) != 0;
     vec8 qf[kKS];
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) {
@@ -707,8 +702,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         const int w = t + grp;
         PD_DMA_K(w + 3)
         PD_DMA_V(w + 2)
-        vec8 pb[4];                                  // P(t) packed: pb[2*kt + s2]
-      if (live_w) {
 #if PD_MAX_SOFTMAX
         {
             MASK_RAGGED(t)
@@ -742,6 +735,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
             }
             l_run += psum0 + psum1;
         }
+        vec8 pb[4];                                  // P(t) packed: pb[2*kt + s2]
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             pb[0][j] = (typename T::scalar)sc0[j];
@@ -764,9 +758,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
             PD_KISSUE(0, 0)
             PD_KISSUE(1, 1)
         }
-#endif
-      }   // live_w
-#if PD_PREK
         // all DMAs this wave issued before this phase (4 per phase) have landed
         if constexpr (kPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -784,7 +775,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
         __builtin_amdgcn_s_setprio(1);
 #endif
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (live_w) {
       if constexpr (D == 128) {
         if (t + 1 < nt) {
 #if !PD_PREK
@@ -852,7 +842,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void attn_ppd_kernel(const AttnPara
 #if !PD_MAX_SOFTMAX
         MAX_FINISH1(mxa, mx_next)
 #endif
-      }   // live_w
         ka0 = (ka0 + kTileBytes) & kRingMask;
         vl0 = ((vl0 + kTileBytes) & kRingMask) | kVBase;
         vh0 = ((vh0 + kTileBytes) & kRingMask) | kVBase;

@@ -326,23 +326,6 @@ class WanImageToVideoPipeline:
                 if s_ is not None:
                     s_.wait_stream(main)
             alive = [True, True]
-            if getattr(plan, "stagger", False) and self._streams[0] is not None and plan.shards[0].exchange == "kv":
-                # STAGGER (opt-in, round 5): started together the two branches run in lockstep -- both reach their K|V gather at
-                # the same moment and both wait for the wire with nothing to compute.  Branch 1 therefore starts only when branch
-                # 0 has launched its first self-attention (half a layer later), so that one branch's gather flies under the
-                # other's attention + FFN.  Nothing holds the offset afterwards; tools/plan_sim.py (FINO_PLAN_SIM_STAGGER with a
-                # modelled wire) measures what is left of it.
-                for sh_ in plan.shards:
-                    sh_.yield_after_attention = True
-                with torch.cuda.stream(self._streams[0]), tr.cache_context(gens[0][0]):
-                    next(gens[0][1])                       # embedding stage
-                    next(gens[0][1])                       # block 0 up to its attention launch
-                    ev = torch.cuda.Event()
-                    ev.record()
-                self._streams[1].wait_event(ev)
-            else:
-                for sh_ in plan.shards:
-                    sh_.yield_after_attention = False
             while any(alive):
                 for i, (name, g) in enumerate(gens):
                     if not alive[i]:

@@ -681,8 +681,6 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     kv3 = kv_all.view(1, -1, 2 * dg)[:, :L]
                     o.attention(q3[:, :, h0 * dh:h1 * dh], kv3[:, :, :dg], kv3[:, :, dg:], h1 - h0,
                                 out=a3[:, :, h0 * dh:h1 * dh], **afold)
-                if getattr(sh, "yield_after_attention", False):
-                    yield
             else:
                 kv_loc = sh.kv_local(lpad, 2 * d, dt, dev)
                 if sh.fused_qkv_ok() and not self._fp8:
@@ -718,8 +716,6 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                         work.wait()
                     kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
                     o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d), **afold)
-                if getattr(sh, "yield_after_attention", False):
-                    yield               # (the interleaved plan's stagger: frameino_amd/pipeline_wan_i2v_motion_frameino.py::_step)
             if default_procs and not once:
                 self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
                           residual=x, gate=m[:, 2], sel=sel, out=x, **tk)

@@ -164,7 +164,6 @@ def main():
         ex = "heads" if kind.endswith("heads") else "kv"
         if kind.startswith("interleave"):
             pipe.parallel = SimpleNamespace(interleave=True, cfg_ways=1, token_ways=ways,
-                                            stagger=bool(os.environ.get("FINO_PLAN_SIM_STAGGER")),
                                             shards=(FakeShard(0, ways, exchange=ex), FakeShard(0, ways, exchange=ex)))
             set_tiling(True)
             for sh in pipe.parallel.shards:
