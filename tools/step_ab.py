@@ -28,8 +28,11 @@ cond = torch.randn(1, C, 1, lh, lw, generator=g).to(dev)
 traj = torch.randn(1, C, fg + 1, lh, lw, generator=g).to(dev)
 idl = torch.randn(1, C, 1, lh, lw, generator=g).to(dev)
 mask = torch.ones(1, 1, fg, lh, lw, device=dev); mask[:, :, 0] = 0
-pe = torch.randn(1, 512, 4096, generator=g).to(dev).bfloat16()
-ne = torch.randn(1, 512, 4096, generator=g).to(dev).bfloat16()
+pe = torch.randn(1, 512, 4096, generator=g)
+ne = torch.randn(1, 512, 4096, generator=g)
+pe[:, 64:] = 0          # the bench's zero-padded prompts (round 5; rounds 2 - 4 ran un-padded ones here)
+ne[:, 8:] = 0
+pe, ne = pe.to(dev).bfloat16(), ne.to(dev).bfloat16()
 pipe.scheduler.set_timesteps(50, device=dev)
 st = pipe.make_state(lat, cond, traj, idl, mask, pe, ne, 5.0)
 st.t_rows[1:2].copy_(pipe.scheduler.timesteps[10:11].float())
@@ -48,6 +51,11 @@ if "--ppd" in sys.argv:        # round 4: self-attention on the register-staged 
     # vs the LDS-DMA-staged one; the text cross-attention stays on the free-running kernel in both
     settings = {"self-attention: register-staged ping-pong kernel (tune 5, the round-3 policy)": (0, True, 5, False, 0),
                 "self-attention: LDS-DMA-staged ping-pong kernel (the policy)": (0, True, 0, False, 0)}
+ew_key = None
+if "--ew-reverse" in sys.argv:  # round 5: the q | k RMSNorm + RoPE walking its rows last to first (FINO_TUNE_EW_ROW_ORDER = 7th knob)
+    settings = {"q|k norm + RoPE rows first to last (product)": (0, True, 0, False, 0, 0),
+                "q|k norm + RoPE rows last to first": (0, True, 0, False, 0, 1)}
+    ew_key = 7
 res = {k: [] for k in settings}
 
 
@@ -55,7 +63,9 @@ attn = {}
 attn_c = {}
 
 
-def run(gm, dedup, attn_k, fold, steps, tile_m=0):
+def run(gm, dedup, attn_k, fold, steps, tile_m=0, ew=0):
+    if ew_key is not None:
+        lib.fino_tune_set(ew_key, ew)
     lib.fino_tune_set(3, tile_m)
     lib.fino_tune_set(0, gm)
     lib.fino_tune_set(4, attn_k)
@@ -67,7 +77,7 @@ def run(gm, dedup, attn_k, fold, steps, tile_m=0):
             pipe._step(st)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    key = (gm, dedup, attn_k, fold, tile_m)[:len(next(iter(settings.values())))]
+    key = (gm, dedup, attn_k, fold, tile_m, ew)[:len(next(iter(settings.values())))]
     attn.setdefault(key, []).append(kt.summary()["attn_self"]["total_ms"] / steps)
     attn_c.setdefault(key, []).append(kt.summary()["attn_cross"]["total_ms"] / steps)
     return ms
