@@ -247,11 +247,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void rmsnorm_rope_kernel(uint1
                                                                            const float* __restrict__ sin_t,
                                                                            int head_dim, uint16_t* __restrict__ out,
                                                                            const int64_t* __restrict__ head_off,
-                                                                           const int64_t* __restrict__ head_ld, int reverse) {
+                                                                           const int64_t* __restrict__ head_ld) {
     const int lane = threadIdx.x & 63;
-    int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
-    if (reverse) row = rows - 1 - row;      // A/B knob FINO_TUNE_EW_ROW_ORDER: last rows first (what the GEMM before it wrote last)
     const int s = blockIdx.y;
     const bool rope = pp.rope[s] != 0;
     rmsnorm_rope_row<T, NP>(x + row * ldx + (int64_t)s * dim, row, dim, pp.w[s], pp.eps[s], rope ? cos_t : nullptr,
@@ -719,15 +718,14 @@ static int rmsnorm_rope_impl(void* x, int64_t rows, int dim, int64_t ldx, int pa
     FINO_CHECK(parts == 1 || dim % 8 == 0, FINO_ERR_ARG, "fino_rmsnorm_rope: segments need dim % 8 == 0");
     const dim3 grid((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)parts), block(kWavesPerBlock * 64);
     hipStream_t st = (hipStream_t)stream;
-    const int reverse = fino_tune_get(FINO_TUNE_EW_ROW_ORDER) == 1;
     const bool ok = dispatch_np<kMaxPasses>(dim, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if (dtype == FINO_BF16)
             rmsnorm_rope_kernel<BF16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx, pp, cos_t, sin_t, head_dim,
-                                                                  (uint16_t*)out, head_off, head_ld, reverse);
+                                                                  (uint16_t*)out, head_off, head_ld);
         else
             rmsnorm_rope_kernel<F16, NP><<<grid, block, 0, st>>>((uint16_t*)x, rows, dim, ldx, pp, cos_t, sin_t, head_dim,
-                                                                 (uint16_t*)out, head_off, head_ld, reverse);
+                                                                 (uint16_t*)out, head_off, head_ld);
     });
     FINO_CHECK(ok, FINO_ERR_UNSUPPORTED, "fino_rmsnorm_rope: dim %d > %d unsupported", dim, kMaxPasses * 512);
     FINO_LAUNCH_CHECK();

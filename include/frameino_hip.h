@@ -58,12 +58,9 @@ const char* fino_last_error(void);
  * tiles, whole blocks; by policy it serves Lk <= 1024 when there are at least two q-blocks per CU, the free-running kernel the
  * rest; 7 = the policy without the walking kernel.  FINO_TUNE_ATTN_WALK_GRID: workgroups of the walking kernel (0 = one per CU; tests use small counts to make runs of
  * blocks cross heads and batches on small shapes).
- * FINO_TUNE_ATTN_FP8_KERNEL (fino_attn_fwd_fp8): 1 = the 8-wave ping-pong kernel instead of the free-running 4-wave one.
- * FINO_TUNE_EW_ROW_ORDER: 1 = fino_rmsnorm_rope* walk their rows last to first (same results; an A/B of the order against what
- * the GEMM in front of them left in the Infinity Cache). */
+ * FINO_TUNE_ATTN_FP8_KERNEL (fino_attn_fwd_fp8): 1 = the 8-wave ping-pong kernel instead of the free-running 4-wave one. */
 enum { FINO_TUNE_GEMM_GROUP_M = 0, FINO_TUNE_GEMM_RASTER = 1, FINO_TUNE_CONV_LOOP = 2, FINO_TUNE_GEMM_TILE_M = 3,
-       FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_ATTN_FP8_KERNEL = 5, FINO_TUNE_ATTN_WALK_GRID = 6, FINO_TUNE_EW_ROW_ORDER = 7,
-       FINO_TUNE_COUNT = 8 };
+       FINO_TUNE_ATTN_KERNEL = 4, FINO_TUNE_ATTN_FP8_KERNEL = 5, FINO_TUNE_ATTN_WALK_GRID = 6, FINO_TUNE_COUNT = 8 };
 int fino_tune_set(int key, int value);
 int fino_tune_get(int key);
 

@@ -51,11 +51,6 @@ if "--ppd" in sys.argv:        # round 4: self-attention on the register-staged 
     # vs the LDS-DMA-staged one; the text cross-attention stays on the free-running kernel in both
     settings = {"self-attention: register-staged ping-pong kernel (tune 5, the round-3 policy)": (0, True, 5, False, 0),
                 "self-attention: LDS-DMA-staged ping-pong kernel (the policy)": (0, True, 0, False, 0)}
-ew_key = None
-if "--ew-reverse" in sys.argv:  # round 5: the q | k RMSNorm + RoPE walking its rows last to first (FINO_TUNE_EW_ROW_ORDER = 7th knob)
-    settings = {"q|k norm + RoPE rows first to last (product)": (0, True, 0, False, 0, 0),
-                "q|k norm + RoPE rows last to first": (0, True, 0, False, 0, 1)}
-    ew_key = 7
 res = {k: [] for k in settings}
 
 
@@ -63,9 +58,7 @@ attn = {}
 attn_c = {}
 
 
-def run(gm, dedup, attn_k, fold, steps, tile_m=0, ew=0):
-    if ew_key is not None:
-        lib.fino_tune_set(ew_key, ew)
+def run(gm, dedup, attn_k, fold, steps, tile_m=0):
     lib.fino_tune_set(3, tile_m)
     lib.fino_tune_set(0, gm)
     lib.fino_tune_set(4, attn_k)
@@ -77,7 +70,7 @@ def run(gm, dedup, attn_k, fold, steps, tile_m=0, ew=0):
             pipe._step(st)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    key = (gm, dedup, attn_k, fold, tile_m, ew)[:len(next(iter(settings.values())))]
+    key = (gm, dedup, attn_k, fold, tile_m)[:len(next(iter(settings.values())))]
     attn.setdefault(key, []).append(kt.summary()["attn_self"]["total_ms"] / steps)
     attn_c.setdefault(key, []).append(kt.summary()["attn_cross"]["total_ms"] / steps)
     return ms
