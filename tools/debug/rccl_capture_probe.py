@@ -13,7 +13,10 @@ PATTERNS = ["allgather_main", "allgather_side", "allgather_two_comms_two_sides",
             "allgather_main_sync", "alltoall_main_sync",
             # round 5: kernels on two side streams, every collective ISSUED with the capturing stream current
             "sides_compute_only", "allgather_main_issue_side_wait", "allgather_main_issue_main_wait",
-            "allgather_main_issue_side_wait_two_comms"]
+            "allgather_main_issue_side_wait_two_comms",
+            # round 5, second pass: SYNCHRONOUS collectives (torch >= 2.7 runs them on the current stream, no communicator-stream
+            # fork) on a side stream forked from the capturing one
+            "alltoall_side_sync", "allgather_side_sync", "alltoall_two_sides_sync"]
 
 
 def child(pattern):
@@ -62,6 +65,26 @@ def child(pattern):
                 r = y1 + z
             main.wait_stream(s1)
             return r
+        if pattern in ("alltoall_side_sync", "allgather_side_sync"):
+            s1.wait_stream(main)
+            with torch.cuda.stream(s1):
+                f = dist.all_gather_into_tensor if pattern == "allgather_side_sync" else dist.all_to_all_single
+                f(y1, x, group=ga)
+            z = x * 2                            # main goes on while the collective runs on s1
+            main.wait_stream(s1)
+            return y1 + z
+        if pattern == "alltoall_two_sides_sync":
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                dist.all_to_all_single(y1, x, group=ga)
+                r1 = y1 * 2
+            with torch.cuda.stream(s2):
+                dist.all_to_all_single(y2, x, group=gb)
+                r2 = y2 * 3
+            main.wait_stream(s1)
+            main.wait_stream(s2)
+            return r1 + r2
         if pattern == "allgather_two_comms_two_sides":
             s1.wait_stream(main)
             s2.wait_stream(main)
