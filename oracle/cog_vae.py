@@ -27,7 +27,8 @@ UNPINNED** (no golden vector can exist offline).  What is restated:
   * TILING (`enable_tiling()`; round 5): `tiled_encode` / `tiled_decode` -- overlapping spatial tiles of half the config's
     sample size, overlap factors 1/6 and 1/5, every tile with its own frame batches and conv caches, `blend_v` / `blend_h`
     (the same loops as the in-tree Wan VAE's, architecture/autoencoder_kl_wan.py:1254-1268) -- restated from the library's
-    documented behaviour like everything else here: parity UNPINNED.
+    documented behaviour like everything else here: parity UNPINNED, except the two blend loops, which are checked bit for bit
+    against the in-tree ones (tests/golden/vae_blend.npz, tests/test_oracle_golden.py).
 
 State-dict keys are diffusers' parameter names (`encoder.down_blocks.0.resnets.0.conv1.conv.weight`, ...)."""
 import torch

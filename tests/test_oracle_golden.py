@@ -232,3 +232,17 @@ def test_unipc_loop_vs_reference_pipeline_run_with_unipc(golden):
                            a["id_latent"], a["mask"], a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]),
                            int(u["steps"]))
     torch.testing.assert_close(ref, torch.from_numpy(u["out_latents"]), atol=2e-5, rtol=2e-5)
+
+
+def test_tile_blends_equal_the_reference_in_tree_loops(golden):
+    """oracle/cog_vae.py::blend_v / blend_h against tests/golden/vae_blend.npz: the reference's in-tree
+    architecture/autoencoder_kl_wan.py:1254-1268 run on random tiles (tools/golden/make_golden.py::gen_blend) -- the one part of
+    the CogVideoX VAE tiling that has a reference implementation inside /root/reference; bit-equal (same loops, fp32)."""
+    from oracle import cog_vae as V
+    _, _, a = golden("vae_blend")
+    n = sum(1 for k in a if k.startswith("extent_"))
+    assert n == 4
+    for i in range(n):
+        e = int(a[f"extent_{i}"])
+        assert torch.equal(V.blend_v(a[f"a_{i}"].clone(), a[f"b_{i}"].clone(), e), a[f"v_{i}"])
+        assert torch.equal(V.blend_h(a[f"a_{i}"].clone(), a[f"b_{i}"].clone(), e), a[f"h_{i}"])

@@ -509,7 +509,22 @@ def gen_cog_pipe():
          **{"te/" + k: v for k, v in te.state_dict().items()})
 
 
-GENS = {"wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae, "cog_dit": gen_cog_dit,
+def gen_blend():
+    """The tile blends of the VAE tiling: the reference's in-tree blend_v / blend_h (architecture/autoencoder_kl_wan.py:1254-1268,
+    the same loops diffusers' CogVideoX VAE runs) on random 5-D tiles, extents below / at / above the tile size."""
+    from architecture.autoencoder_kl_wan import AutoencoderKLWan
+    g = torch.Generator().manual_seed(31)
+    arrays = {}
+    for i, (shape, extent) in enumerate([((1, 3, 2, 6, 5), 2), ((1, 2, 3, 8, 7), 5), ((2, 4, 1, 5, 9), 9), ((1, 1, 2, 4, 4), 1)]):
+        a = torch.randn(*shape, generator=g)
+        b = torch.randn(*shape, generator=g)
+        arrays[f"a_{i}"], arrays[f"b_{i}"], arrays[f"extent_{i}"] = a, b, np.array(extent)
+        arrays[f"v_{i}"] = AutoencoderKLWan.blend_v(None, a.clone(), b.clone(), extent)
+        arrays[f"h_{i}"] = AutoencoderKLWan.blend_h(None, a.clone(), b.clone(), extent)
+    save("vae_blend", **arrays)
+
+
+GENS = {"blend": gen_blend, "wan_dit": gen_wan_dit, "wan_pipe": gen_wan_pipe, "wan_vae": gen_wan_vae, "cog_dit": gen_cog_dit,
         "cog_dit_s1": gen_cog_dit_s1, "cog_pipe": gen_cog_pipe, "traj_kernel": gen_traj_kernel}
 
 if __name__ == "__main__":
