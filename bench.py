@@ -399,7 +399,10 @@ def main():
                     pipe._step(st)                       # eager pass fills every lazy cache before the capture
                     st.lat.copy_(snap)
                     graph = torch.cuda.CUDAGraph()
-                    # (a process group's watchdog thread polls events: see frameino_amd/graph_step.py::capture_error_mode)
+                    # (a process group's watchdog thread polls events: see frameino_amd/graph_step.py::capture_error_mode and
+                    #  ::drain_collectives -- no eager collective may be on a watchdog's list when the capture opens)
+                    from frameino_amd.graph_step import drain_collectives
+                    drain_collectives()
                     with torch.cuda.graph(graph, capture_error_mode="thread_local" if multi else "global"):
                         pipe._step(st)
                 graph.replay()

@@ -70,6 +70,30 @@ def capture_error_mode(plan):
     return "thread_local" if plan is not None else "global"
 
 
+def drain_collectives(wait_s=None):
+    """Call before a capture whenever a process group is alive: returns once c10d's watchdog threads hold no eager work.
+
+    Why (round 5, `tools/debug/loop_bench.sh`: 6 aborts in 30 runs of the forced-shard rehearsal, 0 in 60 with this): a watchdog
+    sweeps its list of issued collectives every 100 ms and `hipEventQuery`s each one's end event.  An eager step's collectives are
+    still on that list when the next step is captured right behind it, and as soon as the capture pulls the communicator's stream
+    in, HIP answers a query of an event recorded on that stream with `hipErrorCapturedEvent` ("operation not permitted on an event
+    last recorded in a capturing stream") -- the watchdog rethrows and the process dies with SIGABRT, whatever the capture mode.
+    CUDA builds of torch wait for the pending work themselves when a capture begins; the ROCm build of torch 2.10 does not.
+    So: finish the GPU's work (every issued collective is then complete), and give the watchdogs three sweep periods to drop
+    them (`FINO_CAPTURE_DRAIN_S`, default 0.3 s -- once per captured loop).  c10d's flight recorder does not help: its "active"
+    entries are retired by whoever dumps them, not by the watchdog (tried: the abort came back)."""
+    import os
+    import time
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+    except (ImportError, RuntimeError):
+        return
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get("FINO_CAPTURE_DRAIN_S", "0.3")) if wait_s is None else wait_s)
+
+
 class StepGraph:
     def __init__(self, step_fn, mode, capturable, total_steps, error_mode="global"):
         self.step_fn, self.mode, self.error_mode = step_fn, mode, error_mode
@@ -86,6 +110,7 @@ class StepGraph:
         else:
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
+                drain_collectives()              # (a no-op without a process group)
                 try:
                     with torch.cuda.graph(g, capture_error_mode=self.error_mode):
                         self.step_fn()
