@@ -301,3 +301,56 @@ def _run_full_size_token_shards(ways, exchange, lat_hw, prompt_tokens):
     if prompt_tokens < 512:
         folded = [v[2] for v in m._text_cache.values()]
         assert folded and all(t.tail is not None and t.w2 is not None for t in folded)
+
+
+_CAPTURE_STRESS = r"""
+import os, socket, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from frameino_amd.graph_step import drain_collectives
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+ga, gb = dist.new_group([0]), dist.new_group([0])
+x = torch.randn(4096, 256, device=dev); y1, y2 = torch.empty_like(x), torch.empty_like(x)
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+def step(hold=0.0):              # the interleaved plan's call pattern: kernels on two side streams, collectives issued on main
+    import time
+    main = torch.cuda.current_stream()
+    s1.wait_stream(main); s2.wait_stream(main)
+    with torch.cuda.stream(s1): a1 = x * 2
+    with torch.cuda.stream(s2): a2 = x * 3
+    main.wait_stream(s1); w1 = dist.all_gather_into_tensor(y1, a1, group=ga, async_op=True)
+    main.wait_stream(s2); w2 = dist.all_gather_into_tensor(y2, a2, group=gb, async_op=True)
+    time.sleep(hold)             # (a real step spends 5 - 15 ms of host time here: the window a watchdog sweep must not fall into)
+    with torch.cuda.stream(s1): w1.wait(); r1 = y1 + a1
+    with torch.cuda.stream(s2): w2.wait(); r2 = y2 + a2
+    main.wait_stream(s1); main.wait_stream(s2)
+    return r1 + r2
+
+for it in range(int(sys.argv[2])):
+    ref = step()                                   # eager: its collectives go on the watchdogs' lists
+    drain_collectives()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        out = step(0.04)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, ref), it
+print("STRESS OK", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_capture_right_behind_eager_collectives_does_not_abort():
+    """graph_step.drain_collectives: c10d's watchdog must hold no eager collective when a capture pulls the communicator's stream
+    in (its hipEventQuery then fails with hipErrorCapturedEvent and the watchdog aborts the process: 6 of 30 runs of the
+    forced-shard rehearsal before the drain existed, profiles/r05z_capture_watchdog_abort.txt).  Twelve eager-step / capture cycles
+    in a child process (an abort must not take pytest down)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _CAPTURE_STRESS, root, "12"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "STRESS OK" in p.stdout, (p.returncode, p.stderr[-2500:])
