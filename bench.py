@@ -269,6 +269,11 @@ def main():
                          "frameino_amd/graph_step.py; a crash inside a capture cannot be caught, so never by default)")
     ap.add_argument("--no-graph-probe", action="store_true",
                     help="N>1: skip the hipGraph replay of the best plan that runs after the line is printed")
+    ap.add_argument("--graph-probe-after-line", action="store_true",
+                    help="more than one rank: after the line is printed, also replay the best plan's step from a hipGraph and "
+                         "report to stderr.  The default with ONE rank (--force-shard rehearsal); with more ranks it has to be "
+                         "asked for: a capture over real links has never run here, a fault inside it cannot be caught and a "
+                         "hang would sit out --stall-s -- neither may cost a scaling run its exit status or its time")
     ap.add_argument("--force-shard", action="store_true",
                     help="rehearsal: take the N>1 code path (process group, sharded forward, collectives) with whatever "
                          "--gpus says, 1 included: one rank drives real RCCL communicators of size 1.  With --plan "
@@ -615,10 +620,11 @@ def main():
         dog.disarm()
         if rank == 0:
             print(line, flush=True)
-        if backend == "nccl" and not a.graph_probe and not a.no_graph_probe:
-            # Round 5: the best plan's step replayed from a hipGraph AFTER the line is out (default).  The call patterns were
-            # probed through RCCL communicators of ONE rank (frameino_amd/graph_step.py); with more ranks a capture has never
-            # run here, and a fault inside a capture cannot be caught -- so it cannot cost the line: the result goes to stderr.
+        if backend == "nccl" and not a.graph_probe and not a.no_graph_probe and (world == 1 or a.graph_probe_after_line):
+            # Round 5: the best plan's step replayed from a hipGraph AFTER the line is out (default with one rank, opt-in with
+            # more: --graph-probe-after-line).  The call patterns were probed through RCCL communicators of ONE rank
+            # (frameino_amd/graph_step.py); with more ranks a capture has never run here, and a fault inside a capture cannot
+            # be caught -- it cannot cost the line (the result goes to stderr), but it would cost the exit status.
             try:
                 from frameino_amd.graph_step import groups_capturable
                 bplan = best[1]
