@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from frameino_amd import _lib  # noqa: E402
 
 lib = _lib.lib()
-scratch = torch.zeros(64 + 2 * 256 * 4, device="cuda")        # 256 B + A and B operands of 256 lanes (8 bf16 each)
+scratch = torch.zeros(64 + 2 * 256 * 4 + 2 * 256 * 8, device="cuda")   # 256 B + A and B operands of 256 lanes (8 bf16 each) + fp8 ones (32 B each)
 fl = ctypes.c_double()
 samples, stop = [], False
 
@@ -42,12 +42,17 @@ def run(kind, wps, iters):
 th = threading.Thread(target=smi)
 th.start()
 g = torch.Generator(device="cuda").manual_seed(0)
-operands = scratch[64:].view(torch.bfloat16)
+operands = scratch[64:64 + 2 * 256 * 4].view(torch.bfloat16)
+operands8 = scratch[64 + 2 * 256 * 4:].view(torch.uint8)
 for data in ("zeros", "gaussian"):
     operands.copy_(torch.zeros_like(operands) if data == "zeros"
                    else torch.randn(operands.shape, device="cuda", generator=g).bfloat16())
+    # e4m3 bytes: random sign and mantissa, exponent field 5 .. 8 of 15 (|x| in [0.25, 4)): what a block-scaled activation looks like
+    r = torch.randint(0, 256, operands8.shape, device="cuda", generator=g)
+    e = torch.randint(5, 9, operands8.shape, device="cuda", generator=g)
+    operands8.copy_(torch.zeros_like(operands8) if data == "zeros" else ((r & 0x87) | (e << 3)).to(torch.uint8))
     print(f"--- operands: {data}")
-    for kind, nm in ((0, "32x32x16"), (1, "16x16x32")):
+    for kind, nm in ((0, "32x32x16"), (1, "16x16x32"), (2, "fp8 32x32x64 (block-scaled, scales 1.0)")):
         for wps in (1, 2):
             for iters, label in ((2000, "short (~1 ms)"), (400000, "long (~0.3 s)")):
                 run(kind, wps, 100)
