@@ -338,3 +338,29 @@ def test_full_size_decode_fp32_compute_vs_oracle_fp32_on_device(planes, min_psnr
            p, min_psnr, lower_is_better=False)
     record(f"wan_vae_decode_fp32_compute_{planes}planes_5_latent_frames_704x1280", f"rel_rms ({dt_s:.2f} s for 17 frames)", r, max_rel)
     assert p > min_psnr and r < max_rel, (p, r)
+
+
+@pytest.mark.parametrize("planes,max_rel", [(0, 2.5e-2), (3, 1e-4)])
+def test_full_size_encode_vs_oracle_fp32_on_device(planes, max_rel):
+    """The encoder at SIZE (app.py:586-590 encodes the 704x1280 conditions with this VAE in fp32): 9 frames of 704x1280 -> 3 latent
+    frames, the real Wan2.2 VAE widths, seeded random weights, bf16 compute and `set_compute_dtype(torch.float32)`, against
+    oracle/wan_vae.py executed in fp32 on the device; the compared quantity is the posterior's moments (mean | logvar)."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    from oracle import wan_vae as V
+    from tests.parity import record
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=7, device=DEV)
+    if planes:
+        vae.set_compute_dtype(torch.float32, planes=planes)
+    sd = {k: v.float() for k, v in vae._sd.items()}
+    x = torch.rand(1, 3, 9, 704, 1280, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)) * 2 - 1
+    with torch.no_grad():
+        got = vae.encode(x).latent_dist.parameters
+        ref = V.wan_vae_encode(sd, dict(WAN22_VAE_CFG), x)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (1, 96, 3, 44, 80) and torch.isfinite(got).all()
+    r = rel_rms(got, ref)
+    name = "bf16" if not planes else f"fp32_compute_{planes}planes"
+    print(f"encode 9 frames 704x1280, {name}: rel-RMS of the moments {r:.2e}")
+    record(f"wan_vae_encode_{name}_9_frames_704x1280", "rel_rms of the moments vs oracle fp32 on device", r, max_rel)
+    assert r < max_rel, r
