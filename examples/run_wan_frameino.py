@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--smoke", action="store_true", help="tiny random model + tiny VAE, 64x96, 5 frames")
     ap.add_argument("--repeat", type=int, default=1, help="generate the clip this many times (the first call is cold)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--vae-fp32", type=int, nargs="?", const=3, default=0, metavar="PLANES",
+                    help="run the VAE like the reference app does (app.py:157 loads it in fp32): fp32-compute mode on split-bf16 "
+                         "products, 3 (default) or 2 bf16 planes per fp32 operand -- `vae.set_compute_dtype(torch.float32)`")
     a = ap.parse_args()
 
     from frameino_amd import _lib
@@ -105,6 +108,8 @@ def main():
         transformer = build_model(cfg, dev)
         text_dim = cfg["text_dim"]
 
+    if a.vae_fp32:
+        vae.set_compute_dtype(torch.float32, planes=a.vae_fp32)
     pipe = WanImageToVideoPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=sched,
                                    transformer=transformer, expand_timesteps=True)
     t0 = time.perf_counter()
