@@ -70,18 +70,32 @@ def capture_error_mode(plan):
     return "thread_local" if plan is not None else "global"
 
 
+def _process_groups():
+    """Every process group this process holds (the default one and the plan's sub-groups)."""
+    import torch.distributed as dist
+    try:
+        return list(dist.distributed_c10d._world.pg_map.keys())
+    except AttributeError:
+        return [dist.group.WORLD]
+
+
 def drain_collectives(wait_s=None):
     """Call before a capture whenever a process group is alive: returns once c10d's watchdog threads hold no eager work.
 
-    Why (round 5, `tools/debug/loop_bench.sh`: 6 aborts in 30 runs of the forced-shard rehearsal, 0 in 60 with this): a watchdog
-    sweeps its list of issued collectives every 100 ms and `hipEventQuery`s each one's end event.  An eager step's collectives are
-    still on that list when the next step is captured right behind it, and as soon as the capture pulls the communicator's stream
-    in, HIP answers a query of an event recorded on that stream with `hipErrorCapturedEvent` ("operation not permitted on an event
-    last recorded in a capturing stream") -- the watchdog rethrows and the process dies with SIGABRT, whatever the capture mode.
+    Why (round 5, `tools/debug/loop_bench.sh`: 6 aborts in 30 runs of the forced-shard rehearsal): a watchdog sweeps its list of
+    issued collectives every 100 ms and `hipEventQuery`s each one's end event.  An eager step's collectives are still on that
+    list when the next step is captured right behind it, and as soon as the capture pulls the communicator's stream in, HIP
+    answers a query of an event recorded on that stream with `hipErrorCapturedEvent` ("operation not permitted on an event last
+    recorded in a capturing stream") -- the watchdog rethrows and the process dies with SIGABRT, whatever the capture mode.
     CUDA builds of torch wait for the pending work themselves when a capture begins; the ROCm build of torch 2.10 does not.
-    So: finish the GPU's work (every issued collective is then complete), and give the watchdogs three sweep periods to drop
-    them (`FINO_CAPTURE_DRAIN_S`, default 0.3 s -- once per captured loop).  c10d's flight recorder does not help: its "active"
-    entries are retired by whoever dumps them, not by the watchdog (tried: the abort came back)."""
+
+    Round 6: the wait is a CONDITION, not a sleep.  `ProcessGroup._wait_for_pending_works()` (c10d's
+    `ProcessGroupNCCL::waitForPendingWorks`, the loop CUDA builds run at `capture_begin`) returns when the backend's
+    `workMetaList_` -- exactly the list the watchdog sweeps -- and its completed-work list are empty.  It is called on every
+    process group of the process after a device synchronize (every issued collective has then completed on the GPU, so the
+    watchdog retires each one on its next sweep, however late that sweep is scheduled).  Round 5's fixed sleep of three sweep
+    periods remains only as the fallback for a torch build without that binding (`FINO_CAPTURE_DRAIN_S`, default 0.3 s per
+    process group), and `wait_s` adds a sleep on top for A/B rehearsals."""
     import os
     import time
     try:
@@ -91,7 +105,17 @@ def drain_collectives(wait_s=None):
     except (ImportError, RuntimeError):
         return
     torch.cuda.synchronize()
-    time.sleep(float(os.environ.get("FINO_CAPTURE_DRAIN_S", "0.3")) if wait_s is None else wait_s)
+    blind = 0
+    for pg in _process_groups():
+        wait = getattr(pg, "_wait_for_pending_works", None)
+        if wait is None:
+            blind += 1
+            continue
+        wait()
+    if blind:
+        time.sleep(blind * float(os.environ.get("FINO_CAPTURE_DRAIN_S", "0.3")))
+    if wait_s:
+        time.sleep(wait_s)
 
 
 class StepGraph:

@@ -42,6 +42,10 @@ class TokenShard:
         self.rank, self.ways, self.group, self.force = rank, ways, group, force
         self.exchange = exchange          # "kv": all-gather of K|V; "heads": all-to-all token shards <-> head shards
         self._buf = {}
+        import os
+        env = os.environ.get("FINO_KV_HEAD_GROUPS")
+        if env:
+            self.kv_head_groups = max(1, int(env))
         # attend to the LOCAL K/V chunk while the other ranks' chunks are still on the wire, then to what arrived, and
         # merge the partials (fino_attn_partial / fino_attn_merge): hides up to 1/ways of the attention under the gather.
 
@@ -77,8 +81,11 @@ class TokenShard:
     # kernel scatters k by head into [group][token][k_g | v_g] send blocks, v follows as a scattering copy instead of
     # staying where the projection wrote it) and attention launches of heads / groups heads each (24 heads x 13 q-blocks of a
     # 3080-row shard are 2 rounds of the CUs as one launch and as two).  1 = one gather.  tools/plan_sim.py with a modelled wire
-    # (FINO_PLAN_SIM_WIRE_GBPS) measures what it hides.
-    kv_head_groups = 2
+    # (FINO_PLAN_SIM_WIRE_GBPS) measures what it hides.  Round 6: the default is ONE gather -- the only evidence for two is a
+    # MODELLED wire (split N = 8: 61.9 -> 58.0 ms at 150 GB/s), and on the interleaved plan it measured a 2.3 ms loss; until a
+    # node run shows the win it is opt-in: `FINO_KV_HEAD_GROUPS=2`, or bench.py's plan probe "…-kvg2" which measures it on the
+    # real links and lets it win the line.
+    kv_head_groups = 1
 
     def kv_groups(self, heads):
         g = max(1, min(int(self.kv_head_groups), heads))
@@ -147,7 +154,10 @@ class TokenShard:
     # can -- also when the kernels around it run on side streams (tools/debug/rccl_capture_probe.py, round 5:
     # profiles/r05_rccl_capture_probe.txt).  So the pipeline names the step's own stream here: that stream waits for the
     # branch's producer kernels (an event), c10d forks its communicator stream from it, and the BRANCH's stream waits for the
-    # collective where the forward calls work.wait().  Eager and captured runs enqueue exactly the same dependencies.
+    # collective where the forward calls work.wait().  Round 6: the pipeline sets it only around a step that is being
+    # CAPTURED and resets it in a `finally` -- an eager interleaved step issues each branch's collectives from that branch's own
+    # stream again, so the two branches (and their two communicators) are not coupled through the main stream, and no stale
+    # capture stream survives a capture.  Results are bit-identical either way (the kernels and their order do not change).
     issue_stream = None
 
     def _issue(self, fn, t, async_op):

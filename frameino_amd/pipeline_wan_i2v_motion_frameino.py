@@ -314,31 +314,37 @@ class WanImageToVideoPipeline:
                 self._streams = (torch.cuda.Stream(), torch.cuda.Stream()) if x.is_cuda else (None, None)
             main = torch.cuda.current_stream() if x.is_cuda else None
             gens, outs = [], [None, None]
-            for shard in plan.shards:
-                # the branches' kernels run on the two side streams, their collectives are issued on the step's own stream
-                # (TokenShard.issue_stream: the call pattern a hipGraph capture of this step survives)
-                shard.issue_stream = main
-            for name, emb, shard in (("cond", st.pe, plan.shards[0]), ("uncond", st.ne, plan.shards[1])):
-                gens.append((name, tr.forward_steps(hidden_states=x, timestep=None, encoder_hidden_states=emb,
-                                                     return_dict=False, attention_kwargs=st.attention_kwargs,
-                                                     timestep_rows=rows, shard=shard)))
-            for s_ in self._streams:
-                if s_ is not None:
-                    s_.wait_stream(main)
-            alive = [True, True]
-            while any(alive):
-                for i, (name, g) in enumerate(gens):
-                    if not alive[i]:
-                        continue
-                    ctx_stream = torch.cuda.stream(self._streams[i]) if self._streams[i] is not None else _null_ctx()
-                    with ctx_stream, tr.cache_context(name):
-                        try:
-                            next(g)
-                        except StopIteration as done:
-                            outs[i], alive[i] = done.value[0][0], False
-            for s_ in self._streams:
-                if s_ is not None:
-                    main.wait_stream(s_)
+            # the branches' kernels run on the two side streams.  Inside a hipGraph capture their collectives are issued on the
+            # step's own stream (TokenShard.issue_stream: the only call pattern a capture of this step survives on this image);
+            # an eager step issues them from the branch's stream, which keeps the two branches independent of each other
+            capturing = bool(x.is_cuda and torch.cuda.is_current_stream_capturing())
+            try:
+                for shard in plan.shards:
+                    shard.issue_stream = main if capturing else None
+                for name, emb, shard in (("cond", st.pe, plan.shards[0]), ("uncond", st.ne, plan.shards[1])):
+                    gens.append((name, tr.forward_steps(hidden_states=x, timestep=None, encoder_hidden_states=emb,
+                                                         return_dict=False, attention_kwargs=st.attention_kwargs,
+                                                         timestep_rows=rows, shard=shard)))
+                for s_ in self._streams:
+                    if s_ is not None:
+                        s_.wait_stream(main)
+                alive = [True, True]
+                while any(alive):
+                    for i, (name, g) in enumerate(gens):
+                        if not alive[i]:
+                            continue
+                        ctx_stream = torch.cuda.stream(self._streams[i]) if self._streams[i] is not None else _null_ctx()
+                        with ctx_stream, tr.cache_context(name):
+                            try:
+                                next(g)
+                            except StopIteration as done:
+                                outs[i], alive[i] = done.value[0][0], False
+                for s_ in self._streams:
+                    if s_ is not None:
+                        main.wait_stream(s_)
+            finally:
+                for shard in plan.shards:
+                    shard.issue_stream = None
             pc, pu = outs
         elif plan is not None and plan.cfg_ways == 2 and st.cfg:
             # CFG branches on two rank groups; one exchange of noise_pred per step (frameino_amd/parallel.py)

@@ -14,7 +14,8 @@ csrc="$here/../../frameino_amd/csrc"
 srcdir="$csrc"
 if [ "$1" = "--experiments" ]; then
     shift
-    srcdir="$csrc/../csrc_exp"          # (a sibling of csrc/: the sources include ../../include/frameino_hip.h)
+    srcdir="$here/../../gpurun_out/debug/csrc_exp"   # scratch, outside the package (two levels under the root: the sources include ../../include/frameino_hip.h)
+    mkdir -p "$(dirname "$srcdir")"
     python3 "$here/strip_experiments.py" --apply "$srcdir" > /dev/null
 fi
 name=$1; src=$2; flags=$3
