@@ -404,6 +404,14 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 vblk[hidx, :, hidx, :] = kv[i, :kp, d:].reshape(kp, heads, dh).permute(1, 0, 2)
                 per_sample.append(o.gemm(blk.attn2.to_out[0].weight, vblk.view(heads * kp, d)))       # [D, heads*kp]
             val.w2.append(per_sample)
+        if dt == torch.float16:
+            # fp16 only (round 6): V W_o^T is STORED in the model dtype.  A text key with a large value vector and a vanishing
+            # probability is harmless in the reference's order -- (P.V) stays finite -- but an element of V W_o^T beyond 65504
+            # is inf here and P.inf = nan for every query.  One host read per prompt (this runs when the per-prompt cache is
+            # built, never inside a captured step): if anything left the range, this prompt keeps the ordinary out-projection.
+            finite = torch.stack([torch.isfinite(w).all() for layer in val.w2 for w in layer]).all()
+            if not bool(finite):
+                val.w2, val.pbuf, val.rrms = None, None, None
 
     def _text_kv(self, encoder_hidden_states, pk, lq=0, may_fold=False):
         """text_embedder (:185) + the 30 layers' attn2 K (after norm_k) and V: step-invariant, cached per

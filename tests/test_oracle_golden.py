@@ -246,3 +246,88 @@ def test_tile_blends_equal_the_reference_in_tree_loops(golden):
         e = int(a[f"extent_{i}"])
         assert torch.equal(V.blend_v(a[f"a_{i}"].clone(), a[f"b_{i}"].clone(), e), a[f"v_{i}"])
         assert torch.equal(V.blend_h(a[f"a_{i}"].clone(), a[f"b_{i}"].clone(), e), a[f"h_{i}"])
+
+
+# ---- round 6: fp16, the dtype the reference's canonical callers load (app.py:156; run_cogvideox_FrameIn_mass_evaluation.py:92-94) ----
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+def _fp16_sd(sd):
+    return {k: (v.float() if any(s in k for s in W.FP32_KEEP) else v.half()) for k, v in sd.items()}
+
+
+def test_wan_fp16_reference_runs_and_the_oracle_in_fp16(golden):
+    """tests/golden/wan_dit_tiny_fp16.npz: the reference's own fp16 forward (fp32 islands kept, as `from_pretrained(torch_dtype=
+    float16)` leaves them).  It sits 1e-3 from its fp32 run -- the yardstick for the HIP path's fp16 bound (5e-3) -- and the
+    oracle run in fp16 with the same rounding points lands on it (the two differ by the CPU kernels' summation order only)."""
+    cfg, sd, a = golden("wan_dit_tiny")
+    _, _, h = golden("wan_dit_tiny_fp16")
+    sdh = _fp16_sd(sd)
+    for ts, y in (("ts_scalar", "y_scalar"), ("ts_tok", "y_tok"), ("ts_many", "y_many")):
+        ref_h = h[y + "_fp16"]
+        assert ref_h.dtype == torch.float16 and _rel(ref_h, a[y]) < 2e-3
+        out = W.wan_forward(sdh, cfg, a["x"].half(), a[ts], a["txt"].half())
+        assert out.dtype == torch.float16 and _rel(out, ref_h) < 1e-3, (ts, _rel(out, ref_h))
+    _, sdb, b = golden("wan_block_tiny")
+    sdbh = _fp16_sd(sdb)
+    rot = (b["rot_cos"], b["rot_sin"])
+    hh, ch = b["h"].half(), b["ctx"].half()
+    got = {"a_self": W.wan_attention(sdbh, "blocks.0.attn1", cfg["num_attention_heads"], cfg["eps"], hh, None, rot),
+           "a_cross": W.wan_attention(sdbh, "blocks.0.attn2", cfg["num_attention_heads"], cfg["eps"], hh, ch, None),
+           "b4": W.wan_block(sdbh, "blocks.0", cfg, hh, ch, b["temb4"], rot),
+           "b3": W.wan_block(sdbh, "blocks.0", cfg, hh, ch, b["temb3"], rot)}
+    for k, out in got.items():
+        assert _rel(h[k + "_fp16"], b[k]) < 2e-3
+        assert out.dtype == torch.float16 and _rel(out, h[k + "_fp16"]) < 1e-3, (k, _rel(out, h[k + "_fp16"]))
+
+
+@pytest.mark.parametrize("case,modpath", [("ffn", "ffn.net.0.proj"), ("attn", "attn1.to_out.0")])
+def test_wan_fp16_saturation_fixture_and_the_oracle_in_fp16(golden, case, modpath):
+    """one neuron of the last block scaled until 9 of 72 tokens overflow in the reference's fp16 run (make_golden.py::gen_wan_dit):
+    the fixture has nan tokens and finite tokens, and the oracle run in fp16 returns nan / finite in exactly the same elements"""
+    cfg, sd, a = golden("wan_dit_tiny")
+    _, _, h = golden("wan_dit_tiny_fp16")
+    gain, layer, j = float(h[f"sat_{case}_gain"]), int(h[f"sat_{case}_layer"]), int(h[f"sat_{case}_neuron"])
+    ref = h[f"y_tok_fp16_sat_{case}"].float()
+    bad_ref = ~torch.isfinite(ref)
+    assert 0 < int(bad_ref.sum()) < ref.numel() // 2
+    sd = {k: v.clone() for k, v in sd.items()}
+    for leaf in ("weight", "bias"):
+        sd[f"blocks.{layer}.{modpath}.{leaf}"][j] *= gain
+    out = W.wan_forward(_fp16_sd(sd), cfg, a["x"].half(), a["ts_tok"], a["txt"].half()).float()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(torch.isinf(out), torch.isinf(ref))
+    fin = ~bad_ref
+    assert _rel(out[fin], ref[fin]) < 1e-3
+
+
+def test_cog_fp16_reference_runs_and_the_oracle_in_fp16(golden):
+    from oracle import cog_dit as C
+    cfg, sd, a = golden("cog_dit_tiny")
+    _, _, h = golden("cog_dit_tiny_fp16")
+    cfg = _cog_cfg(cfg)
+    sdh = {k: v.half() for k, v in sd.items()}
+    for tag in ("def", "rsz"):
+        ref_h = h[f"y_{tag}_fp16"]
+        assert ref_h.dtype == torch.float16 and _rel(ref_h, a[f"y_{tag}"]) < 2e-3
+        out = C.cog_forward(sdh, cfg, a[f"x_{tag}"].half(), a[f"txt_{tag}"].half(), a[f"ts_{tag}"], (a[f"cos_{tag}"], a[f"sin_{tag}"]))
+        assert out.dtype == torch.float16 and _rel(out, ref_h) < 1.5e-3, (tag, _rel(out, ref_h))
+
+
+def test_pipeline_fp16_fixtures_are_close_to_the_fp32_runs(golden):
+    """the reference pipelines' own reduced-precision runs (fp16 DiT + fp32 VAE for Wan = app.py:156-157; all-fp16 for CogVideoX =
+    the evaluation script): what the callers' precision mix costs against the all-fp32 run on these fixtures -- the yardsticks the
+    `-m gpu` tests of tests/test_fp16_gpu.py hold the HIP pipelines to"""
+    _, _, a = golden("wan_pipe_tiny")
+    _, _, u = golden("wan_pipe_unipc_tiny")
+    _, _, h = golden("wan_pipe_fp16_tiny")
+    assert _rel(h["out_latents_fp16dit"], a["out_latents"]) < 5e-3
+    assert _rel(h["out_latents_unipc_fp16dit"], u["out_latents"]) < 5e-3
+    assert float((h["out_video_fp16dit"] - a["out_video"]).pow(2).mean()) < 1e-5            # > 50 dB
+    _, _, c = golden("cog_pipe_tiny")
+    _, _, ch = golden("cog_pipe_fp16_tiny")
+    assert ch["out_ddim_fp16"].dtype == torch.float16
+    assert _rel(ch["out_ddim_fp16"], c["out_ddim"]) < 8e-3 < _rel(c["out_ddim_bf16"], c["out_ddim"])
+    assert _rel(ch["out_ddim_dynamic_cfg_fp16"], c["out_ddim_dynamic_cfg"]) < 8e-3
+    assert float((ch["out_video_fp16"] - c["out_video"]).pow(2).mean()) < 1e-4             # > 40 dB

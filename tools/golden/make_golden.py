@@ -123,6 +123,57 @@ def gen_wan_dit():
     yb = mb(x.bfloat16(), ts_tok, txt.bfloat16(), return_dict=False)[0]
     save("wan_dit_tiny_bf16", y_tok_bf16=yb)
 
+    # round 6: the same model the way the canonical caller loads it -- app.py:156 `torch_dtype=torch.float16` (from_pretrained
+    # keeps `_keep_in_fp32_modules` in fp32 for any half dtype) -- scalar / {0,t} / general per-token timesteps, and the
+    # two attention calls + the block in isolation.  Outputs only: weights and inputs are wan_dit_tiny's / wan_block_tiny's.
+    mh = WanTransformer3DModel(**{k: v for k, v in WAN_TINY.items()}).eval()
+    mh.load_state_dict(m.state_dict())
+    for n, p in mh.named_parameters():
+        if not any(k in n for k in keep):
+            p.data = p.data.to(torch.float16)
+    xh, th = x.half(), txt.half()
+    bh = mh.blocks[0]
+    hh, ch = h.half(), ctx.half()
+    # SATURATION (fp16 ends at 65504): which elements of the reference's own fp16 run come out inf / nan when an intermediate
+    # leaves the range is part of its behaviour at this dtype.  Two model-level cases on wan_dit_tiny's inputs (ts_tok), each with
+    # ONE weight of the LAST block scaled (in fp32, then cast) so that only a handful of intermediate elements overflow; from there
+    # to the output everything is per token (cross-attention queries, FFN, norm_out, proj_out), so the other tokens stay finite:
+    #   ffn : blocks.1.ffn.net.0.proj x g -> a few outputs of the FFN's first linear round to +-inf; gelu(+inf) = inf, gelu(-inf) = nan
+    #         (:345); those ROWS leave the second linear as inf / nan and the gated residual (:348) keeps them
+    #   attn: blocks.1.attn1.to_out.0 x g -> a few elements of attn_output (fp16) or of hidden + attn_output * gate (:336) overflow;
+    #         norm2 (:339) turns such a row into nan
+    import copy
+    sat = {}
+    with torch.no_grad():
+        last = len(m.blocks) - 1
+        pre = {}
+        hk1 = m.blocks[last].ffn.net[0].proj.register_forward_hook(lambda mod, i, o: pre.__setitem__("ffn", o.detach()))
+        hk2 = m.blocks[last].attn1.to_out[0].register_forward_hook(lambda mod, i, o: pre.__setitem__("attn", o.detach()))
+        m(x, ts_tok, txt, return_dict=False)                       # the fp32 model's own pre-activations set the gains
+        hk1.remove(); hk2.remove()
+        for name, modpath, nth in (("ffn", f"blocks.{last}.ffn.net.0.proj", 8), ("attn", f"blocks.{last}.attn1.to_out.0", 8)):
+            # ONE output neuron j of that linear is scaled (row j of the weight and bias[j]): the one whose |pre-activation|,
+            # sorted over the tokens, has the widest gap after the 9th token -- the threshold sits in the middle of that gap, so
+            # that fp16 rounding upstream cannot move a token across it, and 9 of the 72 tokens overflow
+            v = pre[name].abs().flatten(0, -2).sort(dim=0, descending=True).values      # [tokens, neurons]
+            j = int((v[nth] / v[nth + 1]).argmax())
+            gain = float(65520.0 / (v[nth, j] * v[nth + 1, j]).sqrt())
+            ms = copy.deepcopy(mh)
+            lin, lin32 = ms.get_submodule(modpath), m.get_submodule(modpath)
+            lin.weight[j].copy_((lin32.weight[j] * gain).half())
+            lin.bias[j].copy_((lin32.bias[j] * gain).half())
+            sat[f"sat_{name}_neuron"] = np.array(j)
+            print(f"  neuron {j}: gap {float(v[nth, j] / v[nth + 1, j]):.3f}")
+            out = ms(xh, ts_tok, th, return_dict=False)[0]
+            sat[f"y_tok_fp16_sat_{name}"] = out
+            sat[f"sat_{name}_gain"] = np.array(gain)
+            sat[f"sat_{name}_layer"] = np.array(last)
+            print(f"  saturation case {name}: gain {gain:g}; inf {int(torch.isinf(out).sum())}, nan {int(torch.isnan(out).sum())} of {out.numel()}")
+    save("wan_dit_tiny_fp16", y_scalar_fp16=mh(xh, ts_scalar, th, return_dict=False)[0],
+         y_tok_fp16=mh(xh, ts_tok, th, return_dict=False)[0], y_many_fp16=mh(xh, ts_many, th, return_dict=False)[0],
+         a_self_fp16=bh.attn1(hidden_states=hh, rotary_emb=rot), a_cross_fp16=bh.attn2(hidden_states=hh, encoder_hidden_states=ch),
+         b4_fp16=bh(hh, ch, temb4, rot), b3_fp16=bh(hh, ch, temb3, rot), **sat)
+
 
 # ----------------------------------------------------------------------------------- Wan pipeline
 def _ftfy_stand_in():
@@ -214,6 +265,25 @@ def gen_wan_pipe():
     text = {"te/" + k: v for k, v in te.state_dict().items()}
     text.update(prompt=np.array(WAN_PROMPT), negative_prompt=np.array(""), prompt_embeds_from_text=pe_t,
                 negative_embeds_from_text=ne_t, out_latents_prompt=out_prompt)
+    # round 6: the app's precision mix -- app.py:156-157: the DiT in fp16 (fp32 islands kept), the VAE in fp32; the pipeline
+    # casts prompt embeddings to the DiT's dtype (:781-783) -- Euler and UniPC-driven.  Outputs only (wan_pipe_tiny's weights).
+    import copy
+    dit_h = copy.deepcopy(dit)
+    keep = WanTransformer3DModel._keep_in_fp32_modules
+    for n, p in dit_h.named_parameters():
+        if not any(k in n for k in keep):
+            p.data = p.data.to(torch.float16)
+    pipe_h = WanImageToVideoPipeline(tokenizer=None, text_encoder=None, vae=vae, scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0),
+                                     transformer=dit_h, expand_timesteps=True)
+    kw_h = dict(image=PIL.Image.fromarray(img), prompt_embeds=pe, negative_prompt_embeds=ne, traj_tensor=traj, ID_tensor=idt,
+                height=H, width=W, num_frames=F, guidance_scale=5.0)
+    lat_h = pipe_h(**kw_h, num_inference_steps=steps, latents=lat0.clone(), output_type="latent").frames
+    vid_h = pipe_h(**kw_h, num_inference_steps=steps, latents=lat0.clone(), output_type="np").frames
+    pipe_h.scheduler = UniPCMultistepScheduler(flow_shift=5.0)
+    lat_hu = pipe_h(**kw_h, num_inference_steps=6, latents=lat0.clone(), output_type="latent").frames
+    np.savez_compressed(os.path.join(OUT, "wan_pipe_fp16_tiny.npz"), out_latents_fp16dit=to_np(lat_h), out_video_fp16dit=to_np(vid_h),
+                        out_latents_unipc_fp16dit=to_np(lat_hu))
+    print("wrote wan_pipe_fp16_tiny.npz (outputs only: weights and inputs are wan_pipe_tiny's)")
     sched.set_timesteps(steps)
     sd = {"dit." + k: v for k, v in dit.state_dict().items()}
     sd.update({"vae." + k: v for k, v in vae.state_dict().items()})
@@ -292,6 +362,16 @@ def gen_cog_dit():
     arrays["y_def_fused"] = yf
     sd = {k: v for k, v in m.state_dict().items() if "to_qkv" not in k}
     save("cog_dit_tiny", cfg=COG_TINY, sd=sd, **arrays)
+    # round 6: all-fp16, the way test_code/run_cogvideox_FrameIn_mass_evaluation.py:92 loads it (this model has no fp32 islands:
+    # no _keep_in_fp32_modules in cogvideox_transformer_3d.py).  Outputs only.
+    import copy
+    mh = copy.deepcopy(m).to(torch.float16)
+    outs = {}
+    for tag in ("def", "rsz"):
+        outs[f"y_{tag}_fp16"] = mh(hidden_states=arrays[f"x_{tag}"].half(), encoder_hidden_states=arrays[f"txt_{tag}"].half(),
+                                   timestep=arrays[f"ts_{tag}"], image_rotary_emb=(arrays[f"cos_{tag}"], arrays[f"sin_{tag}"]),
+                                   return_dict=False)[0]
+    save("cog_dit_tiny_fp16", **outs)
 
 
 def gen_cog_dit_s1():
@@ -492,6 +572,18 @@ def gen_cog_pipe():
     # the reference's OWN bf16 video: what a reduced-precision run of the same pipeline scores against its fp32 video is
     # the yardstick for the HIP pipeline's video
     video_b = run(CogVideoXDDIMScheduler(), **dict(kwb, output_type="np"))
+    # round 6: all-fp16 -- transformer, VAE and prompt embeddings in fp16 exactly as the evaluation script loads them
+    # (test_code/run_cogvideox_FrameIn_mass_evaluation.py:92-94,106).  Outputs only -> cog_pipe_fp16_tiny.npz.
+    dit_h = copy.deepcopy(dit).to(torch.float16)
+    vae_h = AutoencoderKLCogVideoX(**COG_PIPE_VAE).eval()
+    vae_h.load_flat_state_dict({k: v.half() for k, v in vae_sd.items()})
+    kwh = dict(dit=dit_h, vae=vae_h, pe=pe.half(), ne=ne.half(), lat0=lat0.half(), output_type="latent")
+    out_ddim_h = run(CogVideoXDDIMScheduler(), **kwh)
+    out_dyn_h = run(CogVideoXDDIMScheduler(), use_dynamic_cfg=True, **kwh)
+    out_dpm_h = run(CogVideoXDPMScheduler(), generator=torch.Generator().manual_seed(11), **kwh)
+    video_h = run(CogVideoXDDIMScheduler(), **dict(kwh, output_type="np"))
+    save("cog_pipe_fp16_tiny", out_ddim_fp16=out_ddim_h, out_ddim_dynamic_cfg_fp16=out_dyn_h, out_dpm_fp16=out_dpm_h,
+         out_video_fp16=video_h)
     x0 = seen["model_input0"]                                       # [2, 4, 48, 8, 8] = [noisy + ID | first frame + 0 | traj + 0]
     print("placeholder modules served:", sorted(set(_PlaceholderFinder.served)))
     sd = {"dit." + k: v for k, v in dit.state_dict().items()}
