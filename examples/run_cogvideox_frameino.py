@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--frame-out", action="store_true", help="the FrameOut evaluation: no identity reference")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 linears (reduced precision, opt-in)")
     ap.add_argument("--fp8-attention", action="store_true", help="fp8 (e4m3) attention operands (reduced precision, opt-in)")
+    ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16",
+                    help="dtype of transformer, VAE and text encoder.  Default fp16 = what the evaluation script loads all three in "
+                         "(test_code/run_cogvideox_FrameIn_mass_evaluation.py:92-94,106)")
     ap.add_argument("--smoke", action="store_true", help="tiny random model + tiny VAE, 64x96, 9 frames")
     ap.add_argument("--no-tiling", action="store_true", help="random-weight run: leave the VAE's tiling off (the evaluation "
                                                               "script switches it on)")
@@ -71,21 +74,22 @@ def main():
     from frameino_amd.schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler
     _lib.load()
     dev = torch.device("cuda")
+    dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     sched = CogVideoXDPMScheduler() if a.scheduler == "dpm" else CogVideoXDDIMScheduler()
     tokenizer = text_encoder = None
     if a.ckpt:
         # the loader lines of the evaluation script with only the imports changed (tests/test_loading_cpu.py replays them)
         from frameino_amd.cogvideox_transformer_3d import CogVideoXTransformer3DModel
-        transformer = CogVideoXTransformer3DModel.from_pretrained(os.path.join(a.ckpt, "transformer"), torch_dtype=torch.bfloat16)
-        vae = AutoencoderKLCogVideoX.from_pretrained(a.ckpt, subfolder="vae", torch_dtype=torch.bfloat16)
+        transformer = CogVideoXTransformer3DModel.from_pretrained(os.path.join(a.ckpt, "transformer"), torch_dtype=dt)
+        vae = AutoencoderKLCogVideoX.from_pretrained(a.ckpt, subfolder="vae", torch_dtype=dt)
         vae.enable_slicing()
         vae.enable_tiling()
         if os.path.isdir(os.path.join(a.ckpt, "text_encoder")):
             from transformers import AutoTokenizer, T5EncoderModel
             tokenizer = AutoTokenizer.from_pretrained(os.path.join(a.ckpt, "tokenizer"))
-            text_encoder = T5EncoderModel.from_pretrained(os.path.join(a.ckpt, "text_encoder"), torch_dtype=torch.bfloat16).to(dev)
+            text_encoder = T5EncoderModel.from_pretrained(os.path.join(a.ckpt, "text_encoder"), torch_dtype=dt).to(dev)
         pipe = CogVideoXImageToVideoPipeline.from_pretrained(a.ckpt, text_encoder=text_encoder, tokenizer=tokenizer,
-                                                             transformer=transformer, vae=vae, torch_dtype=torch.bfloat16)
+                                                             transformer=transformer, vae=vae, torch_dtype=dt)
         pipe.to("cuda")
         text_dim = transformer.config.text_embed_dim
     else:
@@ -98,8 +102,8 @@ def main():
             cfg.update(num_attention_heads=2, num_layers=2, text_embed_dim=64, time_embed_dim=64,
                        sample_height=a.height // 8, sample_width=a.width // 8, sample_frames=a.frames)
             vae_kw = dict(block_out_channels=(32, 64, 64, 128), layers_per_block=1, norm_num_groups=8)
-        transformer = random_cog_model(cfg, dev)
-        vae = AutoencoderKLCogVideoX(**vae_kw).random_init_(seed=2, device=dev)
+        transformer = random_cog_model(cfg, dev, dtype=dt)
+        vae = AutoencoderKLCogVideoX(**vae_kw).random_init_(seed=2, device=dev, dtype=dt)
         if not a.no_tiling:
             # as the evaluation script does (test_code/run_cogvideox_FrameIn_mass_evaluation.py:95-96): at 480 x 720 the tiles
             # (240 x 360, overlapping) are active in every encode and in the decode

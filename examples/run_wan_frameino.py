@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--smoke", action="store_true", help="tiny random model + tiny VAE, 64x96, 5 frames")
     ap.add_argument("--repeat", type=int, default=1, help="generate the clip this many times (the first call is cold)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16",
+                    help="the DiT's dtype.  Default fp16 = what the reference app loads it in (app.py:156: "
+                         "`WanTransformer3DModel.from_pretrained(..., torch_dtype=torch.float16)`, fp32 islands kept); bf16 is what "
+                         "bench.py's headline times (the two run within 1 %% of each other)")
     ap.add_argument("--vae-fp32", type=int, nargs="?", const=3, default=0, metavar="PLANES",
                     help="run the VAE like the reference app does (app.py:157 loads it in fp32): fp32-compute mode on split-bf16 "
                          "products, 3 (default) or 2 bf16 planes per fp32 operand -- `vae.set_compute_dtype(torch.float32)`")
@@ -65,6 +69,7 @@ def main():
     from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler, UniPCMultistepScheduler
     _lib.load()
     dev = torch.device("cuda")
+    dit_dtype = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     sched = UniPCMultistepScheduler(flow_shift=5.0) if a.scheduler == "unipc" else FlowMatchEulerDiscreteScheduler(shift=5.0)
 
     tokenizer = text_encoder = None
@@ -78,8 +83,9 @@ def main():
         for sub, assumed, cls in (("transformer", WAN22_5B_CFG, _T), ("vae", WAN22_VAE_CFG, _V)):
             for line in config_report(read_config(os.path.join(a.ckpt, sub)), assumed, cls, f"{sub}/config.json"):
                 print("[config]", line)
-        transformer = load_wan_transformer(os.path.join(a.ckpt, "transformer"), torch.bfloat16, dev)
-        vae = load_wan_vae(os.path.join(a.ckpt, "vae"), torch.bfloat16, dev)
+        transformer = load_wan_transformer(os.path.join(a.ckpt, "transformer"), dit_dtype, dev)
+        # (app.py:157 loads the VAE in fp32: with --vae-fp32 the interface dtype is fp32 too, not only the arithmetic)
+        vae = load_wan_vae(os.path.join(a.ckpt, "vae"), torch.float32 if a.vae_fp32 else torch.bfloat16, dev)
         if os.path.isfile(os.path.join(a.ckpt, "scheduler", "scheduler_config.json")):
             sched = load_scheduler(os.path.join(a.ckpt, "scheduler"))
             print("[config] scheduler from the checkpoint:", type(sched).__name__, dict(sched.config))
@@ -105,7 +111,7 @@ def main():
             from frameino_amd.configs import WAN22_5B_CFG, WAN22_VAE_CFG
             cfg = dict(WAN22_5B_CFG)
             vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=2, device=dev)
-        transformer = build_model(cfg, dev)
+        transformer = build_model(cfg, dev, dtype=dit_dtype)
         text_dim = cfg["text_dim"]
 
     if a.vae_fp32:

@@ -42,6 +42,25 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) s += acc[t][j];
+    } else if constexpr (KIND == 3) {
+        // the same loop on fp16 operands (the caller fills the SAME 16 bytes per lane with fp16 values): what the matrix pipe
+        // sustains under the cap at the dtype the reference app loads the DiT in -- 10 mantissa bits toggle instead of 7
+        const f16x8_t ah = __builtin_bit_cast(f16x8_t, a), bh = __builtin_bit_cast(f16x8_t, b);
+        f32x16_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += acc[t][j];
     } else if constexpr (KIND == 0) {
         f32x16_t acc[4];
 #pragma unroll
@@ -80,12 +99,13 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
 
 // kind 0: 32x32x16 (16 per iteration), kind 1: 16x16x32 (32 per iteration); both = 524288 FLOP per wave-iteration.
 // kind 2: 16 x v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3 operands (scales 1.0) = 2097152 FLOP per wave-iteration.
+// kind 3: kind 0's loop with v_mfma_f32_32x32x16_f16 (the operand bytes are read as fp16).
 // scratch: >= 256 B + 2 x 256 x 16 B; bytes 256.. hold the A and B operands of the 256 lanes (caller-filled); kind 2 reads its
 // 2 x 256 x 32 B of fp8 operands behind them (scratch >= 256 + 8192 + 16384 B).
 // blocks of 256 threads (one wave per SIMD); waves_per_simd in {1, 2} -> blocks = CUs * waves_per_simd.  Returns the FLOPs
 // launched in *flops.
 extern "C" int fino_diag_mfma_peak(int kind, int waves_per_simd, int iters, void* scratch, double* flops, void* stream) {
-    FINO_CHECK(kind >= 0 && kind <= 2 && (waves_per_simd == 1 || waves_per_simd == 2) && iters > 0 && scratch && flops,
+    FINO_CHECK(kind >= 0 && kind <= 3 && (waves_per_simd == 1 || waves_per_simd == 2) && iters > 0 && scratch && flops,
                FINO_ERR_ARG, "fino_diag_mfma_peak: bad arguments");
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fino_current_device()) != hipSuccess || cus <= 0)
@@ -95,6 +115,8 @@ extern "C" int fino_diag_mfma_peak(int kind, int waves_per_simd, int iters, void
         mfma_peak_kernel<0><<<blocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
     else if (kind == 1)
         mfma_peak_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
+    else if (kind == 3)
+        mfma_peak_kernel<3><<<blocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
     else
         mfma_peak_kernel<2><<<blocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
     FINO_LAUNCH_CHECK();

@@ -480,7 +480,8 @@ int fino_u8_hwc_to_chw_unit(const void* src, float* dst, int height, int width, 
 /* ---- diagnostics (tools/ only) --------------------------------------------------------------------------------
  * Dense MFMA rate with nothing else running: `iters` x 16 independent 32x32x16 (kind 0) / 32 independent 16x16x32
  * (kind 1) bf16 MFMAs per wave from registers -- or (kind 2) 16 block-scaled fp8 MFMAs 32x32x64 on e4m3 operands with unit scales,
- * whose 2 x 256 x 32 operand bytes follow the bf16 ones in `scratch` --, waves_per_simd in {1, 2} on every SIMD of the device.  *flops = FLOPs
+ * whose 2 x 256 x 32 operand bytes follow the bf16 ones in `scratch`; (kind 3) kind 0's loop on fp16 operands (v_mfma_f32_32x32x16_f16: the
+ * same operand bytes read as fp16) --, waves_per_simd in {1, 2} on every SIMD of the device.  *flops = FLOPs
  * launched; time it with events.  What the board sustains under its power cap -- the ceiling of every MFMA-bound
  * kernel here. */
 int fino_diag_mfma_peak(int kind, int waves_per_simd, int iters, void* scratch, double* flops, void* stream);

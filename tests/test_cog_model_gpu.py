@@ -474,8 +474,8 @@ def test_baseline_config1_ten_steps_stage1_pipeline_vs_oracle_on_device():
     assert out.shape == ref.shape == (1, F_, C_, h, w) and torch.isfinite(out.float()).all() and r < 3e-2, r
 
 
-@pytest.mark.parametrize("extra", [[], ["--frame-out", "--scheduler", "ddim"], ["--mxfp8", "--fp8-attention"]],
-                         ids=["frame-in-dpm", "frame-out-ddim", "fp8-path"])
+@pytest.mark.parametrize("extra", [[], ["--frame-out", "--scheduler", "ddim"], ["--mxfp8", "--fp8-attention"], ["--dtype", "bf16"]],
+                         ids=["frame-in-dpm (all-fp16: the evaluation script's dtypes)", "frame-out-ddim", "fp8-path", "bf16"])
 def test_cog_example_script_smoke(extra):
     """examples/run_cogvideox_frameino.py --smoke (the evaluation scripts' call, test_code/run_cogvideox_FrameIn_mass_evaluation.py
     :203-213): condition builders -> CogVideoX VAE encodes -> dynamic-CFG loop -> VAE decode -> PIL frames, tiny shapes."""

@@ -219,13 +219,15 @@ def test_stage1_pipeline_no_id_frame_vs_oracle_loop(golden):
     assert rel_rms(out, ref) < 5e-2
 
 
-def test_example_script_smoke():
+@pytest.mark.parametrize("extra", [[], ["--vae-fp32"], ["--dtype", "bf16"]],
+                         ids=["fp16 DiT (app.py:156)", "fp16 DiT + fp32-compute VAE (app.py:156-157)", "bf16"])
+def test_example_script_smoke(extra):
     """examples/run_wan_frameino.py --smoke: condition builder -> VAE encodes -> UniPC loop -> VAE decode, tiny shapes."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_wan_frameino.py"), "--smoke"],
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_wan_frameino.py"), "--smoke"] + extra,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "clip (5 frames 64x96" in r.stdout
