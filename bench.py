@@ -315,7 +315,8 @@ def main():
 
     cfg = dict(WAN22_5B_CFG)
     if a.workload == "tiny":
-        cfg.update(num_attention_heads=2, num_layers=2, ffn_dim=512, text_dim=64, in_channels=8, out_channels=4)
+        # (8 heads: the 8-rank rehearsal can then trade heads on 4 and on 8 token shards)
+        cfg.update(num_attention_heads=8, num_layers=2, ffn_dim=512, text_dim=64, in_channels=8, out_channels=4)
     if a.layers:
         cfg["num_layers"] = a.layers
     fg, lh, lw = WORKLOADS[a.workload]
@@ -348,6 +349,10 @@ def main():
                 plans[name] = pl
             if a.exchange in ("auto", "heads") and heads_ok:
                 plans[name + "-heads"] = pl.with_exchange("heads")
+            # the K|V gather in two head groups (attention of group 0 under the gather of group 1): only a MODELLED wire says it
+            # wins (split plan, >= 4 token shards), so it is a probe on the real links, not a default
+            if a.exchange == "auto" and name == "split" and pl.token_ways >= 4 and nheads % 2 == 0:
+                plans[name + "-kvg2"] = pl.with_kv_groups(2)
         shard_pipeline(pipe, rank, world, plan=next(iter(plans.values())))
         dog.disarm()
     pipe.use_hip_graph = a.graph

@@ -301,9 +301,19 @@ class ParallelPlan:
         return ParallelPlan(self.rank, self.world, self.cfg_ways, self.token_ways, self.token_group, self.cfg_group,
                             self.token_group_b, exchange)
 
+    def with_kv_groups(self, groups):
+        """the same plan with the K|V all-gather cut into `groups` head groups (TokenShard.kv_head_groups; bench.py probes it)"""
+        p = self.with_exchange("kv")
+        for sh in (p.shards or (p.shard,)):
+            sh.kv_head_groups = int(groups)
+        p.kv_groups = int(groups)
+        return p
+
+    kv_groups = 1
+
     @property
     def desc(self):
-        tail = "-heads" if self.exchange == "heads" else ""
+        tail = "-heads" if self.exchange == "heads" else ("" if self.kv_groups <= 1 else f"-kvg{self.kv_groups}")
         if self.interleave:
             return f"token{self.token_ways}x2branches-interleaved{tail}"
         return f"cfg{self.cfg_ways}xtoken{self.token_ways}{tail}"

@@ -46,6 +46,28 @@ def test_bare_command_two_gloo_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bare_command_eight_gloo_ranks_on_one_gpu():
+    """The machine the driver will use is 8 ranks: the bare `bench.py --gpus 8` starts its 8 ranks itself, builds every communicator
+    of both plans in the same order on every rank (split: 2 token groups of 4 + 4 cfg pairs; interleave: 2 groups of 8), measures
+    split-kv in full, probes the other plan x exchange combinations, and prints exactly ONE line.  gloo on the one GPU: the
+    rehearsal of the launch, the groups and the probe protocol -- not of the links."""
+    import time
+    t0 = time.time()
+    p, lines = run_bench(["--gpus", "8", "--workload", "tiny", "--steps", "2", "--warmup", "1"], {"FINO_DIST_BACKEND": "gloo"},
+                         timeout=600)
+    took = time.time() - t0
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-3000:])
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 8 and c["ranks_seen"] == 8 and c["rccl_ranks"] == 8 and c["backend"] == "gloo"
+    probes = c["plan_probe_ms_per_step"]
+    assert set(probes) == {"cfg2xtoken4", "cfg2xtoken4-heads", "cfg2xtoken4-kvg2", "token8x2branches-interleaved",
+                           "token8x2branches-interleaved-heads"}, probes
+    assert all(v > 0 for v in probes.values()) and c["parallelism"] in probes
+    assert took < 240, took                    # (120 s of it is the budget of the run itself; the rest is 8 cold interpreter starts)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("plan,exchange", [("split", "kv"), ("interleave", "kv"), ("interleave", "heads"), ("split", "heads")])
 def test_forced_shard_path_through_rccl_of_one_rank(plan, exchange):
     p, lines = run_bench(["--gpus", "1", "--force-shard", "--plan", plan, "--exchange", exchange, "--workload", "tiny",

@@ -31,11 +31,11 @@ def _run(pipe, a):
                         a["prompt_embeds"], a["negative_embeds"], float(a["guidance"]), int(a["steps"]))
 
 
-def _four_head_case():
-    """a seeded random 4-head model (the golden model has 2 heads: 4 token shards cannot trade them) and the golden
-    run's inputs; the oracle here is the same model in one process"""
+def _four_head_case(heads=4):
+    """a seeded random 4-head (8-head) model (the golden model has 2 heads: 4 / 8 token shards cannot trade them) and the
+    golden run's inputs; the oracle here is the same model in one process"""
     cfg, sd, a = load_golden("wan_pipe_tiny")
-    cfg = dict(cfg, num_attention_heads=4)
+    cfg = dict(cfg, num_attention_heads=heads)
     from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
     from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
     from frameino_amd.transformer_wan import WanTransformer3DModel
@@ -61,7 +61,7 @@ def _worker(rank, world, port, cfg_parallel, q, mode="split", exchange="kv", fou
     try:
         from frameino_amd.parallel import shard_pipeline
         if four_heads:
-            pipe, a = _four_head_case()
+            pipe, a = _four_head_case(4 if four_heads is True else int(four_heads))
         else:
             cfg, sd, a = load_golden("wan_pipe_tiny")
             pipe = _build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")})
@@ -162,6 +162,30 @@ def test_four_token_shards_of_a_four_head_model(exchange, desc):
     for rank, d, out in _spawn(4, (True, "interleave", exchange, True)):
         assert d == desc
         torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode,exchange,heads,desc", [
+    ("split", "kv", 0, "cfg2xtoken4"), ("interleave", "kv", 0, "token8x2branches-interleaved"),
+    ("split", "heads", 8, "cfg2xtoken4-heads"), ("interleave", "heads", 8, "token8x2branches-interleaved-heads")])
+def test_eight_rank_plans_match_single_process(mode, exchange, heads, desc):
+    """The machine the north star names is 8 ranks (BASELINE config 4 is 8-way): the plans `make_plan(rank, 8)` builds -- cfg 2 x
+    token 4 (2 + 4 communicators... every rank creates all of them in the same order) and both branches interleaved on 8 token
+    shards (two communicators over all 8 ranks) -- as 8 PROCESSES over gloo, every rank's latents against the single process.
+    24 tokens: 6 / 3 rows per shard.  The heads all-to-all runs on a seeded 8-head model (4 shards x 2 heads, 8 shards x 1 head)."""
+    if heads:
+        pipe, a = _four_head_case(heads)
+    else:
+        cfg, sd, a = load_golden("wan_pipe_tiny")
+        pipe = _build(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")})
+    single = _run(pipe, a)
+    assert torch.isfinite(single).all()
+    outs = _spawn(8, (True, mode, exchange, heads or False))
+    assert sorted(r for r, _, _ in outs) == list(range(8))
+    for rank, d, out in outs:
+        assert d == desc, d
+        torch.testing.assert_close(out, single, atol=1e-4, rtol=1e-4)
+    for rank, d, out in outs[1:]:
+        assert torch.equal(out, outs[0][2])           # every rank ends the loop on the same latents, bit for bit
 
 
 def test_two_token_shards_trade_two_head_groups():
