@@ -53,6 +53,17 @@ def wan_flops_shared_prefix(L, cfg):
     return 2 * L * cfg["in_channels"] * 4 * d + 8 * L * d * d + 4 * L * L * d
 
 
+def wan_flops_dead_rows(L, dead, cfg, cross_keys, reassoc_k):
+    """what one forward does NOT compute for `dead` token rows in the LAST block and the output head when the caller reads only
+    the other rows (WanTransformer3DModel.forward(live_rows=): the ID frame's and the re-imposed first frame's tokens): their
+    self-attention queries, out-projection, text branch (q projection, attention over `cross_keys` keys, out-projection -- K =
+    `reassoc_k` when it ran re-associated), FFN and head.  Their q | k | v projection still runs (k | v are needed, the GEMM is one)."""
+    d, f = cfg["num_attention_heads"] * cfg["attention_head_dim"], cfg["ffn_dim"]
+    out2 = 2 * (reassoc_k if reassoc_k else d) * d + (0 if reassoc_k else 2 * cross_keys * d)
+    per_row = 4 * L * d + 2 * d * d + 2 * d * d + 2 * cross_keys * d + out2 + 4 * d * f + 2 * d * cfg["out_channels"] * 4
+    return dead * per_row
+
+
 def build_model(cfg, device, seed=0, dtype=torch.bfloat16):
     """Random-init Wan2.2-5B (no checkpoints offline): N(0, 0.02^2) weights generated on the device."""
     from frameino_amd.random_init import random_wan_model
@@ -500,10 +511,17 @@ def main():
             f_ = wan_flops_per_forward(L, cfg, cross_keys=keys, text_proj=False)
             if kp is not None:                      # out-projection 2 L D D -> 2 L (heads kp) D, the P.V product is gone
                 f_ += cfg["num_layers"] * (2 * L * cfg["num_attention_heads"] * kp * d_ - 2 * L * d_ * d_ - 2 * L * keys * d_)
+            # rows of the last block whose output the loop discards (ID frame, re-imposed first frame): keys / values only
+            live_ = getattr(st, "live_rows", None) if (not multi and getattr(model, "skip_dead_rows", False)) else None
+            if live_ is not None:
+                f_ -= wan_flops_dead_rows(L, L - (live_[1] - live_[0]), cfg, keys,
+                                          None if kp is None else cfg["num_attention_heads"] * kp)
             flops_step += f_
             text_route.append({"keys": int(keys), "reassociated_out_projection_k": None if kp is None else int(cfg["num_attention_heads"] * kp)})
         flops_step -= wan_flops_shared_prefix(L, cfg) if shared else 0
-        issued.update(flops=flops_step, route=text_route)
+        issued.update(flops=flops_step, route=text_route,
+                      dead_rows_last_block=0 if (getattr(st, "live_rows", None) is None or multi or not getattr(model, "skip_dead_rows", False))
+                      else L - (st.live_rows[1] - st.live_rows[0]))
 
     def result_line(elapsed, parallelism, extra_cfg, roofline=None, cpu=None, use_graph=False):
         ms_step = elapsed / a.steps * 1e3
@@ -515,7 +533,7 @@ def main():
         if "flops" not in issued:
             issued_flops(shared)
         flops_step = issued["flops"]
-        extra_cfg = dict(extra_cfg, text_branch_as_run=issued["route"])
+        extra_cfg = dict(extra_cfg, text_branch_as_run=issued["route"], dead_rows_last_block=issued.get("dead_rows_last_block", 0))
         out = {
             "metric": "denoise-steps/sec (Wan2.2-5B FrameINO, 49f 704x1280, cond+uncond DiT forward + CFG + Euler)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps,

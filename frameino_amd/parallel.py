@@ -71,6 +71,19 @@ class TokenShard:
     # traffic there (tools/plan_sim.py)
     gemm_tile_m = 0
 
+    def tile_m_for(self, rows):
+        """the tile height this shard's GEMM calls pass for `rows` rows.  A shard that asked for 256-row tiles (8: the interleaved
+        plan) gets 224-row ones (7) when they multiply >= 5 % fewer rows that do not exist: 1540 rows (8-way shard of L = 12320) are
+        7 tile rows either way -- 7 x 224 = 1568 against 7 x 256 = 1792 rows of MFMA work: 42.6 -> 40.6 ms per step and rank
+        (tools/plan_sim.py, profiles/r06_plan_sim_tile_modes.txt); 3080 rows (4-way) measure the same both ways.  A remainder
+        launch at a low height was measured too and LOSES (a second K walk per GEMM: 70.3 -> 77.1 ms at 4 ways)."""
+        t = int(self.gemm_tile_m)
+        if t != 8 or rows <= 0:
+            return t
+        pad8 = -(-rows // 256) * 256
+        pad7 = -(-rows // 224) * 224
+        return 7 if pad7 < 0.95 * pad8 else 8
+
     def fused_qkv_ok(self):
         return bool(self.fused_qkv)
 
@@ -290,7 +303,7 @@ class ParallelPlan:
             for sh in self.shards:
                 sh.head_groups = 1
                 sh.fused_qkv = True
-                sh.gemm_tile_m = 8
+                sh.gemm_tile_m = 8           # (a shard's row count may lower it: TokenShard.tile_m_for)
                 # two kernel streams already put one branch's attention under the other's gather: head groups add 2.3 ms of
                 # launches per step there and hide nothing more (tools/plan_sim.py with a modelled wire, profiles/r05_plan_sim*)
                 sh.kv_head_groups = 1

@@ -301,10 +301,12 @@ class WanImageToVideoPipeline:
         x = o.wan_model_input(st.lat, st.cond, st.idl, st.traj, tr.dtype, out=st.x)[None]
         rows = (st.t_rows, st.sel)
 
+        live = {"live_rows": st.live_rows} if getattr(st, "live_rows", None) is not None else {}
+
         def fwd(name, emb):
             with tr.cache_context(name):
                 return tr(hidden_states=x, timestep=None, encoder_hidden_states=emb, return_dict=False,
-                          attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0][0]
+                          attention_kwargs=st.attention_kwargs, timestep_rows=rows, **live)[0][0]
 
         plan = getattr(self, "parallel", None)
         if plan is not None and plan.interleave and st.cfg:
@@ -371,7 +373,7 @@ class WanImageToVideoPipeline:
             # the tiles per launch, weights streamed once).  The reference makes two calls (:862-882).
             with tr.cache_context("cfg"):
                 both = tr(hidden_states=x.expand(2, -1, -1, -1, -1), timestep=None, encoder_hidden_states=st.pe_ne,
-                          return_dict=False, attention_kwargs=st.attention_kwargs, timestep_rows=rows)[0]
+                          return_dict=False, attention_kwargs=st.attention_kwargs, timestep_rows=rows, **live)[0]
             pc, pu = both[0], both[1]
         else:
             pc = fwd("cond", st.pe)
@@ -403,6 +405,12 @@ class WanImageToVideoPipeline:
         sel = torch.ones((fg + nid) * tok_per_frame, dtype=torch.int32, device=dev)
         sel[:tok_per_frame] = (first_frame_mask[0, 0, 0, ::ps[1], ::ps[2]].flatten() != 0).to(torch.int32)
         st.sel = sel
+        # Token rows whose prediction this loop READS (WanTransformer3DModel.forward(live_rows=)): the ID frames' predictions are
+        # dropped (:884-885), and the first latent frame is taken from the condition in every model input (:829) and in the
+        # returned latents (:913) whenever its mask is zero -- what the model predicts for it never reaches an output.
+        first_dead = bool((first_frame_mask[0, 0, 0] == 0).all()) if fg > 1 else False
+        lo_live, hi_live = (tok_per_frame if first_dead else 0), fg * tok_per_frame
+        st.live_rows = (lo_live, hi_live) if (hi_live - lo_live) < (fg + nid) * tok_per_frame else None
         st.t_rows = torch.zeros(2, dtype=torch.float32, device=dev)
         st.dt = torch.zeros(1, dtype=torch.float32, device=dev)
         # UniPC multistep history (last corrected sample, two x0 predictions) + this step's coefficient row
@@ -441,6 +449,8 @@ class WanImageToVideoPipeline:
         timesteps = self.scheduler.timesteps
         st = self.make_state(latents, condition, traj_latents, id_latent, first_frame_mask, prompt_embeds,
                              negative_prompt_embeds, guidance_scale, attention_kwargs)
+        if callback_on_step_end is not None:
+            st.live_rows = None          # a callback sees the latents after every step, the first frame's Euler update included
         if st.unipc is not None:
             coefs = self.scheduler.coefs.to(dev).clone()
             coefs[:, 0] = st.guidance

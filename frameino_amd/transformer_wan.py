@@ -159,6 +159,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         self.dedup_text_padding = os.environ.get("FINO_TEXT_FOLD", "1") != "0"      # (the environment switch: A/B timing)
         # ... and then the text cross-attention's out-projection re-associated as P.(V W_o^T) (see _text_out_weights)
         self.reassociate_text_out = os.environ.get("FINO_TEXT_REASSOC", "1") != "0"
+        # honour `forward(live_rows=...)`: in the last block, rows the caller discards contribute K | V only (round 6)
+        self.skip_dead_rows = os.environ.get("FINO_SKIP_DEAD_ROWS", "1") != "0"
 
     # ------------------------------------------------------------------ diffusers-style surface
     @property
@@ -456,11 +458,17 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None,
-                return_dict=True, attention_kwargs=None, timestep_rows=None):
+                return_dict=True, attention_kwargs=None, timestep_rows=None, live_rows=None):
         """`timestep_rows=(values [R], selector int32 [L])` is the de-duplicated form of a per-token timestep; when a
-        2-D `timestep` is given instead it is de-duplicated here (torch.unique: host sync, eager only)."""
+        2-D `timestep` is given instead it is de-duplicated here (torch.unique: host sync, eager only).
+        `live_rows=(lo, hi)` (round 6): the caller will only read the output of token rows [lo, hi) -- the FrameINO loop drops the
+        ID frame's prediction (pipeline_wan_i2v_motion_FrameINO.py:884-885) and re-imposes the first latent frame from the
+        condition before every forward and at the end (:829, :913).  In the LAST block the other rows then only feed the
+        self-attention as keys and values: their q projection's use, attention queries, out-projection, text branch, FFN and
+        output head are skipped, and their part of the returned tensor is ZERO.  Every kept row is computed exactly as without it.
+        A bare `transformer(...)` call (None) keeps the full output."""
         gen = self.forward_steps(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image,
-                                 return_dict, attention_kwargs, timestep_rows)
+                                 return_dict, attention_kwargs, timestep_rows, live_rows=live_rows)
         while True:
             try:
                 next(gen)
@@ -468,7 +476,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 return done.value
 
     def forward_steps(self, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None,
-                      return_dict=True, attention_kwargs=None, timestep_rows=None, shard=None):
+                      return_dict=True, attention_kwargs=None, timestep_rows=None, shard=None, live_rows=None):
         """The forward as a generator that yields after the embedding stage and after every block, so that a caller
         can interleave two independent forwards (the CFG branches) kernel-stream by kernel-stream
         (frameino_amd/parallel.py: one branch's K|V all-gather then flies under the other branch's compute).  Every
@@ -505,7 +513,9 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         else:
             lo, n, lpad = 0, L, L
         # the shard's tile height for its GEMM calls (a per-call argument of the C ABI; {} = the library's planner)
-        tk = {"tile_m": sh.gemm_tile_m} if (sh is not None and getattr(sh, "gemm_tile_m", 0)) else {}
+        tk = {}
+        if sh is not None and getattr(sh, "gemm_tile_m", 0):
+            tk = {"tile_m": sh.tile_m_for(n) if hasattr(sh, "tile_m_for") else sh.gemm_tile_m}
         # Batch elements are extra ROWS of the token-major buffers ([B*n, D]): every GEMM / norm is one launch over
         # both CFG branches (twice the tiles per launch, weights read once); attention and RoPE index rows per batch.
         nr = b * n
@@ -574,8 +584,19 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 return o.attention_fp8(q_, k_, v_, heads_, p_mode=getattr(self, "fp8_p_mode", None), **kw_)
         yield
 
+        # rows whose output the caller reads (`live_rows`): honoured in the last block on the single-GPU default-processor path
+        live = None
+        if (live_rows is not None and self.skip_dead_rows and default_procs and sh is None and len(self.blocks) > 1
+                and not self._fp8 and attend is o.attention):
+            l0, l1 = int(live_rows[0]), int(live_rows[1])
+            if 0 <= l0 < l1 <= n and (l1 - l0) < n and l0 % 8 == 0 and l1 % 8 == 0:
+                live = (l0, l1)
+        segs = [(0, nr)]                 # global row ranges the per-token operations of a block run on
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):
             m = mod[:, li]                                                        # [R, 6, D] view, row stride = layers*6*D
+            last_live = live is not None and li == len(self.blocks) - 1
+            if last_live:
+                segs = [(bi * n + live[0], bi * n + live[1]) for bi in range(b)]
             # 1. self-attention (:334-336)
             once = shared and li == 0
             xq1 = None
@@ -606,7 +627,11 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 self._lin(li, "qkv", nrm, e.wqkv, e.bqkv, xq=xq1, out=qkv)
                 self._qk_norm_rope(blk, qkv, d, cos, sin, dh, qfold)
                 q3 = qkv.view(b, n, 3 * d)
-                attend(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
+                if last_live:            # every row is a key; only the live rows are queries
+                    attend(q3[:, live[0]:live[1], :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads,
+                           out=att.view(b, n, d)[:, live[0]:live[1]], **afold)
+                else:
+                    attend(q3[:, :, :d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], heads, out=att.view(b, n, d), **afold)
             elif sh.heads_exchange_ok(heads):
                 # heads exchange (frameino_amd/parallel.py): q | k | v of MY tokens -> all-to-all -> all tokens of MY
                 # heads -> one attention launch over the whole sequence -> all-to-all back to the token owners
@@ -725,8 +750,9 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                     kv3 = kv_all.view(1, -1, 2 * d)[:, :L]
                     o.attention(q2.view(1, n, d), kv3[:, :, :d], kv3[:, :, d:], heads, out=att.view(1, n, d), **afold)
             if default_procs and not once:
-                self._lin(li, "out", att, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
-                          residual=x, gate=m[:, 2], sel=sel, out=x, **tk)
+                for r0, r1 in segs:
+                    self._lin(li, "out", att[r0:r1], blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, o.EPI_GATED_RESIDUAL,
+                              residual=x[r0:r1], gate=m[:, 2], sel=None if sel is None else sel[r0:r1], out=x[r0:r1], **tk)
             # 2. cross-attention (:339-341): text K/V are replicated, nothing to exchange
             n2 = blk.norm2
             xq2 = self._ln_q(li, "q2", 1, x, weight=n2.weight, bias=n2.bias, eps=cfg.eps) if (n2 is not None and
@@ -734,31 +760,39 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             if xq2 is not None:
                 pass
             elif n2 is not None:
-                o.layernorm(x, n2.weight, n2.bias, cfg.eps, out=nrm)
+                for r0, r1 in segs:
+                    o.layernorm(x[r0:r1], n2.weight, n2.bias, cfg.eps, out=nrm[r0:r1])
             else:
                 nrm.copy_(x)
             if default_procs:
-                self._lin(li, "q2", nrm, blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2, **tk)
+                for r0, r1 in segs:
+                    self._lin(li, "q2", nrm[r0:r1], blk.attn2.to_q.weight, blk.attn2.to_q.bias, xq=xq2, out=q2[r0:r1], **tk)
                 kv = text.kv[li].view(b, lt, 2 * d)
+                s0, s1 = (live if last_live else (0, n))                       # the rows of every batch element that run
                 if text.w2 is not None:
                     # norm_q's statistic only (the probabilities kernel normalises q while it loads it: same rounding points, no
                     # pass that rewrites q); probabilities per sample, then x += P.(V W_o^T) + b: K = heads x keys instead of D
-                    rr = o.row_rrms(q2, blk.attn2.norm_q.eps, out=text.rrms)
+                    rr = text.rrms
+                    for r0, r1 in segs:
+                        o.row_rrms(q2[r0:r1], blk.attn2.norm_q.eps, out=rr[r0:r1])
                     for i in range(b):
-                        pr = o.attention_probs(q2[i * n:(i + 1) * n].view(1, n, d), kv[i:i + 1, :, :d], heads, text.tail[0][i:i + 1],
-                                               text.tail[1][i:i + 1], text.kp[i], out=text.pbuf[i].view(1, n, -1),
-                                               q_rrms=rr[i * n:(i + 1) * n].view(1, n), q_weight=blk.attn2.norm_q.weight)
-                        xi = x[i * n:(i + 1) * n]
-                        o.gemm(pr.view(n, -1), text.w2[li][i], blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=xi, out=xi, **tk)
+                        r0, r1 = i * n + s0, i * n + s1
+                        pr = o.attention_probs(q2[r0:r1].view(1, s1 - s0, d), kv[i:i + 1, :, :d], heads, text.tail[0][i:i + 1],
+                                               text.tail[1][i:i + 1], text.kp[i], out=text.pbuf[i][:s1 - s0].view(1, s1 - s0, -1),
+                                               q_rrms=rr[r0:r1].view(1, s1 - s0), q_weight=blk.attn2.norm_q.weight)
+                        xi = x[r0:r1]
+                        o.gemm(pr.view(s1 - s0, -1), text.w2[li][i], blk.attn2.to_out[0].bias, o.EPI_RESIDUAL, residual=xi, out=xi, **tk)
                 else:
-                    o.rmsnorm_rope_(q2, blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
+                    for r0, r1 in segs:
+                        o.rmsnorm_rope_(q2[r0:r1], blk.attn2.norm_q.weight, blk.attn2.norm_q.eps)
+                    qv, av = q2.view(b, n, d)[:, s0:s1], att.view(b, n, d)[:, s0:s1]
                     if text.tail is not None:
-                        o.attention_tail(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, text.tail[0], text.tail[1],
-                                         out=att.view(b, n, d))
+                        o.attention_tail(qv, kv[:, :, :d], kv[:, :, d:], heads, text.tail[0], text.tail[1], out=av)
                     else:
-                        o.attention(q2.view(b, n, d), kv[:, :, :d], kv[:, :, d:], heads, out=att.view(b, n, d))
-                    self._lin(li, "out2", att, blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
-                              residual=x, out=x, **tk)
+                        o.attention(qv, kv[:, :, :d], kv[:, :, d:], heads, out=av)
+                    for r0, r1 in segs:
+                        self._lin(li, "out2", att[r0:r1], blk.attn2.to_out[0].weight, blk.attn2.to_out[0].bias, o.EPI_RESIDUAL,
+                                  residual=x[r0:r1], out=x[r0:r1], **tk)
             else:
                 a = blk.attn2(nrm.view(b, n, d), encoder_hidden_states=text.txt.view(b, lt, d),
                               **(attention_kwargs or {}))
@@ -768,7 +802,8 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
             xq3 = (self._ln_q(li, "ff1", 0, x, shift=m[:, 3], scale=m[:, 4], sel=sel, eps=cfg.eps)
                    if (w1q is not None and w2q is not None) else None)
             if xq3 is None:
-                o.adaln_modulate(x, m[:, 3], m[:, 4], sel, cfg.eps, out=nrm)
+                for r0, r1 in segs:
+                    o.adaln_modulate(x[r0:r1], m[:, 3], m[:, 4], None if sel is None else sel[r0:r1], cfg.eps, out=nrm[r0:r1])
             if w1q is not None and w2q is not None:
                 # MXFP8: the adaLN emits the FFN input already quantised, and the GELU epilogue the hidden activations (no
                 # bf16 round trips)
@@ -777,16 +812,22 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
                 o.gemm_mxfp8(hq[0], hq[1], w2q[0], w2q[1], blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
                              gate=m[:, 5], sel=sel, out=x)
             else:
-                self._lin(li, "ff1", nrm, blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH, out=ff,
-                          **tk)
-                self._lin(li, "ff2", ff, blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL, residual=x,
-                          gate=m[:, 5], sel=sel, out=x, **tk)
+                for r0, r1 in segs:
+                    self._lin(li, "ff1", nrm[r0:r1], blk.ffn.net[0].proj.weight, blk.ffn.net[0].proj.bias, o.EPI_GELU_TANH,
+                              out=ff[r0:r1], **tk)
+                    self._lin(li, "ff2", ff[r0:r1], blk.ffn.net[2].weight, blk.ffn.net[2].bias, o.EPI_GATED_RESIDUAL,
+                              residual=x[r0:r1], gate=m[:, 5], sel=None if sel is None else sel[r0:r1], out=x[r0:r1], **tk)
             yield
 
         # ---- output head (:519-543) ----
-        o.adaln_modulate(x, head[:, 0], head[:, 1], sel, cfg.eps, out=nrm)
+        for r0, r1 in segs:
+            o.adaln_modulate(x[r0:r1], head[:, 0], head[:, 1], None if sel is None else sel[r0:r1], cfg.eps, out=nrm[r0:r1])
         if sh is None:
-            po = o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=ws.po[:nr])
+            po = ws.po[:nr]
+            if live is not None:
+                po.zero_()               # rows nobody computed: the caller asked not to read them -- zeros, not the last call's values
+            for r0, r1 in segs:
+                o.gemm(nrm[r0:r1], self.proj_out.weight, self.proj_out.bias, out=po[r0:r1])
         else:
             po_loc = sh.out_local(lpad, ws.po.shape[1], dt, dev)
             o.gemm(nrm, self.proj_out.weight, self.proj_out.bias, out=po_loc[:n], **tk)

@@ -209,3 +209,36 @@ def test_zero_padded_prompt_tail_folded_into_one_key_vs_all_rows_and_vs_oracle(b
     full = torch.randn(batch, 512, 256, generator=g).to(DEV).bfloat16()
     m(xd, tsd, full, return_dict=False)
     assert next(iter(m._text_cache.values()))[2].tail is None
+
+
+@pytest.mark.parametrize("batch,padded", [(1, True), (2, True), (2, False)])
+def test_live_rows_last_block_skips_dead_rows_and_keeps_every_live_row_bit_equal(batch, padded):
+    """`forward(live_rows=(lo, hi))`: the FrameINO loop discards the ID frame's prediction (pipeline_wan_i2v_motion_FrameINO.py:884-885)
+    and re-imposes the first latent frame from the condition (:829, :913).  In the last block those tokens then only serve as keys
+    and values.  The kept frames must be BIT-EQUAL to the full forward (same kernels on row slices), the dropped frames zero; the
+    text branch both re-associated (padded prompt) and plain (un-padded), batch 1 and the CFG batch."""
+    cfg = dict(W.WAN22_5B_CFG, num_attention_heads=4, attention_head_dim=128, in_channels=16, out_channels=8,
+               text_dim=256, ffn_dim=1024, num_layers=3)
+    sd = W.wan_random_state_dict(cfg, seed=7, dtype=torch.float32, std=0.04)
+    g = torch.Generator().manual_seed(28)
+    x = torch.randn(1, 16, 6, 16, 20, generator=g).to(DEV).bfloat16()        # 6 frames x 80 tokens: first, 4 generated, ID
+    txt = torch.randn(batch, 512, 256, generator=g)
+    if padded:
+        txt[:, 40:] = 0
+    txt = txt.to(DEV).bfloat16()
+    tpf, nf = 80, 6
+    L = tpf * nf
+    rows = (torch.tensor([0.0, 811.0], device=DEV), torch.cat([torch.zeros(tpf), torch.ones(L - tpf)]).to(DEV).to(torch.int32))
+    m = hip_wan_model(cfg, sd, DEV)
+    xin = x if batch == 1 else x.expand(2, -1, -1, -1, -1)
+    kw = dict(hidden_states=xin, timestep=None, encoder_hidden_states=txt, return_dict=False, timestep_rows=rows)
+    full = m(**kw)[0]
+    hit = next(iter(m._text_cache.values()))[2]
+    assert (hit.w2 is not None) == padded
+    live = m(live_rows=(tpf, (nf - 1) * tpf), **kw)[0]
+    assert torch.equal(live[:, :, 1:nf - 1], full[:, :, 1:nf - 1])
+    assert float(live[:, :, 0].abs().max()) == 0.0 and float(live[:, :, nf - 1].abs().max()) == 0.0
+    assert float(full[:, :, 0].abs().max()) > 0.0
+    # switched off: the argument is accepted and ignored
+    m.skip_dead_rows = False
+    assert torch.equal(m(live_rows=(tpf, (nf - 1) * tpf), **kw)[0], full)
