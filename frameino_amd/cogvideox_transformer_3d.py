@@ -133,6 +133,8 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
         # folded into its MFMAs (-5 % per step).  Video rows: one rounding of q.c instead of q; the 226 text rows (LayerNorm
         # only, already rounded) are rounded twice.  False: q as the reference rounds it, scale applied to the logits.
         self.fold_softmax_scale = True
+        # in the last block, rows nobody reads afterwards (text rows; frames beyond forward(live_frames=)) are keys / values only
+        self.skip_dead_rows = os.environ.get("FINO_SKIP_DEAD_ROWS", "1") != "0"
         self.original_attn_processors = None
 
     # ---- reference surface (:346-444) ----
@@ -303,7 +305,12 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
     # ---- forward (:446-562) ----
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, ofs=None,
-                image_rotary_emb=None, attention_kwargs=None, return_dict=True):
+                image_rotary_emb=None, attention_kwargs=None, return_dict=True, live_frames=None):
+        """`live_frames=k` (round 6): the caller reads the prediction of the first k latent frames only -- the FrameINO loop drops
+        the identity frame appended on the frame axis (pipeline_cogvideox_i2v_motion_FrameINO.py:866-881, :896).  In the LAST block
+        the other frames' tokens then serve as keys / values only, and so do the TEXT rows on every call (the model returns video
+        rows only, :531-542): their attention queries, out-projection and feed-forward are skipped; dropped frames come back ZERO.
+        Every returned row is computed exactly as without it."""
         if timestep_cond is not None:
             raise NotImplementedError("timestep_cond is never passed on the FrameINO path")
         if attention_kwargs is not None:
@@ -359,9 +366,34 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
         fold = self.fold_softmax_scale and hasattr(ops, "SCALE_FOLDED")
         qfold = {"out_scale": dh ** -0.5 * ops.LOG2E} if fold else {}
         afold = {"scale": ops.SCALE_FOLDED} if fold else {}
+        # rows of the joint sequence whose output anyone reads after the last block: the video rows of the live frames
+        tpf = (hh // ps) * (ww // ps)
+        kf = nf if live_frames is None else max(1, min(int(live_frames), nf))
+        r0, r1 = lt, lt + kf * tpf
+        skip_dead = (self.skip_dead_rows and default_procs and not self._fp8 and not self.fp8_attention and len(self.transformer_blocks) > 1
+                     and (r1 - r0) < L)
+        if not skip_dead:
+            kf, r0, r1 = nf, lt, L
         # 3. blocks (:503-529)
         for li, (blk, e) in enumerate(zip(self.transformer_blocks, pk.layers)):
             t1, t2 = tables[2 * li], tables[2 * li + 1]                              # [2B, 3, D]
+            if skip_dead and li == len(self.transformer_blocks) - 1:
+                # LAST block: every row is a key / value, only rows [r0, r1) of each sample are queries and go on
+                n = ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
+                qkv = self._lin(li, "qkv", n, e.wqkv, e.bqkv).view(b, L, 3 * d)
+                nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
+                ops.headnorm_rope_(qkv[:, :, :d], heads, dh, nq.weight, nq.bias, nq.eps, cos, sin, rope_row0=lt, **qfold)
+                ops.headnorm_rope_(qkv[:, :, d:2 * d], heads, dh, nk.weight, nk.bias, nk.eps, cos, sin, rope_row0=lt)
+                att = ops.attention(qkv[:, r0:r1, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], heads, **afold)      # [B, r1 - r0, D]
+                for i in range(b):
+                    xs, ss = x2[i * L + r0:i * L + r1], sel[i * L + r0:i * L + r1]
+                    self._lin(li, "out", att[i], blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias,
+                              ops.EPI_GATED_RESIDUAL_STAGED, residual=xs, gate=t1[:, 2], sel=ss, out=xs)
+                    n = ops.layernorm_zero(xs, e.n2w, e.n2b, t2[:, 0], t2[:, 1], ss, c.norm_eps)
+                    ff = self._lin(li, "ff1", n, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, ops.EPI_GELU_TANH)
+                    self._lin(li, "ff2", ff, blk.ff.net[2].weight, blk.ff.net[2].bias, ops.EPI_GATED_RESIDUAL_STAGED,
+                              residual=xs, gate=t2[:, 2], sel=ss, out=xs)
+                continue
             xq1 = self._lnz_q(li, "qkv", x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps) if default_procs else None
             n = None if xq1 is not None else ops.layernorm_zero(x2, e.n1w, e.n1b, t1[:, 0], t1[:, 1], sel, c.norm_eps)
             if default_procs:
@@ -400,12 +432,14 @@ class CogVideoXTransformer3DModel(nn.Module, FromPretrainedMixin):
         # 4. final norms + projection (:531-542) on the video rows
         outs = []
         for i in range(b):
-            v = ops.layernorm(x[i, lt:], pk.nfw, pk.nfb, c.norm_eps)
+            v = ops.layernorm(x[i, lt:r1], pk.nfw, pk.nfb, c.norm_eps)
             v = ops.layernorm_zero(v, pk.now, pk.nob, out_mod[i, 0], out_mod[i, 1], None, c.norm_eps)
             y = ops.gemm(v, self.proj_out.weight, self.proj_out.bias)                # [Lv, p*p*Cout] (c, dh, dw) columns
-            y = y.view(nf, hh // ps, ww // ps, c.out_channels, ps, ps).permute(0, 3, 1, 4, 2, 5)
-            outs.append(y.reshape(nf, c.out_channels, hh, ww))
+            y = y.view(kf, hh // ps, ww // ps, c.out_channels, ps, ps).permute(0, 3, 1, 4, 2, 5)
+            outs.append(y.reshape(kf, c.out_channels, hh, ww))
         out = torch.stack(outs)
+        if kf < nf:                                                                  # frames nobody reads: zeros
+            out = torch.cat([out, out.new_zeros((b, nf - kf) + tuple(out.shape[2:]))], dim=1)
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)

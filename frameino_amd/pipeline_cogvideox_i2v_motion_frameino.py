@@ -316,8 +316,11 @@ class CogVideoXImageToVideoPipeline:
     def _step(self, st):
         """One denoise step on the static buffers `st` (no host sync, no data-dependent shapes: hipGraph-capturable)."""
         st.x[:, :st.nlf, :st.C].copy_(st.lat)                                                   # broadcast over the CFG batch
+        # (live_frames: the identity frame appended on the frame axis is dropped from the prediction, :896 -- the model may skip
+        # what only that frame's output needs; only passed to the mirror's own transformer class)
+        live = {"live_frames": st.nlf} if (st.x.shape[1] > st.nlf and getattr(self.transformer, "skip_dead_rows", False)) else {}
         pred = self.transformer(hidden_states=st.x, encoder_hidden_states=st.prompt, timestep=st.t,
-                                image_rotary_emb=st.rot, attention_kwargs=st.attention_kwargs, return_dict=False)[0]
+                                image_rotary_emb=st.rot, attention_kwargs=st.attention_kwargs, return_dict=False, **live)[0]
         if st.dpm:
             ops.cfg_dpm_step_(st.lat, pred.contiguous(), st.x0_old, st.noise, st.coef, has_uncond=st.cfg_on)
         else:

@@ -589,7 +589,7 @@ class WanTransformer3DModel(nn.Module, FromPretrainedMixin):
         if (live_rows is not None and self.skip_dead_rows and default_procs and sh is None and len(self.blocks) > 1
                 and not self._fp8 and attend is o.attention):
             l0, l1 = int(live_rows[0]), int(live_rows[1])
-            if 0 <= l0 < l1 <= n and (l1 - l0) < n and l0 % 8 == 0 and l1 % 8 == 0:
+            if 0 <= l0 < l1 <= n and (l1 - l0) < n:
                 live = (l0, l1)
         segs = [(0, nr)]                 # global row ranges the per-token operations of a block run on
         for li, (blk, e) in enumerate(zip(self.blocks, pk.layers)):

@@ -487,3 +487,22 @@ def test_cog_example_script_smoke(extra):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "clip (9 frames 64x96" in r.stdout and "cropped region (9, " in r.stdout
+
+
+def test_last_block_skips_text_rows_and_dead_frames_bit_equal(golden):
+    """The model returns video rows only (cogvideox_transformer_3d.py:531-542): in the LAST block the text rows are keys / values and
+    nothing else -- and with `live_frames=k` (the FrameINO loop drops the identity frame's prediction, pipeline :896) so are the
+    frames beyond k.  The returned rows must be bit-equal to the forward that computes everything; dropped frames are zero."""
+    m, cfg, sd, a = _model(golden)
+    assert m.skip_dead_rows
+    skipped = _run(m, a, "def")                                    # text rows skipped in the last block
+    m.skip_dead_rows = False
+    full = _run(m, a, "def")
+    assert torch.equal(skipped, full)
+    m.skip_dead_rows = True
+    kw = dict(hidden_states=a["x_def"].to(DEV).bfloat16(), encoder_hidden_states=a["txt_def"].to(DEV).bfloat16(),
+              timestep=a["ts_def"].to(DEV), image_rotary_emb=(a["cos_def"].to(DEV), a["sin_def"].to(DEV)), return_dict=False)
+    nf = kw["hidden_states"].shape[1]
+    live = m(live_frames=nf - 1, **kw)[0]
+    assert live.shape == full.shape and torch.equal(live[:, :nf - 1], full[:, :nf - 1])
+    assert float(live[:, nf - 1].abs().max()) == 0.0 and float(full[:, nf - 1].abs().max()) > 0.0
