@@ -376,7 +376,13 @@ class AutoencoderKLWan(FromPretrainedMixin):
             span = (((255 + h * w - 1) // (h * w) + 1) * stride[0] + kt) * h * w * cw * 2        # (fino_conv3d_split's own formula)
             if span >= lim and tuple(stride) == (1, 1, 1) and not up and out_thw is None and pad[1] == kh // 2 \
                     and pad[2] == kw // 2 and h >= 8:
-                n = min(h // 4, -(-span // (lim - lim // 16)))
+                # the strip count from the kernel's own span formula evaluated on a STRIP (its rows + the kh - 1 halo rows; the
+                # ceil((255 + h w - 1) / (h w)) term grows once a strip's h w drops under 256): the first n that fits
+                def strip_span(hs):
+                    return (((255 + hs * w - 1) // (hs * w) + 1) * stride[0] + kt) * hs * w * cw * 2
+                n = 2
+                while n < h and strip_span(-(-h // n) + kh - 1) >= lim:
+                    n += 1
                 rows = -(-h // n)
                 outs = []
                 for r0 in range(0, h, rows):

@@ -1004,6 +1004,8 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, void* y, 
     FINO_CHECK(fino_aligned16(x) && fino_aligned16(w) && fino_aligned16(y) && fino_aligned16(r) &&
                    fino_aligned16(zero_page),
                FINO_ERR_ARG, "fino_conv3d: 16-byte alignment required");
+    // (the split products' fp32 epilogue loads the bias as float4: gemm_epilogue_f32)
+    FINO_CHECK(planes == 0 || fino_aligned16(bias), FINO_ERR_ARG, "fino_conv3d_split: bias must be 16-byte aligned");
     const int products = planes == 0 ? 1 : (planes == 2 ? 3 : 6);
     const int64_t a_width = (int64_t)(planes == 0 ? 1 : planes) * c_in_pad;         // elements of one A row
     GemmParams p = {};

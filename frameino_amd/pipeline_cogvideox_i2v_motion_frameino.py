@@ -354,6 +354,8 @@ class CogVideoXImageToVideoPipeline:
                         dtype=None, device=None, generator=None, latents=None):
         """reference :350-423 (patch_size_t None).  image [B, C, H, W] in [-1, 1]."""
         self._need_vae()
+        if isinstance(generator, tuple):
+            generator = list(generator)
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
                              f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
@@ -435,7 +437,9 @@ class CogVideoXImageToVideoPipeline:
         n_lat = c.out_channels          # 16 for CogVideoX-5B (hard-coded at :797)
         if img.shape[0] == 1 and batch_size > 1:
             # ONE first frame for B prompts: its latent is one posterior sample, shared by the B videos like the trajectory and
-            # identity latents below; the noise is drawn as the batch's rows (diffusers' randn_tensor rule for generator lists)
+            # identity latents below; the noise is drawn as the batch's rows (diffusers' randn_tensor rule for generator lists).
+            # With a LIST of generators only row 0 therefore reproduces the single call made with its generator (posterior draw
+            # first, then the noise row): rows i > 0 draw their noise from generator[i] with no posterior draw in front of it.
             g0 = generator[0] if isinstance(generator, (list, tuple)) else generator
             _, image_latents = self.prepare_latents(img, 1, n_lat, num_frames, height, width, dt, dev, g0,
                                                     torch.zeros(1, device=dev))
