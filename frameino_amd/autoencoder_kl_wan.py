@@ -498,9 +498,33 @@ class AutoencoderKLWan(FromPretrainedMixin):
         return self._res(x, p + ".resnets.1")
 
     # ---- decode (reference :1198-1227, whole-sequence) ----
+    def _tail_halo_rows(self, first, nb):
+        """(input rows of halo one side of a slab of the decoder tail `up_blocks[first:]` + head needs, output rows per input row):
+        walking the layers from the output back, a stride-1 3 x 3 convolution adds one row at its resolution, a 2x nearest
+        upsample halves (rounding up) what lies behind it."""
+        cfg = self.config
+        ps = cfg.patch_size or 1
+        need, scale = 1, ps                                   # conv_out (3 x 3 x 3); unpatchify is pointwise
+        for i in range(nb - 1, first - 1, -1):
+            if i != nb - 1:                                   # this block ends in [2x upsample, 3 x 3 conv]: the conv, then halve
+                need = -(-(need + 1) // 2)
+                scale *= 2
+            need += 2 * (cfg.num_res_blocks + 1)              # its resnets: two 3 x 3 (x 3) convolutions each
+        return need, scale
+
     @torch.no_grad()
-    def decode(self, z, return_dict=True):
+    def decode_slab(self, z, index, count):
+        """rows of the decoded video that slab `index` of `count` holds, computed WITHOUT the other slabs' tail work:
+        -> (video rows [1, C, T, rows, W] or None for an empty slab, (row0, row1, rows_per_slab, H)).  The blocks up to the last
+        temporal upsampling (26 % of the decode's FLOPs at 704 x 1280) run whole on every caller; the tail runs on the slab +
+        its halo.  Bit-identical to the same rows of `decode(z)` (tests/test_wan_vae_gpu.py)."""
+        return self.decode(z, return_dict="slab", slab=(index, count))
+
+    @torch.no_grad()
+    def decode(self, z, return_dict=True, slab=None):
         if z.shape[0] != 1:
+            if slab is not None:
+                raise NotImplementedError("decode_slab decodes one video per call")
             outs = [self.decode(z[i:i + 1], return_dict=False)[0] for i in range(z.shape[0])]
             out = torch.cat(outs)
             return (out,) if not return_dict else SimpleNamespace(sample=out)
@@ -555,20 +579,21 @@ class AutoencoderKLWan(FromPretrainedMixin):
         last_temporal = max([i for i in range(nb - 1) if tup[i]], default=-1)
         for i in range(last_temporal + 1):
             x = up_block(x, i)
-        chunk = self.decode_chunk_frames
-        tt = x.shape[0]
-        if chunk == "auto":
-            # measured: the whole-sequence peak is ~6.4 tensors of [T, H/2, W/2, decoder_base_dim] at the output size
-            sp = 2 ** (nb - 1 - (last_temporal + 1))
-            est = 6.4 * tt * x.shape[1] * sp * x.shape[2] * sp * cpad(cfg.decoder_base_dim) * 2 / 2 ** 30
-            if self._planes:
-                est *= 2 + self._planes                 # fp32 activations + their bf16 planes
-            chunk = 8 if est > self.decode_memory_budget_gib else 0
-        if not chunk or chunk >= tt or last_temporal + 1 >= nb:
-            for i in range(last_temporal + 1, nb):
-                x = up_block(x, i)
-            out = head(x)[None]
-        else:
+
+        def tail(x):
+            chunk = self.decode_chunk_frames
+            tt = x.shape[0]
+            if chunk == "auto":
+                # measured: the whole-sequence peak is ~6.4 tensors of [T, H/2, W/2, decoder_base_dim] at the output size
+                sp = 2 ** (nb - 1 - (last_temporal + 1))
+                est = 6.4 * tt * x.shape[1] * sp * x.shape[2] * sp * cpad(cfg.decoder_base_dim) * 2 / 2 ** 30
+                if self._planes:
+                    est *= 2 + self._planes                 # fp32 activations + their bf16 planes
+                chunk = 8 if est > self.decode_memory_budget_gib else 0
+            if not chunk or chunk >= tt or last_temporal + 1 >= nb:
+                for i in range(last_temporal + 1, nb):
+                    x = up_block(x, i)
+                return head(x)
             caches, out = {}, None
             for t0 in range(0, tt, chunk):
                 xc = x[t0:t0 + chunk]
@@ -576,9 +601,36 @@ class AutoencoderKLWan(FromPretrainedMixin):
                     xc = up_block(xc, i, caches)
                 v = head(xc, caches)
                 if out is None:
-                    out = torch.empty((1, v.shape[0], tt) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
-                out[0, :, t0:t0 + v.shape[1]] = v
+                    out = torch.empty((v.shape[0], tt) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+                out[:, t0:t0 + v.shape[1]] = v
                 del xc, v
+            return out
+
+        if slab is None or last_temporal + 1 >= nb:
+            out = tail(x)[None]
+        else:
+            # ---- the tail on ONE horizontal slab of the frame (round 6: N ranks decode N slabs, frameino_amd/parallel.py) ----
+            # From here on every layer is local in space except the 3 x 3 taps of its convolutions (RMS norms are per pixel, the
+            # mid-block attention is behind us, DupUp3D and nearest upsampling are pointwise): rows [a, b) of this tensor become
+            # rows [a, b) x (output rows per input row) of the video, and need input rows [a - halo, b + halo) -- one row per
+            # stride-1 3 x 3 convolution at this resolution, half a row per convolution behind a 2x upsample.  The slab is cut
+            # WITH that halo, runs through the unchanged layers (whose zero padding is right at the frame's own border and
+            # wrong at a cut: the error creeps in one row per convolution and ends exactly at the halo), and the halo's output
+            # is cropped.  Every kept element sees the same taps in the same K order as in the un-cut decode: bit-identical.
+            si, sn = int(slab[0]), int(slab[1])
+            hrows = x.shape[1]
+            halo, scale = self._tail_halo_rows(last_temporal + 1, nb)
+            per = -(-hrows // sn)
+            a, b = min(hrows, si * per), min(hrows, (si + 1) * per)
+            if b <= a:
+                out = None
+            else:
+                s0, s1 = max(0, a - halo), min(hrows, b + halo)
+                v = tail(x[:, s0:s1].contiguous())
+                del x
+                out = v[:, :, (a - s0) * scale:(b - s0) * scale].contiguous()[None]
+            if return_dict == "slab":
+                return out, (a * scale, b * scale, per * scale, hrows * scale)
         return (out,) if not return_dict else SimpleNamespace(sample=out)
 
     # ---- encode (reference :1145-1169, whole-sequence) ----

@@ -384,3 +384,30 @@ def shard_pipeline(pipe, rank, world, cfg_parallel=True, mode="split", plan=None
     pipe.token_shards = plan.token_ways
     pipe.transformer.parallel = plan.shard if plan.shard.active else None
     return plan
+
+
+def sharded_vae_decode(vae, z, rank, world, group=None):
+    """The Wan VAE decode on `world` ranks (round 6): every rank runs the blocks up to the last temporal upsampling (26 % of the
+    decode's FLOPs at 704 x 1280; no attention after them), then the tail -- up_blocks.2 / 3 + head, 74 %, local 3 x 3 x 3
+    convolutions -- on ITS horizontal slab of the frame plus the halo rows its 15 convolutions need (`AutoencoderKLWan.decode_slab`:
+    recomputed, not exchanged), and ONE all-gather of the finished video slabs puts the clip on every rank.  Bit-identical to
+    `vae.decode(z)`.  Reference: architecture/autoencoder_kl_wan.py:1198-1227 (decode), :783-909 (decoder); the reference has no
+    multi-GPU path.  -> video [1, C, T, H, W]."""
+    out, (r0, r1, per, height) = vae.decode_slab(z, rank, world)
+    probe = out if out is not None else None
+    if probe is None:                               # a slab past the frame's last row (world > rows): an empty contribution
+        raise ValueError(f"{world} slabs for a frame of {height} rows: fewer ranks than that, please")
+    _, c, t, _, w = out.shape
+    send = out.new_zeros((1, c, t, per, w))
+    send[:, :, :, :r1 - r0] = out
+    allv = out.new_empty((world, 1, c, t, per, w))
+    g = group if group is not None else dist.group.WORLD
+    if dist.get_backend(g) == "gloo" and out.is_cuda:           # tests: staged through the host
+        parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(world)]
+        dist.all_gather(parts, send.cpu().contiguous(), group=g)
+        allv.copy_(torch.stack(parts).to(out.device))
+    elif dist.get_backend(g) == "gloo":
+        dist.all_gather(list(allv.unbind(0)), send.contiguous(), group=g)
+    else:
+        dist.all_gather_into_tensor(allv, send.contiguous(), group=g)
+    return allv.permute(1, 2, 3, 0, 4, 5).reshape(1, c, t, world * per, w)[:, :, :, :height].contiguous()

@@ -104,6 +104,7 @@ class WanImageToVideoPipeline:
         self.video_processor = VideoProcessor(vae_scale_factor=self.vae_scale_factor_spatial)
         self.use_hip_graph = None        # None: graph replay whenever the loop is capturable (graph_step.StepGraph)
         self.batch_cfg = True            # run cond+uncond as one batch-2 forward when not CFG-parallel
+        self.shard_vae_decode = True     # under a multi-rank plan: every rank decodes a slab of the frame (parallel.sharded_vae_decode)
         self.cfg_streams = False         # ... or as two B=1 forwards on two concurrent streams (takes precedence)
         self._streams = None
         self._interrupt = False
@@ -532,7 +533,14 @@ class WanImageToVideoPipeline:
             mean = torch.tensor(cfgv.latents_mean).view(1, cfgv.z_dim, 1, 1, 1).to(lat.device, lat.dtype)
             inv_std = 1.0 / torch.tensor(cfgv.latents_std).view(1, cfgv.z_dim, 1, 1, 1).to(lat.device, lat.dtype)
             lat = lat / inv_std + mean                                                # :917-925
-            video = self.vae.decode(lat, return_dict=False)[0]
+            plan = getattr(self, "parallel", None)
+            if (plan is not None and plan.world > 1 and self.shard_vae_decode and hasattr(self.vae, "decode_slab")
+                    and lat.shape[0] == 1):
+                # every rank holds the same latents: each decodes its slab of the frame, one all-gather of video rows
+                from .parallel import sharded_vae_decode
+                video = sharded_vae_decode(self.vae, lat, plan.rank, plan.world)
+            else:
+                video = self.vae.decode(lat, return_dict=False)[0]
             video = self.video_processor.postprocess_video(video, output_type=output_type)
         else:
             video = latents

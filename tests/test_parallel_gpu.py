@@ -354,3 +354,44 @@ def test_capture_right_behind_eager_collectives_does_not_abort():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", _CAPTURE_STRESS, root, "12"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "STRESS OK" in p.stdout, (p.returncode, p.stderr[-2500:])
+
+
+# ---- round 6: the Wan VAE decode sharded over the ranks (parallel.sharded_vae_decode) ----
+def _vae_worker(rank, world, port, q, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+        from frameino_amd.configs import WAN22_VAE_CFG
+        from frameino_amd.parallel import sharded_vae_decode
+        vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=7, device="cuda:0")
+        z = torch.randn(1, 48, 2, 12, 20, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(8))
+        whole = vae.decode(z, return_dict=False)[0]
+        out = sharded_vae_decode(vae, z, rank, world)
+        q.put((rank, bool(torch.equal(out, whole)), tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")], ids=["2 ranks gloo", "3 ranks gloo (ragged slabs)",
+                                                                                         "RCCL communicator of one rank"])
+def test_sharded_vae_decode_on_every_rank_equals_the_whole_decode(world, backend):
+    """every rank decodes its slab of the frame, one all-gather of the video rows: all ranks end with the whole clip, bit-equal to
+    `vae.decode` (full-width Wan2.2 VAE, 192 x 320 frame: 48 rows of decoder-tail input / slabs of 24 and 16 + halo 10)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vae_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in outs) == list(range(world))
+    for rank, same, shape in outs:
+        assert same and shape == (1, 3, 5, 192, 320), (rank, same, shape)

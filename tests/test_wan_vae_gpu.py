@@ -364,3 +364,34 @@ def test_full_size_encode_vs_oracle_fp32_on_device(planes, max_rel):
     print(f"encode 9 frames 704x1280, {name}: rel-RMS of the moments {r:.2e}")
     record(f"wan_vae_encode_{name}_9_frames_704x1280", "rel_rms of the moments vs oracle fp32 on device", r, max_rel)
     assert r < max_rel, r
+
+
+# ------------------------------------------------------------------------------------------------ decoder tail in slabs (round 6)
+@pytest.mark.parametrize("count,latent_frames,fp32", [(4, 13, False), (2, 5, False), (3, 5, False), (8, 3, False), (2, 3, True)],
+                         ids=["4 slabs, 49 frames", "2 slabs", "3 ragged slabs", "8 slabs", "2 slabs fp32-compute"])
+def test_decoder_tail_in_slabs_is_bit_identical_to_the_whole_decode_at_704x1280(count, latent_frames, fp32):
+    """N ranks of a node decode N horizontal slabs of the frame (frameino_amd/parallel.py::sharded_vae_decode): the blocks up to the
+    last temporal upsampling whole, the tail (up_blocks.2 / 3 + head: 74 % of the FLOPs, 15 convolutions, no attention) on the slab
+    + 10 halo rows each side.  Simulated here as N calls on one GPU: the slabs put together must EQUAL `decode(z)`, bit for bit, at
+    the bench's 704 x 1280 -- whole slabs, ragged ones (176 rows / 3), the fp32-compute mode."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=7, device=DEV)
+    if fp32:
+        vae.set_compute_dtype(torch.float32)
+    z = torch.randn(1, 48, latent_frames, 44, 80, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    whole = vae.decode(z, return_dict=False)[0]
+    assert whole.shape == (1, 3, 1 + 4 * (latent_frames - 1), 704, 1280)
+    assert vae._tail_halo_rows(2, 4) == (10, 4)
+    rows_seen = 0
+    for i in range(count):
+        part, (r0, r1, per, height) = vae.decode_slab(z, i, count)
+        assert height == 704 and r0 == rows_seen and per == -(-176 // count) * 4
+        assert part.shape == (1, 3, whole.shape[2], r1 - r0, 1280)
+        assert torch.equal(part, whole[:, :, :, r0:r1]), (i, float((part - whole[:, :, :, r0:r1]).abs().max()))
+        rows_seen = r1
+        del part
+    assert rows_seen == 704
+    # a slab count larger than anything sensible still tiles the frame (empty slabs are None)
+    got = [vae.decode_slab(z[:, :, :1], i, 200)[0] for i in (0, 175, 176, 199)]
+    assert got[0] is not None and got[1] is not None and got[2] is None and got[3] is None

@@ -17,6 +17,9 @@ ap.add_argument("--encode", action="store_true")
 ap.add_argument("--cog", action="store_true", help="CogVideoX VAE (49 f 480x720: latent 13 x 60 x 90) instead of the Wan one")
 ap.add_argument("--fp32", type=int, default=0, metavar="PLANES",
                 help="Wan VAE in the fp32-compute mode (set_compute_dtype(torch.float32, planes=2|3): split-bf16 products)")
+ap.add_argument("--slabs", type=int, default=0, metavar="N",
+                help="Wan decode: time what ONE rank of an N-rank sharded decode does (slab 0 .. N-1 each, "
+                     "AutoencoderKLWan.decode_slab: replicated head of the decoder + the tail on a slab with its halo)")
 ap.add_argument("--tiling", action="store_true", help="--cog: diffusers' tiled encode / decode (enable_tiling())")
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -58,6 +61,14 @@ for it in range(2):
           f"total {s.get('total_ms', 0):.1f} ms, {kt.flops.get('conv3d', 0) / max(s.get('total_ms', 1), 1e-9) / 1e9:.1f} TFLOP/s "
           f"(padded FLOPs {kt.flops.get('conv3d', 0):.3e}); peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 assert torch.isfinite(out).all()
+if a.slabs:
+    for i in range(a.slabs):
+        for it in range(2):
+            torch.cuda.synchronize(); t0 = time.time()
+            part, geo = vae.decode_slab(z, i, a.slabs)
+            torch.cuda.synchronize(); dt = time.time() - t0
+        print(f"decode_slab {i} of {a.slabs}: rows [{geo[0]}, {geo[1]}) of {geo[3]}: {dt:.3f} s", flush=True)
+        assert torch.equal(part, out[:, :, :, geo[0]:geo[1]])
 if a.encode:
     vid = torch.rand(1, 3, 1 + 4 * (a.frames - 1), a.h * 16, a.w * 16, device=dev) * 2 - 1
     for it in range(2):
