@@ -29,8 +29,22 @@ where the kernels around it run:
 
 A segfault cannot be caught, so the rule is static: the K|V all-gather captures when it is issued on the step's own stream --
 the split plan does that by construction, the interleaved plan (two side streams, two communicators) since round 5 through
-`TokenShard.issue_stream`; tests/test_parallel_gpu.py replays both bit-equal through real RCCL communicators.  The heads
-all-to-all stays eager until the runtime is fixed.  With more than one rank a capture has never run on real links here: it is
+`TokenShard.issue_stream`; tests/test_parallel_gpu.py replays both bit-equal through real RCCL communicators.
+
+Round 6 (profiles/r06_rccl_capture_probe.txt) -- the heads all-to-all, every c10d entry point that moves its bytes:
+
+    all_to_all_single / all_to_all (tensor lists) / unequal splits / batch_isend_irecv,
+      async_op=True, capturing stream current (with the watchdog drained, thread_local mode)    SIGSEGV inside hipStreamEndCapture
+    all_to_all_single / all_to_all (lists), SYNCHRONOUS, capturing stream current                 captured, replayed, bit-equal, also
+                                                                                                on new operand data; the process
+                                                                                                group's teardown hangs IF the graph
+                                                                                                is still alive -- with the graph
+                                                                                                destroyed first it returns
+    all_gather_into_tensor of the send blocks + a local pick (ways x the bytes)                 captured, replayed, bit-equal
+
+So a captured step issues the all-to-all synchronously on the step's own stream (`TokenShard._issue(sync_in_capture=True)`; the
+eager step keeps the asynchronous form and its overlap), and `StepGraph.close()` drops the graph when the loop ends -- before
+anyone can destroy the process group.  With more than one rank a capture has never run on real links here: it is
 taken only when asked for (`use_hip_graph = True`).  A gloo exchange staged through host memory (tests) and a user callback
 between steps cannot be captured either.
 
@@ -47,10 +61,10 @@ def groups_capturable(plan, explicit=False):
     `explicit`: the caller asked for the graph (`use_hip_graph = True`) -- needed with more than one rank."""
     if plan is None:
         return True
-    if plan.exchange == "heads" and plan.shard.active:
-        return False                       # an all-to-all inside a capture segfaults in hipStreamEndCapture / hangs in teardown
-    # (the interleaved plan's K|V all-gathers are issued on the step's own stream -- TokenShard.issue_stream -- while the
-    # branches' kernels run on two side streams: that pattern captures; round 5 probe)
+    # (the interleaved plan's collectives are issued on the step's own stream -- TokenShard.issue_stream -- while the branches'
+    # kernels run on two side streams: that pattern captures; round 5 probe.  Round 6: the heads all-to-all captures too, as a
+    # SYNCHRONOUS collective on that stream -- TokenShard._issue(sync_in_capture=True) -- provided the graph is destroyed before
+    # the process group: StepGraph.close)
     if plan.world > 1 and not explicit:
         return False                       # never run on real xGMI links here: opt-in
     import torch.distributed as dist
@@ -151,3 +165,10 @@ class StepGraph:
                 self.graph = g
             self.graph.replay()
         self.ran += 1
+
+    def close(self):
+        """Drop the captured graph (call when the loop ends).  A graph that holds a captured all-to-all must die BEFORE the process
+        group does: `destroy_process_group()` never returns while such a graph is alive (profiles/r06_rccl_capture_probe.txt)."""
+        if self.graph is not None:
+            self.graph = None
+            torch.cuda.synchronize()

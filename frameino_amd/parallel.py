@@ -173,11 +173,25 @@ class TokenShard:
     # capture stream survives a capture.  Results are bit-identical either way (the kernels and their order do not change).
     issue_stream = None
 
-    def _issue(self, fn, t, async_op):
+    def _issue(self, fn, t, async_op, sync_in_capture=False):
         """run the collective `fn()` (-> work handle) with `issue_stream` current; the calling stream waits for it at once unless
-        async_op.  -> work handle or None"""
+        async_op.  -> work handle or None.
+        `sync_in_capture` (the all-to-all, round 6): inside a hipGraph capture the collective is issued SYNCHRONOUSLY on the step's
+        own stream -- c10d then runs it on that stream itself instead of forking its communicator stream; an asynchronous
+        send / receive-based collective (ncclAllToAll, grouped ncclSend / ncclRecv, batch_isend_irecv) segfaults in
+        hipStreamEndCapture on this image, the synchronous form captures and replays bit-equal (tools/debug/rccl_capture_probe.py,
+        profiles/r06_rccl_capture_probe.txt).  The graph must then be destroyed BEFORE the process group (StepGraph.close)."""
         iss = self.issue_stream
         cur = torch.cuda.current_stream() if (iss is not None and t.is_cuda) else None
+        if sync_in_capture and t.is_cuda and torch.cuda.is_current_stream_capturing():
+            if cur is None or cur == iss:
+                fn(False)
+                return None
+            iss.wait_stream(cur)
+            with torch.cuda.stream(iss):
+                fn(False)
+            cur.wait_stream(iss)                 # the branch's stream goes on behind the collective
+            return None
         if cur is None or cur == iss:
             return fn(async_op)
         iss.wait_stream(cur)                     # what produced `t` is enqueued on the calling (branch) stream
@@ -269,7 +283,8 @@ class TokenShard:
             dist.all_to_all_single(r, send.cpu().contiguous(), group=self.group)
             recv.copy_(r.to(send.device))
             return recv, None
-        work = self._issue(lambda a_: dist.all_to_all_single(recv, send, group=self.group, async_op=a_), send, async_op)
+        work = self._issue(lambda a_: dist.all_to_all_single(recv, send, group=self.group, async_op=a_), send, async_op,
+                           sync_in_capture=True)
         return recv, (work if async_op else None)
 
     def a2a_buffer(self, key, shape, dtype, dev):

@@ -311,6 +311,7 @@ class CogVideoXImageToVideoPipeline:
                 out = callback_on_step_end(self, i, t, {"latents": lat[None]})
                 if "latents" in out and out["latents"] is not None:
                     lat.copy_(out["latents"][0])
+        stepper.close()
         return lat[None]
 
     def _step(self, st):

@@ -487,6 +487,7 @@ class WanImageToVideoPipeline:
                     st.pe, st.ne = pe, ne
                     st.pe_ne = torch.cat([pe, ne], dim=0).contiguous() if st.cfg and pe.shape == ne.shape else None
         self._current_timestep = None
+        stepper.close()
         return (1 - first_frame_mask) * condition + first_frame_mask * st.lat[None]          # :913
 
     @torch.no_grad()

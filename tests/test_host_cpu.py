@@ -135,12 +135,13 @@ def test_step_graph_policy_and_schedule():
     # round 5: the interleaved plan's K|V all-gathers are issued on the step's own stream (TokenShard.issue_stream) while the
     # branches' kernels run on side streams -- that pattern captures (profiles/r05_rccl_capture_probe.txt)
     assert G.groups_capturable(plan(interleave=True))
-    assert not G.groups_capturable(plan(exchange="heads"))                # all_to_all_single: segfault in hipStreamEndCapture
-    assert not G.groups_capturable(plan(interleave=True, exchange="heads"))
+    # round 6: the heads all-to-all captures as a SYNCHRONOUS collective on the step's own stream (TokenShard._issue)
+    assert G.groups_capturable(plan(exchange="heads")) and G.groups_capturable(plan(interleave=True, exchange="heads"))
     assert not G.groups_capturable(plan(world=4))                         # real links: only on request
     assert G.groups_capturable(plan(world=4), explicit=True)
     assert G.groups_capturable(plan(world=4, interleave=True), explicit=True)
-    assert not G.groups_capturable(plan(world=4, interleave=True, exchange="heads"), explicit=True)
+    assert G.groups_capturable(plan(world=4, interleave=True, exchange="heads"), explicit=True)
+    assert not G.groups_capturable(plan(world=4, interleave=True, exchange="heads"))
     # schedule: eager when not capturable / fewer than three steps / mode False; an impossible explicit request raises
     calls = []
     sg = G.StepGraph(lambda: calls.append("s"), None, False, 10)

@@ -16,7 +16,14 @@ PATTERNS = ["allgather_main", "allgather_side", "allgather_two_comms_two_sides",
             "allgather_main_issue_side_wait_two_comms",
             # round 5, second pass: SYNCHRONOUS collectives (torch >= 2.7 runs them on the current stream, no communicator-stream
             # fork) on a side stream forked from the capturing one
-            "alltoall_side_sync", "allgather_side_sync", "alltoall_two_sides_sync"]
+            "alltoall_side_sync", "allgather_side_sync", "alltoall_two_sides_sync",
+            # round 6: the heads exchange's bytes through OTHER c10d entry points (all_to_all_single with equal splits is RCCL's
+            # ncclAllToAll on ROCm builds; these go through grouped ncclSend / ncclRecv, or through the all-gather that captures)
+            "alltoall_list_main", "alltoall_list_main_sync", "alltoall_unequal_main", "isend_irecv_main",
+            "alltoall_list_side_wait", "allgather_select_main"]
+# PROBE_SAFE=1: capture the way frameino_amd/graph_step.py does since round 5 / 6 -- drain_collectives() first (c10d's watchdog
+# holds no eager work), capture_error_mode="thread_local"
+SAFE = os.environ.get("PROBE_SAFE") == "1"
 
 
 def child(pattern):
@@ -55,6 +62,47 @@ def child(pattern):
         if pattern == "alltoall_main_sync":
             dist.all_to_all_single(y1, x, group=ga)
             return y1 + 1
+        if pattern in ("alltoall_list_main", "alltoall_list_main_sync", "alltoall_list_side_wait"):
+            # dist.all_to_all on tensor LISTS: ProcessGroupNCCL::alltoall -> torch::cuda::nccl::all2all = ncclGroupStart,
+            # one ncclSend + ncclRecv per peer, ncclGroupEnd
+            ins, outs = list(x.view(1, -1, 256).unbind(0)), list(y1.view(1, -1, 256).unbind(0))
+            if pattern == "alltoall_list_main_sync":
+                dist.all_to_all(outs, ins, group=ga)
+                return y1 + 1
+            w = dist.all_to_all(outs, ins, group=ga, async_op=True)
+            z = x * 2
+            if pattern == "alltoall_list_side_wait":
+                s1.wait_stream(main)
+                with torch.cuda.stream(s1):
+                    w.wait()
+                    r = y1 + z
+                main.wait_stream(s1)
+                return r
+            w.wait()
+            return y1 + z
+        if pattern == "alltoall_unequal_main":
+            # explicit split sizes: all2all_single_unequal_split (grouped send / recv) instead of ncclAllToAll
+            w = dist.all_to_all_single(y1, x, output_split_sizes=[x.shape[0]], input_split_sizes=[x.shape[0]], group=ga,
+                                       async_op=True)
+            z = x * 2
+            w.wait()
+            return y1 + z
+        if pattern == "isend_irecv_main":
+            ops_ = [dist.P2POp(dist.isend, x, 0, group=ga), dist.P2POp(dist.irecv, y1, 0, group=ga)]
+            reqs = dist.batch_isend_irecv(ops_)
+            z = x * 2
+            for r_ in reqs:
+                r_.wait()
+            return y1 + z
+        if pattern == "allgather_select_main":
+            # the exchange as an all-gather of every rank's whole send buffer [ways, rows, width] + a local pick of "my" slice of
+            # each: `ways` times the bytes, but the collective that is known to capture
+            big = torch.empty((1,) + tuple(x.shape), device=x.device)
+            w = dist.all_gather_into_tensor(big, x[None], group=ga, async_op=True)
+            z = x * 2
+            w.wait()
+            y1.copy_(big[0])
+            return y1 + z
         if pattern in ("allgather_side", "alltoall_side"):
             s1.wait_stream(main)
             with torch.cuda.stream(s1):
@@ -153,13 +201,38 @@ def child(pattern):
     torch.cuda.synchronize()
     print(f"[{pattern}] eager ok", flush=True)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    if SAFE:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        from frameino_amd.graph_step import drain_collectives
+        drain_collectives()
+    with torch.cuda.graph(g, capture_error_mode="thread_local" if SAFE else "global"):
         out = body()
     print(f"[{pattern}] captured", flush=True)
     g.replay()
     torch.cuda.synchronize()
     print(f"[{pattern}] replayed equal={bool(torch.equal(out, ref))}", flush=True)
+    x.mul_(-0.5)                                    # new input through the same graph: a replay that re-reads its operands
+    ref2 = body()
+    g.replay()
+    torch.cuda.synchronize()
+    print(f"[{pattern}] replayed on new data equal={bool(torch.equal(out, ref2))}", flush=True)
     faulthandler.cancel_dump_traceback_later()
+    if os.environ.get("PROBE_DEL_GRAPH") == "1":
+        # does the teardown hang of a captured synchronous all-to-all go away when the graph dies BEFORE the process group?
+        import gc
+        del g, out
+        gc.collect()
+        torch.cuda.synchronize()
+        print(f"[{pattern}] graph deleted", flush=True)
+    if os.environ.get("PROBE_ABORT_PG") == "1":
+        # ... or when the communicators are aborted instead of destroyed in order?
+        for pg in (ga, gb, dist.group.WORLD):
+            try:
+                pg._get_backend(dev).abort()
+            except Exception as ex:      # noqa: BLE001
+                print(f"[{pattern}] abort: {type(ex).__name__}: {ex}", flush=True)
+        print(f"[{pattern}] aborted", flush=True)
+    faulthandler.dump_traceback_later(25, exit=True)
     dist.destroy_process_group()
     print(f"[{pattern}] DONE", flush=True)
 
