@@ -14,7 +14,7 @@ csrc="$here/../../frameino_amd/csrc"
 srcdir="$csrc"
 if [ "$1" = "--experiments" ]; then
     shift
-    srcdir="$here/../../gpurun_out/debug/csrc_exp"   # scratch, outside the package (two levels under the root: the sources include ../../include/frameino_hip.h)
+    srcdir="$here/../../gpurun_out/csrc_exp"   # scratch, outside the package (two levels under the root: the sources include ../../include/frameino_hip.h)
     mkdir -p "$(dirname "$srcdir")"
     python3 "$here/strip_experiments.py" --apply "$srcdir" > /dev/null
 fi
