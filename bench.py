@@ -786,6 +786,17 @@ def main():
                                                "split-bf16 product (3 bf16 planes per operand, 6 MFMA terms, fp32 accumulate): "
                                                "fp32-faithful (tests/test_wan_vae_gpu.py), opt-in"})
                 del vid
+                # ---- ... and the whole clip in the APP'S precision mix as ONE call (app.py:156-157: the DiT in fp16, the VAE in fp32 --
+                # here its fp32-compute mode): what a user of the reference's app gets from the drop-in, timed by the wall clock ----
+                if not a.no_secondary and not a.mxfp8 and not a.fp8_attention:
+                    m16 = build_model(cfg, dev, dtype=torch.float16)
+                    clip16 = measured_clip(m16, vae, cfg, dev, fg, lh, lw)
+                    extra["sec_per_clip_measured_app_mix"] = clip16["sec_per_clip_measured"]
+                    extra["sec_per_clip_measured_app_mix_stages"] = clip16["sec_per_clip_measured_stages"]
+                    extra["sec_per_clip_measured_app_mix_what"] = ("the same pipe(...) call with the DiT in fp16 and the VAE computing like "
+                                                                   "fp32 (set_compute_dtype(torch.float32)): app.py:156-157's precision mix")
+                    del m16
+                    torch.cuda.empty_cache()
             except Exception as ex:      # noqa: BLE001
                 extra["vae_decode_fp32_s"] = None
                 extra["vae_fp32_what"] = f"failed: {type(ex).__name__}: {ex}"

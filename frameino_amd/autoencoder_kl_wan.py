@@ -634,8 +634,28 @@ class AutoencoderKLWan(FromPretrainedMixin):
         return (out,) if not return_dict else SimpleNamespace(sample=out)
 
     # ---- encode (reference :1145-1169, whole-sequence) ----
+    _ENC_SLAB_BLOCKS = 2          # conv_in + down_blocks.0 / .1 (73 % of the encoder's FLOPs at 704 x 1280) run on a slab; see _enc_halo_rows
+
+    def _enc_halo_rows(self, k):
+        """(rows of halo above, below) -- at the resolution of conv_in's input -- that rows [a, b) of the output of `down_blocks[k - 1]`
+        need, rounded up to multiples of 2^k so that a slab starts on the same phase of every stride-2 convolution as the whole frame
+        does (and the asymmetric ZeroPad2d((0, 1, 0, 1)) lands on the frame's own bottom edge only).  Walking back from the output: a
+        stride-2 3 x 3 convolution reads input rows 2r .. 2r + 2 (and the AvgDown3D shortcut 2r, 2r + 1), a stride-1 one r - 1 .. r + 1."""
+        nrb = self.config.num_res_blocks
+        lo = hi = 0
+        for _ in range(k):
+            lo, hi = 2 * lo, 2 * hi + 1                       # the block's downsampler
+            lo, hi = lo + 2 * nrb, hi + 2 * nrb               # its resnets (two 3 x 3 x 3 convolutions each)
+        lo, hi = lo + 1, hi + 1                               # conv_in
+        q = 2 ** k
+        return -(-lo // q) * q, -(-hi // q) * q
+
     @torch.no_grad()
-    def _encode(self, x):
+    def _encode(self, x, slab=None, resume=None):
+        """`slab=(index, count)`: run conv_in and the first `_ENC_SLAB_BLOCKS` down blocks on one horizontal slab of the frame (+ halo)
+        and return (rows [a, b) of that block's output [T', b - a, W', Cpad], (a, b, rows per slab, H')) -- bit-identical to those rows of
+        the whole encode.  `resume=activation`: continue from that block's (gathered) output to the moments.  (round 6:
+        frameino_amd/parallel.py::sharded_vae_encode)"""
         pk = self._pk or self._pack()
         cfg, dt = self.config, self._dtype
         mult = cfg.dim_mult
@@ -644,10 +664,31 @@ class AutoencoderKLWan(FromPretrainedMixin):
         ps = cfg.patch_size or 1
         if self._planes:
             dt = torch.float32
-        x = ops.vae_patchify(x[0].float().contiguous(), cpad(cfg.in_channels), ps, dt)
-        x = self._causal3(x, "encoder.conv_in")
         nb = len(mult)
-        for i in range(nb):
+        k = min(self._ENC_SLAB_BLOCKS, nb - 1)
+        crop = None
+        if resume is not None:
+            x, first = resume, k
+        else:
+            x = ops.vae_patchify(x[0].float().contiguous(), cpad(cfg.in_channels), ps, dt)
+            first = 0
+            if slab is not None:
+                si, sn = int(slab[0]), int(slab[1])
+                q = 2 ** k
+                h0 = x.shape[1]
+                if h0 % q:
+                    raise ValueError(f"encode_slab: the frame's {h0 * ps} rows must be a multiple of {q * ps}")
+                hk = h0 // q
+                per = -(-hk // sn)
+                a, b = min(hk, si * per), min(hk, (si + 1) * per)
+                if b <= a:
+                    return None, (a, b, per, hk)
+                lo, hi = self._enc_halo_rows(k)
+                s0, s1 = max(0, a * q - lo), min(h0, b * q + hi)
+                x = x[:, s0:s1].contiguous()
+                crop = (a - s0 // q, b - s0 // q, (a, b, per, hk))
+            x = self._causal3(x, "encoder.conv_in")
+        for i in range(first, nb):
             p = f"encoder.down_blocks.{i}"
             down_flag = i != nb - 1
             temporal = bool(tdown[i]) if down_flag else False
@@ -665,12 +706,24 @@ class AutoencoderKLWan(FromPretrainedMixin):
                                     out_thw=((tt - 1) // 2, x.shape[1], x.shape[2]))
                     x = torch.cat([x[:1], zc], dim=0)
             x = ops.avg_down3d_add(x, x_copy, enc[i], enc[i + 1], 2 if temporal else 1, 2 if down_flag else 1)
+            if crop is not None and i == k - 1:
+                return x[:, crop[0]:crop[1]].contiguous(), crop[2]
         x = self._mid(x, "encoder.mid_block")
         x = self._norm(x, "encoder.norm_out.gamma")
         x = self._causal3(x, "encoder.conv_out")
         x = self._causal3(x, "quant_conv")
         z2 = 2 * cfg.z_dim
         return x[..., :z2].permute(3, 0, 1, 2).float()[None].contiguous()             # [1, 2z, T', h, w]
+
+    def encode_slab(self, x, index, count):
+        """-> (rows [a, b) of the activation behind `encoder.down_blocks[_ENC_SLAB_BLOCKS - 1]` or None, (a, b, rows per slab, H'))"""
+        if x.shape[0] != 1:
+            raise NotImplementedError("encode_slab encodes one video per call")
+        return self._encode(x, slab=(index, count))
+
+    def encode_resume(self, activation):
+        """the rest of the encoder on the (gathered) activation `encode_slab` returns pieces of -> latent_dist"""
+        return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(self._encode(None, resume=activation)))
 
     def encode(self, x, return_dict=True):
         moments = torch.cat([self._encode(x[i:i + 1]) for i in range(x.shape[0])])

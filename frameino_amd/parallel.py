@@ -426,3 +426,32 @@ def sharded_vae_decode(vae, z, rank, world, group=None):
     else:
         dist.all_gather_into_tensor(allv, send.contiguous(), group=g)
     return allv.permute(1, 2, 3, 0, 4, 5).reshape(1, c, t, world * per, w)[:, :, :, :height].contiguous()
+
+
+def sharded_vae_encode(vae, x, rank, world, group=None):
+    """The Wan VAE encode of one video on `world` ranks (round 6): conv_in and the first two down blocks -- 73 % of the encoder's
+    FLOPs at 704 x 1280, all local 3 x 3 (x 3) convolutions -- run on the rank's horizontal slab of the frame plus a recomputed halo
+    (`AutoencoderKLWan.encode_slab`), ONE all-gather of the slabs' activations (a quarter of the frame's rows, 320 channels) puts
+    the whole tensor on every rank, and the rest (two down blocks, the mid block with its attention, the head) runs replicated.
+    Bit-identical to `vae.encode(x)`.  Reference: architecture/autoencoder_kl_wan.py:1145-1169 (encode), :505-623 (encoder); the
+    reference has no multi-GPU path.  -> what `vae.encode(x)` returns (`.latent_dist`)."""
+    part, (a, b, per, hk) = vae.encode_slab(x, rank, world)
+    g = group if group is not None else dist.group.WORLD
+    # (every rank can derive the activation's shape from its own slab; a rank whose slab is empty asks the others: rare -- more
+    # ranks than rows -- and refused)
+    if part is None:
+        raise ValueError(f"{world} slabs for {hk} rows of encoder activation: fewer ranks than that, please")
+    t, _, w, c = part.shape
+    send = part.new_zeros((t, per, w, c))
+    send[:, :b - a] = part
+    allv = part.new_empty((world, t, per, w, c))
+    if dist.get_backend(g) == "gloo" and part.is_cuda:           # tests: staged through the host
+        parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(world)]
+        dist.all_gather(parts, send.cpu().contiguous(), group=g)
+        allv.copy_(torch.stack(parts).to(part.device))
+    elif dist.get_backend(g) == "gloo":
+        dist.all_gather(list(allv.unbind(0)), send.contiguous(), group=g)
+    else:
+        dist.all_gather_into_tensor(allv, send.contiguous(), group=g)
+    full = allv.permute(1, 0, 2, 3, 4).reshape(t, world * per, w, c)[:, :hk].contiguous()
+    return vae.encode_resume(full)

@@ -105,6 +105,7 @@ class WanImageToVideoPipeline:
         self.use_hip_graph = None        # None: graph replay whenever the loop is capturable (graph_step.StepGraph)
         self.batch_cfg = True            # run cond+uncond as one batch-2 forward when not CFG-parallel
         self.shard_vae_decode = True     # under a multi-rank plan: every rank decodes a slab of the frame (parallel.sharded_vae_decode)
+        self.shard_vae_encode = True     # ... and encodes a slab of the trajectory video (parallel.sharded_vae_encode)
         self.cfg_streams = False         # ... or as two B=1 forwards on two concurrent streams (takes precedence)
         self._streams = None
         self._interrupt = False
@@ -280,7 +281,14 @@ class WanImageToVideoPipeline:
         cond = self.vae.encode(video_condition).latent_dist.mode().repeat(batch_size, 1, 1, 1, 1)
         cond = self._norm_latents(cond, dtype)
         traj = traj_tensor.to(device, dtype=vdt).unsqueeze(0).permute(0, 2, 1, 3, 4)  # [1, C, F, H, W]
-        traj_latents = self._norm_latents(self.vae.encode(traj).latent_dist.mode(), dtype)
+        plan = getattr(self, "parallel", None)
+        if plan is not None and plan.world > 1 and self.shard_vae_encode and hasattr(self.vae, "encode_slab") and traj.shape[2] > 1:
+            # the one long encode of a call (the trajectory video): every rank a slab of the frame (parallel.sharded_vae_encode)
+            from .parallel import sharded_vae_encode
+            traj_post = sharded_vae_encode(self.vae, traj, plan.rank, plan.world).latent_dist
+        else:
+            traj_post = self.vae.encode(traj).latent_dist
+        traj_latents = self._norm_latents(traj_post.mode(), dtype)
         traj_latents = traj_latents.contiguous().float()
         id_cond = None
         if ID_tensor is not None and ID_tensor.shape[2] != 0:

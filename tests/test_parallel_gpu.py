@@ -371,14 +371,18 @@ def _vae_worker(rank, world, port, q, backend):
         z = torch.randn(1, 48, 2, 12, 20, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(8))
         whole = vae.decode(z, return_dict=False)[0]
         out = sharded_vae_decode(vae, z, rank, world)
-        q.put((rank, bool(torch.equal(out, whole)), tuple(out.shape)))
+        # ... and the encode of a 5-frame 192 x 320 video: 24 rows of activation behind down_blocks.1, slabs of 12 / 8 + halo 4
+        from frameino_amd.parallel import sharded_vae_encode
+        xv = torch.rand(1, 3, 5, 192, 320, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(9)) * 2 - 1
+        enc_same = torch.equal(sharded_vae_encode(vae, xv, rank, world).latent_dist.parameters, vae.encode(xv).latent_dist.parameters)
+        q.put((rank, bool(torch.equal(out, whole)) and bool(enc_same), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")], ids=["2 ranks gloo", "3 ranks gloo (ragged slabs)",
                                                                                          "RCCL communicator of one rank"])
-def test_sharded_vae_decode_on_every_rank_equals_the_whole_decode(world, backend):
+def test_sharded_vae_decode_and_encode_on_every_rank_equal_the_whole_ones(world, backend):
     """every rank decodes its slab of the frame, one all-gather of the video rows: all ranks end with the whole clip, bit-equal to
     `vae.decode` (full-width Wan2.2 VAE, 192 x 320 frame: 48 rows of decoder-tail input / slabs of 24 and 16 + halo 10)"""
     ctx = mp.get_context("spawn")

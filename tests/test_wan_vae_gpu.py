@@ -395,3 +395,45 @@ def test_decoder_tail_in_slabs_is_bit_identical_to_the_whole_decode_at_704x1280(
     # a slab count larger than anything sensible still tiles the frame (empty slabs are None)
     got = [vae.decode_slab(z[:, :, :1], i, 200)[0] for i in (0, 175, 176, 199)]
     assert got[0] is not None and got[1] is not None and got[2] is None and got[3] is None
+
+
+def test_decoder_tail_in_eight_slabs_at_config4_size_1024x1792():
+    """BASELINE config 4's frame (1024 x 1792: 256 rows of decoder-tail input, 32 per rank + 10 halo rows each side) on the 8 ranks it
+    names, 3 latent frames: every slab bit-equal to its rows of the whole decode"""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=9, device=DEV)
+    z = torch.randn(1, 48, 3, 64, 112, device=DEV, generator=torch.Generator(device=DEV).manual_seed(10))
+    whole = vae.decode(z, return_dict=False)[0]
+    assert whole.shape == (1, 3, 9, 1024, 1792)
+    for i in range(8):
+        part, (r0, r1, per, height) = vae.decode_slab(z, i, 8)
+        assert (r0, r1, per, height) == (128 * i, 128 * (i + 1), 128, 1024)
+        assert torch.equal(part, whole[:, :, :, r0:r1])
+        del part
+
+
+@pytest.mark.parametrize("count,frames,fp32", [(4, 49, False), (2, 9, False), (3, 9, False), (8, 5, False), (2, 5, True)],
+                         ids=["4 slabs, 49 frames", "2 slabs", "3 ragged slabs", "8 slabs", "2 slabs fp32-compute"])
+def test_encoder_head_in_slabs_is_bit_identical_to_the_whole_encode_at_704x1280(count, frames, fp32):
+    """The trajectory-video encode on N ranks (parallel.sharded_vae_encode): conv_in + down_blocks.0 / .1 on horizontal slabs with a
+    16-row halo (a multiple of 4, so that a slab keeps the frame's phase through both stride-2 convolutions), the slabs' activations put
+    together, the rest of the encoder on the whole tensor.  Simulated as N calls on one GPU: the assembled activation must resume to
+    EXACTLY the moments of `encode(x)`."""
+    from frameino_amd.autoencoder_kl_wan import AutoencoderKLWan
+    from frameino_amd.configs import WAN22_VAE_CFG
+    vae = AutoencoderKLWan(**WAN22_VAE_CFG).random_init_(seed=7, device=DEV)
+    if fp32:
+        vae.set_compute_dtype(torch.float32)
+    x = torch.rand(1, 3, frames, 704, 1280, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8)) * 2 - 1
+    whole = vae.encode(x).latent_dist.parameters
+    assert vae._enc_halo_rows(2) == (16, 16)
+    parts, rows_seen = [], 0
+    for i in range(count):
+        part, (a, b, per, hk) = vae.encode_slab(x, i, count)
+        assert hk == 88 and a == rows_seen and per == -(-88 // count) and part.shape[1] == b - a
+        parts.append(part)
+        rows_seen = b
+    assert rows_seen == 88
+    post = vae.encode_resume(torch.cat(parts, dim=1)).latent_dist
+    assert torch.equal(post.parameters, whole)
