@@ -67,7 +67,7 @@ def test_bare_command_eight_gloo_ranks_on_one_gpu():
     # round 6: the metric's second half on the ranks -- one real pipe(...) call under the best plan, VAE decode in 8 slabs
     assert c["sec_per_clip_measured"] and c["sec_per_clip_measured"] > 0 and c["vae_decode_slabs"] == 8, c.get("sec_per_clip_measured_what")
     assert "finite=True" in c["sec_per_clip_measured_what"]
-    assert took < 300, took                    # (120 s of it is the budget of the run itself; the rest is 8 cold interpreter starts)
+    assert took < 420, took                    # (120 s of it is the budget of the run itself; the rest is 8 cold interpreter starts)
 
 
 @pytest.mark.gpu
