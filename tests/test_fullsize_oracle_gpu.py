@@ -34,8 +34,6 @@ def test_wan_two_layer_forward_full_size_vs_oracle_on_device(lh, lw, dtype):
     from frameino_amd.configs import WAN22_5B_CFG
     from frameino_amd.random_init import random_wan_model
     from oracle import wan_dit as W
-    if dtype == torch.float16 and lh == 64:
-        pytest.skip("fp16 at full size is covered at L = 12320 (Wan) and L = 19126 (CogVideoX)")
     cfg = dict(WAN22_5B_CFG, num_layers=2)
     m = random_wan_model(cfg, torch.device(DEV), seed=11, dtype=dtype)
     sd = _oracle_sd(m)
