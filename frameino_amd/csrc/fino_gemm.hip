@@ -589,8 +589,31 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pp_kernel(const GemmParams p
     int tm, tn;
     tile_coords(p, tm, tn);
     const int64_t m0 = (int64_t)tm * (32 * MI), n0 = (int64_t)tn * BN;
-    f32x4_t acc[MI][4];
     int nk = (int)(p.k / BK);
+    // A RAGGED LAST TILE ROW runs as a lower tile (round 6).  M = 24640 ends in a tile row of 64 rows, a 4-way token shard's 3080
+    // rows in one of 8: as a 256-row tile it issues every MFMA of 256 rows -- on a power-capped chip joules spent on rows that do not
+    // exist (1/13 of the GEMM's matrix work on that shard).  The loop and the epilogue are templates on the tile height, so the
+    // workgroup simply runs the 64- or 128-row instantiation on its rows: same K walk, same MFMA order per element, bit-identical
+    // results (tests/test_gemm_tiles_gpu.py), a quarter / half of the matrix instructions and of the A staging.
+#ifndef GP_RAGGED
+#define GP_RAGGED 1        /* A/B knob (same bits): 0 = the ragged last tile row as a whole 256-row tile (rounds 1 - 5) */
+#endif
+    if constexpr (GP_RAGGED && MI == 8 && !CONV && EPI != FINO_EPI_F32 && EPI != FINO_EPI_F32_RESIDUAL) {
+        const int64_t rows = p.m - m0;                      // (block-uniform)
+        if (rows <= 64) {
+            f32x4_t acc2[2][4];
+            pp_mainloop<T, false, 2, ABLK>(p, smem, m0, n0, 0, nk, acc2, tid, lane, wave, wm, wn);
+            gemm_epilogue<T, EPI, false, 2>(acc2, p, smem, m0, n0, tid, lane, wm, wn);
+            return;
+        }
+        if (rows <= 128) {
+            f32x4_t acc4[4][4];
+            pp_mainloop<T, false, 4, ABLK>(p, smem, m0, n0, 0, nk, acc4, tid, lane, wave, wm, wn);
+            gemm_epilogue<T, EPI, false, 4>(acc4, p, smem, m0, n0, tid, lane, wm, wn);
+            return;
+        }
+    }
+    f32x4_t acc[MI][4];
 #ifdef FINO_GEMM_STAMP
     unsigned long long ts0, ts1;
     STAMP(ts0)

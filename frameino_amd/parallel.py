@@ -73,14 +73,17 @@ class TokenShard:
 
     def tile_m_for(self, rows):
         """the tile height this shard's GEMM calls pass for `rows` rows.  A shard that asked for 256-row tiles (8: the interleaved
-        plan) gets 224-row ones (7) when they multiply >= 5 % fewer rows that do not exist: 1540 rows (8-way shard of L = 12320) are
-        7 tile rows either way -- 7 x 224 = 1568 against 7 x 256 = 1792 rows of MFMA work: 42.6 -> 40.6 ms per step and rank
-        (tools/plan_sim.py, profiles/r06_plan_sim_tile_modes.txt); 3080 rows (4-way) measure the same both ways.  A remainder
-        launch at a low height was measured too and LOSES (a second K walk per GEMM: 70.3 -> 77.1 ms at 4 ways)."""
+        plan) gets 224-row ones (7) when they multiply >= 5 % fewer rows that do not exist.  Since round 6 a RAGGED last tile row of
+        256-row tiles runs as a 64- or 128-row tile inside the same launch (csrc/fino_gemm.hip: `GP_RAGGED`), so 3080 rows (4-way shard
+        of L = 12320) count as 12 x 256 + 64 and 1540 rows (8-way) as 6 x 256 + 64: 256-row tiles win both (interleave:4 69.0 -> 67.7 ms
+        per step and rank against 69.7 - 71.1 with 224-row tiles, interleave:8 40.4 - 40.7 either way; tools/plan_sim.py,
+        profiles/r06_ragged_step_ab.txt).  A separate remainder LAUNCH was measured too and loses (a second K walk per GEMM:
+        70.3 -> 77.1 ms at 4 ways, profiles/r06_plan_sim_tile_modes.txt)."""
         t = int(self.gemm_tile_m)
         if t != 8 or rows <= 0:
             return t
-        pad8 = -(-rows // 256) * 256
+        rem = rows % 256
+        pad8 = rows - rem + (0 if rem == 0 else 64 if rem <= 64 else 128 if rem <= 128 else 256)
         pad7 = -(-rows // 224) * 224
         return 7 if pad7 < 0.95 * pad8 else 8
 

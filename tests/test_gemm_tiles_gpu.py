@@ -178,3 +178,28 @@ def test_blocked_a_with_non_power_of_two_blocks(blocks, blk_k):
     for tm in (8, 3):                                         # the per-call tile height does not change a bit either
         assert torch.equal(ops.gemm_blocked_a(orv, rows, w, b, x, gate, sel, out=torch.empty_like(x), tile_m=tm), want)
         assert torch.equal(ops.gemm(a, w, b, ops.EPI_GATED_RESIDUAL, x, gate, sel, tile_m=tm), want)
+
+
+@pytest.mark.parametrize("m", [8, 65, 129, 300, 3080, 1540])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gated"])
+def test_ragged_last_tile_row_runs_as_a_lower_tile_bit_identically(m, epi):
+    """Round 6 (`GP_RAGGED`): a launch of 256-row tiles runs a last tile row of <= 64 / <= 128 valid rows as the 64- / 128-row
+    instantiation of the same loop and epilogue.  Bit-equal to the one-height launches of 128-row tiles and to the planned launch, and
+    to a torch fp32 reference within bf16 rounding."""
+    from frameino_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(m)
+    n, k = 768, 1024
+    a = torch.randn(m, k, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(n, k, device=DEV, generator=g) * 0.05).bfloat16()
+    b = torch.randn(n, device=DEV, generator=g).bfloat16()
+    res = torch.randn(m, n, device=DEV, generator=g).bfloat16()
+    gate = torch.randn(2, n, device=DEV, generator=g)
+    sel = (torch.arange(m, device=DEV) % 2).to(torch.int32)
+    kw = {"bias": dict(epilogue=ops.EPI_NONE), "gelu": dict(epilogue=ops.EPI_GELU_TANH),
+          "gated": dict(epilogue=ops.EPI_GATED_RESIDUAL, residual=res, gate=gate, sel=sel)}[epi]
+    outs = [ops.gemm(a, w, b, tile_m=t, **kw) for t in (8, 4, 0)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    lin = torch.nn.functional.linear(a.float(), w.float(), b.float())
+    ref = {"bias": lin, "gelu": torch.nn.functional.gelu(lin.bfloat16().float(), approximate="tanh"),
+           "gated": res.float() + lin.bfloat16().float() * gate[sel.long()]}[epi]
+    assert rel_rms(outs[0], ref) < 4e-3

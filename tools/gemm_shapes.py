@@ -8,6 +8,7 @@ from frameino_amd import _lib, ops
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 24640
+TILE_M = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # the per-call tile height (0 = planned, 8 = 256-row tiles only, ...)
 SHAPES = [("qkv", 9216, 3072, 0), ("out-proj", 3072, 3072, 3), ("q2", 3072, 3072, 0), ("out2", 3072, 3072, 2),
           ("ffn-up", 14336, 3072, 1), ("ffn-down", 3072, 14336, 3)]
 tot = 0.0
@@ -25,7 +26,7 @@ for nm, n, k, epi in SHAPES:
         ar = torch.arange(M, device=dev)
         sel = ((ar % 2) if os.environ.get("FINO_SEL_ALT") else ((ar % 12320) >= 880)).to(torch.int32)
     out = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
-    f = lambda: ops.gemm(A, W, b, epi, res, gate, sel, out=out)
+    f = lambda: ops.gemm(A, W, b, epi, res, gate, sel, out=out, tile_m=TILE_M)
     f(); f()
     r = []
     for _ in range(7):
