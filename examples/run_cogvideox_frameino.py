@@ -137,7 +137,7 @@ def main():
         frames = np.stack([np.asarray(f) for f in video])
         assert frames.shape == (a.frames, a.height, a.width, 3) and frames.dtype == np.uint8
         cond_s = f"conditions {tc - t0:.2f} s, " if rep == 0 else ""
-        mode = ("mxfp8 linears" if a.mxfp8 else "bf16 linears") + (" + fp8 attention" if a.fp8_attention else "")
+        mode = ("mxfp8 linears" if a.mxfp8 else f"{a.dtype} linears") + (" + fp8 attention" if a.fp8_attention else "")
         print(f"{cond_s}clip ({a.frames} frames {a.height}x{a.width}, {a.steps} steps, {a.scheduler}, {mode}) {t2 - t1:.2f} s"
               f"{' (cold)' if rep == 0 and a.repeat > 1 else ''}, frames in [{frames.min()}, {frames.max()}], peak device memory "
               f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
