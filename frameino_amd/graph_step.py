@@ -125,7 +125,10 @@ def drain_collectives(wait_s=None):
         if wait is None:
             blind += 1
             continue
-        wait()
+        try:
+            wait()
+        except RuntimeError:             # a backend that does not implement it: fall back to the sleep for this group
+            blind += 1
     if blind:
         time.sleep(blind * float(os.environ.get("FINO_CAPTURE_DRAIN_S", "0.3")))
     if wait_s:
