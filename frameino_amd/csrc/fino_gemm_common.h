@@ -124,13 +124,14 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 }
 // linear raster id -> (tm, tn): groups of GROUP_M tile rows, column-major inside a group
 __device__ __forceinline__ void tile_raster(const GemmParams& p, int id, int& tm, int& tn) {
-    const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
+    const int GROUP_M = (p.group_m & 0xff) > 0 ? (p.group_m & 0xff) : 4;
     const int group = id / (GROUP_M * p.tiles_n);
     const int first_m = group * GROUP_M;
     const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
     const int in_group = id - group * GROUP_M * p.tiles_n;
     tm = first_m + in_group % gsz;
     tn = in_group / gsz;
+    if (p.group_m & 0x100) tm = p.tiles_m - 1 - tm;      // tile rows last to first (FINO_TUNE_GEMM_RASTER = 1: A/B knob)
 }
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
     tile_raster(p, xcd_remap((int)blockIdx.x, p.tiles_m * p.tiles_n), tm, tn);
