@@ -930,7 +930,10 @@ extern "C" int fino_gemm_split_n(const void* a, const void* w, const void* bias,
     // rows the producer wrote last are the ones still in the 256 MiB Infinity Cache, and a first-to-last walk evicts them before it gets
     // there.  Same bits; FFN-up + FFN-down 3373.8 -> 3340.4 us per pair at M = 24640 (tools/ffn_pair_ab.py, profiles/r06_ffn_pair_ab.txt).
     // FINO_TUNE_GEMM_RASTER: 0 = this default, 1 = last to first for every K >= 8192 (the same), 2 = first to last (rounds 1 - 5).
-    if (k >= 8192 && fino_tune_get(FINO_TUNE_GEMM_RASTER) != 2) p.group_m |= 0x100;
+    {
+        const int rk = fino_tune_get(FINO_TUNE_GEMM_RASTER);
+        if (rk == 1 || (rk == 3 && (k >= 8192 || n >= 8192)) || (rk != 2 && rk != 3 && k >= 8192)) p.group_m |= 0x100;
+    }
     if (dtype == FINO_BF16)
         return generic ? launch_gemm_e<BF16, true>(p, epilogue, tile_m, st) : launch_gemm_e<BF16, false>(p, epilogue, tile_m, st);
     return generic ? launch_gemm_e<F16, true>(p, epilogue, tile_m, st) : launch_gemm_e<F16, false>(p, epilogue, tile_m, st);

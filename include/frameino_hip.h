@@ -47,7 +47,7 @@ const char* fino_last_error(void);
 
 /* Tuning knobs for A/B timing of kernel variants inside one process (tools/): results never depend on them.
  * value 0 = the built-in default.  FINO_TUNE_GEMM_GROUP_M: tile rows per raster group of the GEMM's XCD-aware tile
- * order.  FINO_TUNE_GEMM_RASTER: 2 = long-K GEMMs (K >= 8192) walk their tile rows first to last as rounds 1 - 5 did (default since round 6: last to first, what the producer wrote last is still in the Infinity Cache).  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
+ * order.  FINO_TUNE_GEMM_RASTER: 2 = long-K GEMMs (K >= 8192) walk their tile rows first to last as rounds 1 - 5 did (default since round 6: last to first, what the producer wrote last is still in the Infinity Cache); A/B only: 1 = every GEMM last to first, 3 = long-K and wide-N (>= 8192) ones (both measured slower than the default: profiles/r06_ffn_pair_ab.txt).  FINO_TUNE_CONV_LOOP: 1 = the one-barrier conv loop instead of the
  * ping-pong one.  FINO_TUNE_GEMM_TILE_M: 2 .. 7 = one launch of 32 x that many rows per tile, 8 = 256-row tiles only (the round-2 behaviour).
  * FINO_TUNE_ATTN_KERNEL: 1 = the register-staged 8-wave ping-pong kernel everywhere, 2 = the 4-wave one-wave-per-SIMD kernel
  * (head_dim 128), 3 = the free-running kernel (4 waves, two workgroups per CU) everywhere, 4 = the LDS-DMA-staged 8-wave

@@ -20,15 +20,16 @@ pipe.scheduler.set_timesteps(50, device=dev)
 st = pipe.make_state(lat, cond, traj, idl, mask, pe.to(dev), ne.to(dev), 5.0)
 st.t_rows[1:2].copy_(pipe.scheduler.timesteps[10:11].float()); st.dt.copy_(pipe.scheduler.dts[10:11])
 lib = _lib.lib()
-res = {0: [], 2: []}
+res = {0: [], 2: [], 1: [], 3: []}
 with torch.no_grad():
-    for k in (0, 2): lib.fino_tune_set(1, k); pipe._step(st); pipe._step(st)
+    for k in (0, 2, 1, 3): lib.fino_tune_set(1, k); pipe._step(st); pipe._step(st)
     for rnd in range(5):
-        for k in (2, 0):
+        for k in (2, 0, 1, 3):
             lib.fino_tune_set(1, k)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(4): pipe._step(st)
             torch.cuda.synchronize(); res[k].append((time.perf_counter() - t0) / 4 * 1e3)
 lib.fino_tune_set(1, 0)
-for k, nm in ((2, "long-K GEMM rows first to last (rounds 1-5)"), (0, "long-K GEMM rows last to first (default)")):
+for k, nm in ((2, "long-K GEMM rows first to last (rounds 1-5)"), (0, "long-K GEMM rows last to first (default)"),
+              (1, "EVERY GEMM's rows last to first"), (3, "long-K and wide-N (>= 8192) GEMMs last to first")):
     print(f"{nm}: median {statistics.median(res[k]):.2f} ms/step ({' '.join(f'{v:.1f}' for v in res[k])})")
