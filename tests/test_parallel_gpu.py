@@ -18,11 +18,11 @@ from tests.parity import hip_wan_model, rel_rms
 pytestmark = pytest.mark.gpu
 
 
-def _pipe(dev):
+def _pipe(dev, dtype=torch.bfloat16):
     from frameino_amd.pipeline_wan_i2v_motion_frameino import WanImageToVideoPipeline
     from frameino_amd.schedulers import FlowMatchEulerDiscreteScheduler
     cfg, sd, a = load_golden("wan_pipe_tiny")
-    m = hip_wan_model(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}, dev)
+    m = hip_wan_model(cfg, {k[4:]: v for k, v in sd.items() if k.startswith("dit.")}, dev, dtype=dtype)
     return WanImageToVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(shift=5.0), transformer=m,
                                    expand_timesteps=True), a
 
@@ -33,14 +33,14 @@ def _run(pipe, a, dev):
                         d("prompt_embeds"), d("negative_embeds"), float(a["guidance"]), int(a["steps"]))
 
 
-def _worker(rank, world, port, cfg_parallel, q, mode="split", overlap_local=True, exchange="kv"):
+def _worker(rank, world, port, cfg_parallel, q, mode="split", overlap_local=True, exchange="kv", dtype=torch.bfloat16):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from frameino_amd import parallel
         from frameino_amd.parallel import shard_pipeline
         parallel.TokenShard.overlap_local = overlap_local
-        pipe, a = _pipe("cuda:0")
+        pipe, a = _pipe("cuda:0", dtype)
         plan = shard_pipeline(pipe, rank, world, cfg_parallel=cfg_parallel, mode=mode, exchange=exchange)
         out = _run(pipe, a, "cuda:0")
         q.put((rank, plan.desc, out.cpu()))
@@ -353,6 +353,33 @@ def test_capture_right_behind_eager_collectives_does_not_abort():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", _CAPTURE_STRESS, root, "12"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "STRESS OK" in p.stdout, (p.returncode, p.stderr[-2500:])
+
+
+@pytest.mark.parametrize("mode,exchange,desc", [("split", "kv", "cfg1xtoken2"), ("interleave", "kv", "token2x2branches-interleaved"),
+                                                ("interleave", "heads", "token2x2branches-interleaved-heads")])
+def test_two_ranks_on_one_gpu_in_fp16(mode, exchange, desc):
+    """round 6: the token-sharded loop with the DiT in fp16 (the dtype the reference app loads it in, app.py:156): send / receive buffers,
+    partials and the exchanges in fp16; one attention launch over the gathered keys (overlap_local off) = the unsharded arithmetic"""
+    pipe, a = _pipe("cuda:0", torch.float16)
+    pipe.batch_cfg = False
+    single = _run(pipe, a, "cuda:0").cpu()
+    del pipe
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, False, q, mode, False, exchange, torch.float16)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, d, out in outs:
+        assert d == desc
+        assert rel_rms(out, single) < 2e-3, (rank, rel_rms(out, single))          # fp16: 8x tighter than the bf16 bound
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert rel_rms(single, a["out_latents"]) < 1e-2                                 # and the fp16 loop itself sits on the reference's run
 
 
 # ---- round 6: the Wan VAE decode sharded over the ranks (parallel.sharded_vae_decode) ----
