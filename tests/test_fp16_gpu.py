@@ -20,7 +20,7 @@ import math
 import pytest
 import torch
 
-from tests.parity import bf16_state_dict, hip_wan_model, record, rel_rms
+from tests.parity import hip_wan_model, record, rel_rms
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -1,4 +1,6 @@
-import os, sys, statistics, time
+import statistics
+import sys
+import time
 sys.path.insert(0, ".")
 import torch
 from bench import build_model
